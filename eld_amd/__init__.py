@@ -1,0 +1,17 @@
+"""eld_amd -- MI355X (gfx950) native implementation of ELD's data-parallel hot path.
+
+Per-pixel physics-based noise synthesis on packed-raw Bayer tensors feeding the SID U-Net
+forward/backward, behind the reference's own plugin surface:
+
+    eld_amd.noise.NoiseModel        <->  reference noise.NoiseModel          (noise.py:175-225)
+    eld_amd.unet.unet / UNetSeeInDark <-> reference models.arch.unet          (models/arch/__init__.py:6-7)
+    eld_amd.model.ELDModel / eld_model <-> reference models.eld_model          (models/__init__.py:3-4)
+    eld_amd.engine.Engine            <->  reference engine.Engine             (engine.py:10-128)
+
+All device work goes through the C ABI of eld_amd/libeld_amd.so (include/eld_amd.h), hand-written
+HIP for gfx950.  There is no CPU fallback: if the library is missing, loading fails loudly.
+"""
+from ._lib import load_library, lib, LibraryMissing  # noqa: F401
+
+__all__ = ['load_library', 'lib', 'LibraryMissing']
+__version__ = '0.1.0'

@@ -1,0 +1,87 @@
+"""ctypes binding of include/eld_amd.h (the drop-in C ABI).  No torch types cross the ABI:
+device pointers travel as integers, the stream as the raw hipStream_t."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libeld_amd.so')
+
+# flags / enums of include/eld_amd.h
+SHOT_POISSON, SHOT_GAUSS, READ_GAUSS, READ_TL, ROW, QUANT, CBIAS, CLIP = 1, 2, 4, 8, 16, 32, 64, 128
+IN_F32, IN_U16 = 0, 1
+NPLANES = 6
+PLANE = {'counts': 0, 'n_shot': 1, 'n_read': 2, 't_tl': 3, 'n_row': 4, 'u_q': 5}
+
+# numpy mirror of struct EldNoiseParams (64 bytes)
+NOISE_PARAMS_DTYPE = np.dtype([
+    ('K', '<f4'), ('g_scale', '<f4'), ('tl_lambda', '<f4'), ('tl_scale', '<f4'), ('row_scale', '<f4'),
+    ('q_step', '<f4'), ('saturation', '<f4'), ('ratio', '<f4'), ('color_bias', '<f4', (4,)),
+    ('sample_id_lo', '<u4'), ('sample_id_hi', '<u4'), ('reserved', '<u4', (2,))])
+assert NOISE_PARAMS_DTYPE.itemsize == 64
+
+_vp, _i, _u32, _u64, _f = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_float
+
+# name -> (restype, argtypes): exactly the prototypes of include/eld_amd.h
+SIGNATURES = {
+    'eld_abi_version': (_i, []),
+    'eld_build_info': (C.c_char_p, []),
+    'eld_error_string': (C.c_char_p, [_i]),
+    'eld_noise_forward': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _u32, _u64, _vp, _vp, _vp]),
+    'eld_philox_words': (_i, [_vp, _u32, _u32, _u64, _u32, _u32, _u64, _vp]),
+    'eld_pack_bayer': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'eld_unpack_bayer': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+}
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load libeld_amd.so and bind every prototype.  Fails loudly -- there is no fallback path."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise LibraryMissing(
+            '%s not found: the HIP extension has not been built.  Run `python __graft_entry__.py` '
+            '(hipcc --offload-arch=gfx950) first; eld_amd has no CPU fallback.' % p)
+    lib_ = C.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib_, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib_.eld_abi_version() != 1:
+        raise RuntimeError('libeld_amd ABI version mismatch')
+    _lib = lib_
+    return lib_
+
+
+def lib():
+    return load_library()
+
+
+class EldError(RuntimeError):
+    pass
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().eld_error_string(int(rc)).decode()
+        raise EldError('%s failed: %s (code %d)' % (what or 'libeld_amd call', msg, rc))
+
+
+def dptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def cur_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,18 @@
+// api.hip -- ABI bookkeeping entry points of libeld_amd.so.
+#include "common.h"
+
+extern "C" int eld_abi_version(void) { return ELD_ABI_VERSION; }
+
+extern "C" const char* eld_build_info(void) {
+    return "libeld_amd gfx950 (CDNA4) HIP " __VERSION__;
+}
+
+extern "C" const char* eld_error_string(int code) {
+    switch (code) {
+        case 0: return "success";
+        case ELD_EINVAL: return "ELD_EINVAL: bad shape, flag combination or null pointer";
+        case ELD_ENOTSUP: return "ELD_ENOTSUP: not implemented in this build";
+        case ELD_EWS: return "ELD_EWS: workspace too small";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown eld_amd error";
+    }
+}

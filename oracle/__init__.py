@@ -1,0 +1,7 @@
+"""CPU oracle for the ELD hot path -- TEST INFRASTRUCTURE ONLY.
+
+Nothing under ``oracle/`` is product code.  Only ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may
+import it, and only as the checker.  The product path (``eld_amd``) never
+imports this package and fails loudly when its HIP library is missing.
+"""

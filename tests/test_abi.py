@@ -1,0 +1,92 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol the header
+declares; the host-side plugin logic (no compute) behaves like the reference's."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, 'include', 'eld_amd.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(eld_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol(eld_lib):
+    from eld_amd import _lib
+    names = header_functions()
+    assert len(names) >= 7
+    for n in names:
+        assert hasattr(eld_lib, n), 'libeld_amd.so does not export %s' % n
+        assert n in _lib.SIGNATURES, 'eld_amd/_lib.py does not bind %s' % n
+    assert sorted(_lib.SIGNATURES) == names
+    assert eld_lib.eld_abi_version() == 1
+    assert b'gfx950' in eld_lib.eld_build_info()
+    assert b'EINVAL' in eld_lib.eld_error_string(-1)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    import eld_amd
+    with pytest.raises(eld_amd.LibraryMissing):
+        eld_amd.load_library(str(tmp_path / 'nope.so'))
+
+
+def test_argument_errors_without_gpu(eld_lib):
+    # argument validation happens before any device work, so these run on a CPU-only box
+    assert eld_lib.eld_noise_forward(None, 0, None, None, -1, 4, 8, 8, 0, 0, None, None, None) == -1
+    assert eld_lib.eld_noise_forward(None, 7, None, None, 1, 4, 8, 8, 0, 0, None, None, None) == -1
+    assert eld_lib.eld_noise_forward(None, 0, None, None, 1, 4, 8, 8, 1 | 2, 0, None, None, None) == -1
+    assert eld_lib.eld_noise_forward(None, 0, None, None, 1, 3, 8, 8, 16, 0, None, None, None) == -1   # row noise needs C==4
+    assert eld_lib.eld_noise_forward(None, 0, None, None, 0, 4, 8, 8, 0, 0, None, None, None) == 0     # empty batch
+    assert eld_lib.eld_noise_forward(None, 0, None, None, 1, 4, 0, 8, 0, 0, None, None, None) == 0     # empty image
+    assert eld_lib.eld_noise_forward(None, 0, None, None, 1, 4, 8, 8, 0, 0, None, None, None) == -1    # null pointers
+
+
+def test_params_record_layout():
+    from eld_amd import _lib
+    from eld_amd.noise import NoiseParams
+    assert _lib.NOISE_PARAMS_DTYPE.itemsize == 64
+    r = NoiseParams(2.5, 6.0, 15583, 200.0, tl_lambda=-0.1, tl_scale=3.0, row_scale=0.5, color_bias=(1, 2, 3, 4)).record((7 << 32) | 9)
+    raw = np.frombuffer(r.tobytes(), dtype=np.float32)
+    assert raw[:8].tolist() == [2.5, 6.0, np.float32(-0.1), 3.0, 0.5, 1.0, 15583.0, 200.0]
+    assert raw[8:12].tolist() == [1, 2, 3, 4]
+    assert np.frombuffer(r.tobytes(), dtype=np.uint32)[12:14].tolist() == [9, 7]
+    K, g, s, ratio = NoiseParams(1.0, 2.0, 3, 4.0)            # unpacks like noise.py:225's tuple
+    assert (K, g, s, ratio) == (1.0, 2.0, 3, 4.0)
+
+
+def test_plugin_constructor_and_sample_params(golden_dir, capsys):
+    """NoiseModel ctor semantics (noise.py:175-199) and _sample_params draw order (noise.py:201-225)."""
+    from eld_amd.noise import NoiseModel, ALL_CAMERAS, model_flags
+    recs = np.load(os.path.join(golden_dir, 'sample_params.npz'))['recs']
+    i = 0
+    for inc in (None, 4, 1):
+        nm = NoiseModel(model='g', include=inc)
+        assert nm.cameras == (ALL_CAMERAS if inc is None else [ALL_CAMERAS[inc]])
+        for s in (0, 1, 2018):
+            np.random.seed(s)
+            for _ in range(3):
+                got = nm._sample_params()
+                assert np.array_equal(np.array(tuple(got), np.float64), recs[i][2:])
+                i += 1
+    out = capsys.readouterr().out
+    assert '[i] NoiseModel with camera_params/release' in out and '[i] using noise model g' in out
+    with pytest.raises(AssertionError):
+        NoiseModel(include=1, exclude=2)
+    with pytest.raises(AssertionError):
+        NoiseModel(cfa='foveon')
+    nm = NoiseModel(model='g', exclude=0)
+    assert sorted(nm.cameras) == sorted(ALL_CAMERAS[1:])
+    assert nm.model == 'g' and nm.raw_packer.cfa == 'bayer' and set(nm.camera_params) == set(nm.cameras)
+    # letter parsing: 'P' shadows 'p' (noise.py:158-160)
+    assert model_flags('Pg') == 1 | 4 and model_flags('P+g') == 1 | 4 and model_flags('pg') == 2 | 4
+    assert model_flags('Ppg') == 1 | 4 and model_flags('PGRU') == 1 | 8 | 16 | 32 and model_flags('') == 0
+    # full-model params: the reference's 4-tuple is unchanged for a given seed
+    np.random.seed(5)
+    base = NoiseModel(model='Pg', include=4)._sample_params()
+    np.random.seed(5)
+    full = NoiseModel(model='PGRU', include=4)._sample_params()
+    assert tuple(base) == tuple(full) and full.tl_scale > 0 and full.row_scale > 0 and -0.25 < full.tl_lambda < 0.25

@@ -1,0 +1,159 @@
+"""CPU tests: the oracle (oracle/*.py) against the golden vectors minted from the reference itself
+(oracle/gen_golden.py), plus the published Random123 known-answer vectors for Philox."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import noise_ref as O
+from oracle import philox_ref as px
+
+
+def test_philox_random123_kat():
+    # kat_vectors of Random123 (philox4x32, 10 rounds)
+    kats = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+            ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+            ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+             (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, exp in kats:
+        got = tuple(int(x) for x in px.philox4x32_10(*ctr, *key))
+        assert got == exp
+
+
+def test_u01_exact_complement():
+    w = np.random.default_rng(0).integers(0, 2 ** 32, size=10000, dtype=np.uint64).astype(np.uint32)
+    u, v = px.u01(w), px.u01(~w)
+    assert np.all((u > 0) & (u < 1))
+    assert np.array_equal((u.astype(np.float64) + v.astype(np.float64)), np.ones(w.shape))
+
+
+def _cases(golden_dir):
+    return sorted(f for f in glob.glob(os.path.join(golden_dir, 'noise_*_*_*.npz')) if 'default' not in f)
+
+
+def test_noise_arith_matches_reference_bit_exact(golden_dir):
+    """E-1: oracle arithmetic with the reference's own draws re-injected == reference output, all bits."""
+    files = _cases(golden_dir)
+    assert len(files) == 45
+    for f in files:
+        d = np.load(f)
+        model = str(d['model'])
+        p = O.Params.from_tuple(d['params'])
+        v = {k: d[k] for k in ('counts', 'n_shot', 'n_read') if k in d.files}
+        z = O.noise_arith(d['y'], p, O.model_flags(model), **v)
+        assert z.dtype == np.float32 and z.shape == d['z'].shape
+        assert np.array_equal(z, d['z']), f
+
+
+def test_noise_numpy_rng_replay(golden_dir):
+    """The oracle consumes the global NumPy stream in the reference's order (Poisson block, then randn)."""
+    for f in _cases(golden_dir):
+        d = np.load(f)
+        np.random.seed(int(d['np_seed']))
+        z, _ = O.noise_numpy_rng(d['y'], str(d['model']), tuple(d['params']))
+        assert np.array_equal(z, d['z']), f
+
+
+def test_noise_default_params_path(golden_dir):
+    """params=None: 5 host draws (noise.py:201-225) then the per-pixel blocks; the reference evaluates this
+    case in float64 under NumPy 2 so the float32 oracle agrees to float32 round-off."""
+    d = np.load(os.path.join(golden_dir, 'noise_default_params.npz'))
+    from eld_amd.noise import load_camera_params
+    cp = {'SonyA7S2': load_camera_params('SonyA7S2')}
+    np.random.seed(int(d['np_seed']))
+    params = O.sample_params(cp, ['SonyA7S2'])
+    assert np.allclose(params, d['params'], rtol=0, atol=0)
+    z, _ = O.noise_numpy_rng(d['y'], 'Pg', tuple(np.float32(x) for x in params))
+    assert np.max(np.abs(z.astype(np.float64) - d['z'])) < 5e-7
+
+
+def test_sample_params(golden_dir):
+    from eld_amd.noise import load_camera_params, ALL_CAMERAS
+    recs = np.load(os.path.join(golden_dir, 'sample_params.npz'))['recs']
+    cp = {c: load_camera_params(c) for c in ALL_CAMERAS}
+    i = 0
+    for inc in (None, 4, 1):
+        cams = ALL_CAMERAS if inc is None else [ALL_CAMERAS[inc]]
+        for s in (0, 1, 2018):
+            np.random.seed(s)
+            for _ in range(3):
+                got = O.sample_params(cp, cams)
+                assert recs[i][0] == (-1 if inc is None else inc) and recs[i][1] == s
+                assert np.array_equal(np.array(got, np.float64), recs[i][2:]), (inc, s)
+                i += 1
+
+
+def test_rawpacker(golden_dir):
+    d = np.load(os.path.join(golden_dir, 'rawpacker.npz'))
+    assert np.array_equal(O.pack_raw_bayer(d['mosaic']), d['packed'])
+    assert np.array_equal(O.unpack_raw_bayer(d['packed']), d['unpacked'])
+    assert np.array_equal(d['unpacked'], d['mosaic'])
+    rows = O.sensor_row_index(4, 5)
+    assert rows[0].tolist() == [0, 2, 4, 6, 8] and rows[1].tolist() == rows[0].tolist()
+    assert rows[2].tolist() == [1, 3, 5, 7, 9] and rows[3].tolist() == rows[2].tolist()
+
+
+def test_lmdb_decode_all_codes(golden_dir):
+    dec = np.load(os.path.join(golden_dir, 'lmdb_decode.npz'))['decoded']
+    codes = np.arange(65536, dtype=np.uint16)
+    assert np.array_equal(O.lmdb_decode_u16(codes), dec)
+    # the form the kernel uses: float32 true division
+    assert np.array_equal((codes.astype(np.float32) / np.float32(65535.0)).astype(np.float32), dec)
+
+
+def test_augment(golden_dir):
+    d = np.load(os.path.join(golden_dir, 'augment.npz'))
+    for i in range(d['inp'].shape[0]):
+        b = d['bits'][i]
+        ti = np.clip(O.augment(d['inp'][i], b[0], b[1], b[2]), 0, 1)       # sid_dataset.py:354
+        tt = O.augment(d['tgt'][i], b[0], b[1], b[2])
+        assert np.array_equal(ti, d['out_inp'][i]) and np.array_equal(tt, d['out_tgt'][i])
+
+
+def test_tukey_lambda_vs_scipy():
+    from scipy.stats import tukeylambda
+    u = np.linspace(0.001, 0.999, 999).astype(np.float32)
+    for lam in (0.2, 0.114285715, 0.0, -0.142857149, -0.243):
+        q = O.tukey_lambda_quantile(u, lam).astype(np.float64)
+        ref = tukeylambda.ppf(u.astype(np.float64), lam)
+        assert np.max(np.abs(q - ref) / (1 + np.abs(ref))) < 2e-5, lam
+
+
+@pytest.mark.parametrize('lam', [0.05, 1.0, 9.5, 10.5, 40.0, 1558.0])
+def test_philox_poisson_distribution(lam):
+    """E-2 on the oracle's own Philox Poisson (the statement the kernel follows): moments + chi-square."""
+    from scipy import stats
+    shape = (4, 64, 200)
+    p = O.Params(K=1.0, saturation=1.0, ratio=1.0)
+    y = np.full(shape, lam, np.float32)
+    v = O.philox_variates(shape, p, O.SHOT_POISSON, seed=7, sample_id=3, y=y)
+    k = v['counts'].reshape(-1).astype(np.int64)
+    n = k.size
+    assert abs(k.mean() - lam) < 5 * np.sqrt(lam / n) + 1e-9
+    assert abs(k.var() - lam) < 6 * lam * np.sqrt(2.0 / n) + 5 * np.sqrt(lam / n) + 1e-9
+    lo, hi = int(stats.poisson.ppf(1e-4, lam)), int(stats.poisson.ppf(1 - 1e-4, lam))
+    edges = np.arange(lo, hi + 2)
+    obs = np.histogram(np.clip(k, lo, hi), bins=edges)[0].astype(np.float64)
+    pmf = stats.poisson.pmf(np.arange(lo, hi + 1), lam)
+    pmf[0] += stats.poisson.cdf(lo - 1, lam)
+    pmf[-1] += stats.poisson.sf(hi, lam)
+    exp = pmf * n
+    keep = exp > 5
+    chi2 = ((obs[keep] - exp[keep]) ** 2 / exp[keep]).sum() + (obs[~keep].sum() - exp[~keep].sum()) ** 2 / max(exp[~keep].sum(), 1e-9) * (exp[~keep].sum() > 5)
+    dof = keep.sum()
+    assert chi2 < stats.chi2.ppf(1 - 1e-6, dof), (chi2, dof)
+
+
+def test_philox_normals_and_rows():
+    from scipy import stats
+    shape = (4, 32, 64)
+    p = O.Params(K=1.0, g_scale=1.0, row_scale=1.0, saturation=1.0, ratio=1.0)
+    v = O.philox_variates(shape, p, O.READ_GAUSS | O.ROW | O.QUANT, seed=11, sample_id=5)
+    n = v['n_read'].reshape(-1).astype(np.float64)
+    assert stats.kstest(n, 'norm').pvalue > 1e-4
+    assert stats.kstest(v['u_q'].reshape(-1).astype(np.float64), 'uniform').pvalue > 1e-4
+    nr = v['n_row']
+    assert np.all(nr == nr[:, :, :1])                        # constant along a row
+    assert np.array_equal(nr[0], nr[1]) and np.array_equal(nr[2], nr[3])     # channel pairs share the sensor row
+    assert not np.array_equal(nr[0], nr[2])
