@@ -143,13 +143,29 @@ def test_philox_variates_match_oracle(dev):
         _, v = run(y, [p], flags, seed=99, ids=[sid], dump=True)
         o = O.philox_variates(shape[1:], OP(p), flags, 99, sid, y=y[0])
         assert np.array_equal(v['u_q'][0], o['u_q'])
-        assert np.max(np.abs(v['n_read'][0] - o['n_read'])) < 2e-5
-        assert np.max(np.abs(v['n_row'][0] - o['n_row'])) < 2e-5
+        # gfx950 v_sin/v_cos/v_log vs NumPy libm: ~4e-5 absolute on N(0,1) draws, i.e. < 1e-5 of full scale
+        # once multiplied by sigma*ratio/saturation (checked on z in test_gaussian_model_z_parity)
+        assert np.max(np.abs(v['n_read'][0] - o['n_read'])) < 1e-4
+        assert np.max(np.abs(v['n_row'][0] - o['n_row'])) < 1e-4
         tl_err = np.abs(v['t_tl'][0] - o['t_tl']) / (1.0 + np.abs(o['t_tl']))
         assert np.max(tl_err) < 5e-5
         mism = np.mean(v['counts'][0] != o['counts'])
         assert mism < 2e-3, mism
         assert np.max(np.abs(v['counts'][0] - o['counts'])) <= np.maximum(3, 0.2 * np.sqrt(o['counts'].max()))
+
+
+def test_gaussian_model_z_parity(dev):
+    """Whole-sampler parity for the reference's default model 'g' under Philox: |z_hip - z_oracle| <= 1e-5
+    (BASELINE.json north_star tolerance for the floating-point part), SonyA7S2 mid-range parameters."""
+    shape = (2, 4, 64, 96)
+    y = synth(np.random.default_rng(5), shape)
+    p = P()
+    for flags in (O.READ_GAUSS, O.SHOT_GAUSS | O.READ_GAUSS, O.READ_GAUSS | O.READ_TL | O.ROW | O.QUANT):
+        pp = P(tl_lambda=-0.14285714, tl_scale=3.0, row_scale=0.5)
+        z = run(y, [pp, pp], flags, seed=4, ids=[8, 9])
+        for i in range(2):
+            zo, _ = O.noise_philox(y[i], OP(pp), flags, 4, 8 + i)
+            assert np.max(np.abs(z[i] - zo)) <= 1e-5, (flags, np.max(np.abs(z[i] - zo)))
 
 
 # ------------------------------------------------------------------------------------------ E-3
