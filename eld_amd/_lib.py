@@ -21,7 +21,7 @@ NOISE_PARAMS_DTYPE = np.dtype([
     ('sample_id_lo', '<u4'), ('sample_id_hi', '<u4'), ('reserved', '<u4', (2,))])
 assert NOISE_PARAMS_DTYPE.itemsize == 64
 
-_vp, _i, _u32, _u64, _f = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_float
+_vp, _i, _u32, _u64, _f, _d, _sz = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_float, C.c_double, C.c_size_t
 
 # name -> (restype, argtypes): exactly the prototypes of include/eld_amd.h
 SIGNATURES = {
@@ -32,6 +32,22 @@ SIGNATURES = {
     'eld_philox_words': (_i, [_vp, _u32, _u32, _u64, _u32, _u32, _u64, _vp]),
     'eld_pack_bayer': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'eld_unpack_bayer': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'eld_unet_param_offsets': (_i, [_i, _i, _vp]),
+    'eld_unet_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
+    'eld_unet_forward': (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
+    'eld_unet_backward': (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
+    'eld_l1_workspace_bytes': (_sz, []),
+    'eld_l1_loss': (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _f, _vp]),
+    'eld_adam_step': (_i, [_vp, _vp, _vp, _vp, _sz, _d, _d, _d, _d, _d, _i, _d, _vp]),
+    'eld_layer_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
+    'eld_conv3x3_forward': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'eld_conv3x3_backward_data': (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'eld_conv3x3_backward_weight': (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'eld_convt2x2_forward': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'eld_convt2x2_backward_data': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'eld_convt2x2_backward_weight': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    'eld_maxpool2x2_forward': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    'eld_maxpool2x2_backward': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
 }
 
 

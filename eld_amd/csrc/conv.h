@@ -1,0 +1,60 @@
+// conv.h -- argument records and launchers of the U-Net convolution kernels (internal; gfx950).
+//
+// Activations are NHWC float32 in HBM (channel-contiguous: the GEMM K dimension of the implicit
+// GEMM is contiguous, a 32-channel pixel is one 128-byte line).  All three convolution flavours of
+// the U-Net (3x3 s1 p1, 1x1, and the 2x2 stride-2 transposed conv in both directions) are one
+// implicit-GEMM kernel family on the exact-fp32 MFMA v_mfma_f32_32x32x2_f32:
+//      D[pixel][n] = sum_{tap, c} A_tap[pixel][c] * Wp[tap][n][c]
+#pragma once
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum ConvMode { CONV_3X3 = 0, CONV_1X1 = 1, CONV_GATHER2X2 = 2 };
+enum ConvEpi { EPI_FWD = 0, EPI_CONVT_FWD = 1, EPI_GRAD = 2 };
+
+struct ConvArgs {
+    const float* in0;   // NHWC source 0 (C0 channels)
+    const float* in1;   // NHWC source 1 (C1 channels) -- virtual channel concat [in0, in1]; may be null
+    int C0, C1;
+    const float* wp;    // packed weights [taps][Nout][C0+C1], c contiguous
+    int N, H, W;        // tile domain: output pixels (3x3 / 1x1) or input-resolution pixels (gather: source is 2H x 2W)
+    int Nout;           // GEMM N
+    int epi;
+    const float* bias;  // EPI_FWD: [Nout]; EPI_CONVT_FWD: [Cout_t]
+    int lrelu;          // EPI_FWD: apply max(0.2v, v)
+    float* out0;        // EPI_FWD/CONVT: destination.  EPI_GRAD: channels [0, split)
+    float* out1;        // EPI_GRAD: channels [split, Nout)
+    int split;
+    const float* act0;  // EPI_GRAD: saved post-activation tensor (layout of out0) -> multiply by lrelu slope; may be null
+    const float* act1;
+    int Cout_t;         // EPI_CONVT_FWD: real Cout (Nout = 4*Cout_t, n = tap*Cout_t + co)
+    int tiles_x, tiles_y;
+};
+
+// d/dx max(0.2x, x) as autograd computes it for torch.max(0.2*x, x) (models/arch/Unet.py:102-104):
+// ties (x == 0) split the gradient evenly between the two branches -> 0.6.  The saved tensor is the
+// post-activation value, whose sign equals the pre-activation's.
+__device__ __forceinline__ float lrelu_slope(float y) { return y > 0.f ? 1.0f : (y < 0.f ? 0.2f : 0.6f); }
+
+int launch_conv(const ConvArgs& a, int mode, hipStream_t st);
+
+// dW-type reduction:  P[tap][i][j] = sum_pixels G[pixel][i] * X[pixel (+) tap][j]
+struct WgradArgs {
+    const float* g;      // NHWC, CA channels, unshifted (the A operand)
+    int CA;
+    const float* x0;     // NHWC sources of the shifted/gathered operand (virtual concat)
+    const float* x1;
+    int C0, C1;          // C0 + C1 = CB (may be smaller than the padded j extent)
+    int N, H, W;         // pixel domain of g
+    float* part;         // partials [psplit][taps][CA][CBp]
+    float* bpart;        // optional bias partials [psplit][CA] (sum over pixels of g); null to skip
+    int CBp;             // padded CB (multiple of 32)
+    int psplit;
+    int tiles_x, tiles_y;
+};
+
+int launch_wgrad(const WgradArgs& a, int mode, hipStream_t st);
+// out[(i*CBr + j)*T + tap] = sum_s part[s][tap][i][j]   (OIHW / (Cin,Cout,2,2) layouts);  bgrad[i] = sum_s bpart[s][i]
+int launch_wgrad_reduce(const float* part, const float* bpart, float* wgrad, float* bgrad, int psplit, int T, int CA,
+                        int CBp, int CBr, hipStream_t st);

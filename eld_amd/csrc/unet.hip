@@ -1,0 +1,437 @@
+// unet.hip -- host-side orchestration of the SID U-Net forward / backward over the HIP kernels, and
+// the C-ABI entry points of include/eld_amd.h for it.  No allocation, no synchronisation: every launch
+// goes to the caller's stream and all scratch comes out of the caller's workspace, so a whole training
+// step is one stream-ordered chain (hipGraph-capturable).
+//
+// Network (models/arch/Unet.py:6-91): 5 scales, channels 32/64/128/256/512, 18 conv3x3+LeakyReLU,
+// 4 maxpool2, 4 transposed conv 2x2/s2, 4 channel concats [up, skip] (never materialised: the conv
+// kernels read two sources), 1x1 head.
+#include <math.h>
+#include "unet_misc.h"
+
+namespace {
+
+constexpr int NLEV = 5;
+inline int chan(int l) { return 32 << l; }
+
+struct LayerDef {
+    int kind;        // 0 conv3x3, 1 convT2x2, 2 head 1x1
+    int cin, cout;
+    size_t w_off, b_off;      // flat parameter offsets (floats)
+};
+
+// layer order == named_parameters() order of the reference module
+enum {
+    L_E0A = 0, L_E0B, L_E1A, L_E1B, L_E2A, L_E2B, L_E3A, L_E3B, L_E4A, L_E4B,
+    L_UP3, L_D3A, L_D3B, L_UP2, L_D2A, L_D2B, L_UP1, L_D1A, L_D1B, L_UP0, L_D0A, L_D0B, L_HEAD, NLAYERS
+};
+
+size_t build_layers(int in_ch, int out_ch, LayerDef* L) {
+    int k = 0;
+    for (int l = 0; l < NLEV; ++l) {
+        L[k++] = {0, l == 0 ? in_ch : chan(l - 1), chan(l), 0, 0};
+        L[k++] = {0, chan(l), chan(l), 0, 0};
+    }
+    for (int l = 3; l >= 0; --l) {
+        L[k++] = {1, chan(l + 1), chan(l), 0, 0};
+        L[k++] = {0, 2 * chan(l), chan(l), 0, 0};
+        L[k++] = {0, chan(l), chan(l), 0, 0};
+    }
+    L[k++] = {2, 32, out_ch, 0, 0};
+    size_t off = 0;
+    for (int i = 0; i < NLAYERS; ++i) {
+        const size_t taps = L[i].kind == 0 ? 9 : (L[i].kind == 1 ? 4 : 1);
+        L[i].w_off = off; off += (size_t)L[i].cin * L[i].cout * taps;
+        L[i].b_off = off; off += L[i].cout;
+    }
+    return off;
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+int choose_psplit(int groups, int ntiles) {
+    int ps = 512 / groups;
+    if (ps < 1) ps = 1;
+    if (ps > ntiles) ps = ntiles;
+    if (ps < 1) ps = 1;
+    return ps;
+}
+
+struct WgradGeom { int T, CA, CBp, groups, ntiles, psplit; size_t floats; };
+
+WgradGeom wgrad_geom(int mode, int CA, int CB, int N, int H, int W) {
+    WgradGeom g;
+    g.T = mode == CONV_3X3 ? 9 : 4;
+    g.CA = CA;
+    g.CBp = (CB + 31) / 32 * 32;
+    const int COB = (CA % 64 == 0) ? 64 : 32;
+    const int TH = mode == CONV_3X3 ? 4 : 2;
+    g.groups = (CA / COB) * (g.CBp / 32);
+    g.ntiles = ((W + 31) / 32) * ((H + TH - 1) / TH) * N;
+    g.psplit = choose_psplit(g.groups, g.ntiles);
+    g.floats = (size_t)g.psplit * ((size_t)g.T * CA * g.CBp + CA);
+    return g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// layer helpers on packed weights
+// ------------------------------------------------------------------------------------------------
+int conv_fwd(const float* in0, int C0, const float* in1, int C1, const float* wp, const float* bias, float* out, int N, int H, int W,
+             int Cout, int lrelu, hipStream_t st) {
+    ConvArgs a = {};
+    a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1; a.wp = wp; a.N = N; a.H = H; a.W = W; a.Nout = Cout;
+    a.epi = EPI_FWD; a.bias = bias; a.lrelu = lrelu; a.out0 = out;
+    return launch_conv(a, CONV_3X3, st);
+}
+
+// g: [N,H,W,Cout] -> din (Cin channels, split over out0/out1), wb packed [9][Cin][Cout]
+int conv_bwd_data(const float* g, const float* wb, float* out0, float* out1, int split, const float* act0, const float* act1, int N, int H,
+                  int W, int Cin, int Cout, hipStream_t st) {
+    ConvArgs a = {};
+    a.in0 = g; a.C0 = Cout; a.wp = wb; a.N = N; a.H = H; a.W = W; a.Nout = Cin;
+    a.epi = EPI_GRAD; a.out0 = out0; a.out1 = out1; a.split = split; a.act0 = act0; a.act1 = act1;
+    return launch_conv(a, CONV_3X3, st);
+}
+
+int conv_wgrad(const float* g, int Cout, const float* x0, int C0, const float* x1, int C1, int Cin_real, float* dw, float* db, float* part,
+               int N, int H, int W, hipStream_t st) {
+    const WgradGeom q = wgrad_geom(CONV_3X3, Cout, C0 + C1, N, H, W);
+    WgradArgs a = {};
+    a.g = g; a.CA = Cout; a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.N = N; a.H = H; a.W = W;
+    a.part = part; a.bpart = db ? part + (size_t)q.psplit * q.T * q.CA * q.CBp : nullptr; a.CBp = q.CBp; a.psplit = q.psplit;
+    int rc = launch_wgrad(a, CONV_3X3, st);
+    if (rc) return rc;
+    return launch_wgrad_reduce(part, a.bpart, dw, db, q.psplit, q.T, q.CA, q.CBp, Cin_real, st);
+}
+
+// in [N,H,W,Cin] -> out [N,2H,2W,Cout]; wf packed [4*Cout][Cin]
+int convt_fwd(const float* in, const float* wf, const float* bias, float* out, int N, int H, int W, int Cin, int Cout, hipStream_t st) {
+    ConvArgs a = {};
+    a.in0 = in; a.C0 = Cin; a.wp = wf; a.N = N; a.H = H; a.W = W; a.Nout = 4 * Cout;
+    a.epi = EPI_CONVT_FWD; a.bias = bias; a.out0 = out; a.Cout_t = Cout;
+    return launch_conv(a, CONV_1X1, st);
+}
+
+// dout [N,2H,2W,Cout] -> din [N,H,W,Cin] (times slope(act) if act); wb packed [4][Cin][Cout]
+int convt_bwd_data(const float* dout, const float* wb, const float* act, float* din, int N, int H, int W, int Cin, int Cout, hipStream_t st) {
+    ConvArgs a = {};
+    a.in0 = dout; a.C0 = Cout; a.wp = wb; a.N = N; a.H = H; a.W = W; a.Nout = Cin;
+    a.epi = EPI_GRAD; a.out0 = din; a.split = Cin; a.act0 = act;
+    return launch_conv(a, CONV_GATHER2X2, st);
+}
+
+// dw[ci][co][tap] = sum in[p][ci] * dout[gather(p,tap)][co];  db[co] = column sums of dout
+int convt_wgrad(const float* in, const float* dout, float* dw, float* db, float* part, int N, int H, int W, int Cin, int Cout, hipStream_t st) {
+    const WgradGeom q = wgrad_geom(CONV_GATHER2X2, Cin, Cout, N, H, W);
+    WgradArgs a = {};
+    a.g = in; a.CA = Cin; a.x0 = dout; a.C0 = Cout; a.N = N; a.H = H; a.W = W;
+    a.part = part; a.bpart = nullptr; a.CBp = q.CBp; a.psplit = q.psplit;
+    int rc = launch_wgrad(a, CONV_GATHER2X2, st);
+    if (rc) return rc;
+    rc = launch_wgrad_reduce(part, nullptr, dw, nullptr, q.psplit, q.T, q.CA, q.CBp, Cout, st);
+    if (rc || !db) return rc;
+    return launch_colsum(dout, db, part, (size_t)N * 4 * H * W, Cout, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace plan
+// ------------------------------------------------------------------------------------------------
+struct Plan {
+    LayerDef L[NLAYERS];
+    size_t nparams;
+    int N, H, W, in_ch, out_ch;
+    int Hl[NLEV], Wl[NLEV];
+    // offsets in floats
+    size_t wp_fwd[NLAYERS], wp_bwd[NLAYERS];
+    size_t x16, ea[NLEV], eb[NLEV], pool[NLEV - 1], up[NLEV - 1], da[NLEV - 1], db[NLEV - 1];
+    size_t gA, gB, skip[NLEV - 1], part;
+    size_t total;     // floats
+};
+
+int make_plan(Plan& P, int N, int H, int W, int in_ch, int out_ch) {
+    if (N < 1 || H < 16 || W < 16 || (H % 16) || (W % 16)) return ELD_EINVAL;     // 4 pool levels (Unet.py:51-63)
+    if (in_ch < 1 || in_ch > 16 || out_ch < 1 || out_ch > 4) return ELD_ENOTSUP;
+    P.N = N; P.H = H; P.W = W; P.in_ch = in_ch; P.out_ch = out_ch;
+    P.nparams = build_layers(in_ch, out_ch, P.L);
+    for (int l = 0; l < NLEV; ++l) { P.Hl[l] = H >> l; P.Wl[l] = W >> l; }
+    size_t off = 0;
+    auto take = [&](size_t n) { const size_t o = off; off += align_up(n, 64); return o; };   // 256-byte aligned
+    for (int i = 0; i < NLAYERS; ++i) {
+        const LayerDef& d = P.L[i];
+        if (d.kind == 0) {
+            const int cinp = (d.cin + 15) / 16 * 16;
+            P.wp_fwd[i] = take((size_t)9 * d.cout * cinp);
+            P.wp_bwd[i] = (i == L_E0A) ? 0 : take((size_t)9 * d.cin * d.cout);
+        } else if (d.kind == 1) {
+            P.wp_fwd[i] = take((size_t)4 * d.cout * d.cin);
+            P.wp_bwd[i] = take((size_t)4 * d.cin * d.cout);
+        } else {
+            P.wp_fwd[i] = P.wp_bwd[i] = 0;
+        }
+    }
+    auto act = [&](int l, int c) { return (size_t)N * P.Hl[l] * P.Wl[l] * c; };
+    P.x16 = take(act(0, 16));
+    for (int l = 0; l < NLEV; ++l) { P.ea[l] = take(act(l, chan(l))); P.eb[l] = take(act(l, chan(l))); }
+    for (int l = 0; l < NLEV - 1; ++l) {
+        P.pool[l] = take(act(l + 1, chan(l)));
+        P.up[l] = take(act(l, chan(l)));
+        P.da[l] = take(act(l, chan(l)));
+        P.db[l] = take(act(l, chan(l)));
+        P.skip[l] = take(act(l, chan(l)));
+    }
+    P.gA = take(act(0, 32));
+    P.gB = take(act(0, 32));
+    size_t pmax = head_bwd_ws_floats();
+    pmax = pmax > colsum_ws_floats(256) ? pmax : colsum_ws_floats(256);
+    for (int i = 0; i < NLAYERS; ++i) {
+        const LayerDef& d = P.L[i];
+        int lev;
+        if (i <= L_E4B) lev = i / 2; else if (i < L_HEAD) lev = 3 - (i - L_UP3) / 3; else lev = 0;
+        size_t f = 0;
+        if (d.kind == 0) f = wgrad_geom(CONV_3X3, d.cout, i == L_E0A ? 16 : d.cin, N, P.Hl[lev], P.Wl[lev]).floats;
+        else if (d.kind == 1) f = wgrad_geom(CONV_GATHER2X2, d.cin, d.cout, N, P.Hl[lev + 1], P.Wl[lev + 1]).floats;
+        pmax = f > pmax ? f : pmax;
+    }
+    P.part = take(pmax);
+    P.total = off;
+    return 0;
+}
+
+int pack_weights(const Plan& P, const float* params, float* ws, bool for_backward, hipStream_t st) {
+    for (int i = 0; i < NLAYERS; ++i) {
+        const LayerDef& d = P.L[i];
+        int rc = 0;
+        if (d.kind == 0) {
+            const int cinp = (d.cin + 15) / 16 * 16;
+            if (!for_backward) rc = launch_pack(params + d.w_off, ws + P.wp_fwd[i], PACK_CONV_FWD, d.cout, d.cin, cinp, 9, st);
+            else if (i != L_E0A) rc = launch_pack(params + d.w_off, ws + P.wp_bwd[i], PACK_CONV_BWD, d.cout, d.cin, d.cin, 9, st);
+        } else if (d.kind == 1) {
+            if (!for_backward) rc = launch_pack(params + d.w_off, ws + P.wp_fwd[i], PACK_CONVT_FWD, d.cout, d.cin, d.cin, 4, st);
+            else rc = launch_pack(params + d.w_off, ws + P.wp_bwd[i], PACK_CONVT_BWD, d.cout, d.cin, d.cin, 4, st);
+        }
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+#define RC(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
+
+int unet_forward(const Plan& P, const float* x, const float* prm, float* out, float* ws, hipStream_t st) {
+    const int N = P.N;
+    RC(pack_weights(P, prm, ws, false, st));
+    RC(launch_nchw_to_nhwc16(x, ws + P.x16, N, P.in_ch, P.H, P.W, st));
+    for (int l = 0; l < NLEV; ++l) {
+        const LayerDef& A = P.L[2 * l]; const LayerDef& B = P.L[2 * l + 1];
+        const float* src = l == 0 ? ws + P.x16 : ws + P.pool[l - 1];
+        const int cin = l == 0 ? 16 : chan(l - 1);
+        RC(conv_fwd(src, cin, nullptr, 0, ws + P.wp_fwd[2 * l], prm + A.b_off, ws + P.ea[l], N, P.Hl[l], P.Wl[l], chan(l), 1, st));
+        RC(conv_fwd(ws + P.ea[l], chan(l), nullptr, 0, ws + P.wp_fwd[2 * l + 1], prm + B.b_off, ws + P.eb[l], N, P.Hl[l], P.Wl[l], chan(l), 1, st));
+        if (l < NLEV - 1) RC(launch_maxpool_fwd(ws + P.eb[l], ws + P.pool[l], N, P.Hl[l + 1], P.Wl[l + 1], chan(l), st));
+    }
+    for (int l = 3; l >= 0; --l) {
+        const int iu = L_UP3 + 3 * (3 - l);
+        const float* src = l == 3 ? ws + P.eb[4] : ws + P.db[l + 1];
+        RC(convt_fwd(src, ws + P.wp_fwd[iu], prm + P.L[iu].b_off, ws + P.up[l], N, P.Hl[l + 1], P.Wl[l + 1], chan(l + 1), chan(l), st));
+        RC(conv_fwd(ws + P.up[l], chan(l), ws + P.eb[l], chan(l), ws + P.wp_fwd[iu + 1], prm + P.L[iu + 1].b_off, ws + P.da[l], N, P.Hl[l], P.Wl[l], chan(l), 1, st));
+        RC(conv_fwd(ws + P.da[l], chan(l), nullptr, 0, ws + P.wp_fwd[iu + 2], prm + P.L[iu + 2].b_off, ws + P.db[l], N, P.Hl[l], P.Wl[l], chan(l), 1, st));
+    }
+    const LayerDef& Hd = P.L[L_HEAD];
+    RC(launch_head_fwd(ws + P.db[0], prm + Hd.w_off, prm + Hd.b_off, out, N, P.H, P.W, P.out_ch, st));
+    return 0;
+}
+
+int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd, float* ws, hipStream_t st) {
+    const int N = P.N;
+    RC(pack_weights(P, prm, ws, true, st));
+    float* gA = ws + P.gA; float* gB = ws + P.gB; float* part = ws + P.part;
+    const LayerDef& Hd = P.L[L_HEAD];
+    // head: g (pre-activation grad of conv9_2) -> gA
+    RC(launch_head_bwd(dout, ws + P.db[0], prm + Hd.w_off, gA, grd + Hd.w_off, grd + Hd.b_off, part, N, P.H, P.W, P.out_ch, st));
+    float* cur = gA; float* oth = gB;
+    for (int l = 0; l <= 3; ++l) {            // decoder levels 0 (conv9) .. 3 (conv6)
+        const int iu = L_UP3 + 3 * (3 - l);
+        const int H = P.Hl[l], W = P.Wl[l], C = chan(l);
+        // conv_2 of the level: input da[l]
+        RC(conv_wgrad(cur, C, ws + P.da[l], C, nullptr, 0, C, grd + P.L[iu + 2].w_off, grd + P.L[iu + 2].b_off, part, N, H, W, st));
+        RC(conv_bwd_data(cur, ws + P.wp_bwd[iu + 2], oth, nullptr, C, ws + P.da[l], nullptr, N, H, W, C, C, st));
+        { float* t = cur; cur = oth; oth = t; }
+        // conv_1: input cat[up[l], eb[l]] -> d_up (raw) in oth, skip grad (raw) in skip[l]
+        RC(conv_wgrad(cur, C, ws + P.up[l], C, ws + P.eb[l], C, 2 * C, grd + P.L[iu + 1].w_off, grd + P.L[iu + 1].b_off, part, N, H, W, st));
+        RC(conv_bwd_data(cur, ws + P.wp_bwd[iu + 1], oth, ws + P.skip[l], C, nullptr, nullptr, N, H, W, 2 * C, C, st));
+        { float* t = cur; cur = oth; oth = t; }
+        // transposed conv: input src (level l+1, 2C channels), output grad = cur (d_up)
+        const float* src = l == 3 ? ws + P.eb[4] : ws + P.db[l + 1];
+        RC(convt_wgrad(src, cur, grd + P.L[iu].w_off, grd + P.L[iu].b_off, part, N, P.Hl[l + 1], P.Wl[l + 1], 2 * C, C, st));
+        RC(convt_bwd_data(cur, ws + P.wp_bwd[iu], src, oth, N, P.Hl[l + 1], P.Wl[l + 1], 2 * C, C, st));
+        { float* t = cur; cur = oth; oth = t; }
+    }
+    // cur = pre-activation grad of conv5_2 (level 4)
+    for (int l = 4; l >= 0; --l) {
+        const int H = P.Hl[l], W = P.Wl[l], C = chan(l);
+        const int ia = 2 * l, ib = 2 * l + 1;
+        RC(conv_wgrad(cur, C, ws + P.ea[l], C, nullptr, 0, C, grd + P.L[ib].w_off, grd + P.L[ib].b_off, part, N, H, W, st));
+        RC(conv_bwd_data(cur, ws + P.wp_bwd[ib], oth, nullptr, C, ws + P.ea[l], nullptr, N, H, W, C, C, st));
+        { float* t = cur; cur = oth; oth = t; }
+        if (l == 0) {
+            RC(conv_wgrad(cur, C, ws + P.x16, 16, nullptr, 0, P.in_ch, grd + P.L[ia].w_off, grd + P.L[ia].b_off, part, N, H, W, st));
+            break;
+        }
+        const int Cp = chan(l - 1);
+        RC(conv_wgrad(cur, C, ws + P.pool[l - 1], Cp, nullptr, 0, Cp, grd + P.L[ia].w_off, grd + P.L[ia].b_off, part, N, H, W, st));
+        RC(conv_bwd_data(cur, ws + P.wp_bwd[ia], oth, nullptr, Cp, nullptr, nullptr, N, H, W, Cp, C, st));      // d_pool (raw)
+        { float* t = cur; cur = oth; oth = t; }
+        RC(launch_maxpool_bwd(ws + P.eb[l - 1], cur, ws + P.skip[l - 1], oth, N, H, W, Cp, st));
+        { float* t = cur; cur = oth; oth = t; }
+    }
+    return 0;
+}
+
+}  // namespace
+
+// ====================================================================================================
+// C ABI
+// ====================================================================================================
+extern "C" int eld_unet_param_offsets(int in_ch, int out_ch, int64_t* offsets) {
+    if (!offsets || in_ch < 1 || in_ch > 16 || out_ch < 1 || out_ch > 4) return ELD_EINVAL;
+    LayerDef L[NLAYERS];
+    const size_t n = build_layers(in_ch, out_ch, L);
+    for (int i = 0; i < NLAYERS; ++i) { offsets[2 * i] = (int64_t)L[i].w_off; offsets[2 * i + 1] = (int64_t)L[i].b_off; }
+    offsets[ELD_UNET_NTENSORS] = (int64_t)n;
+    return 0;
+}
+
+extern "C" size_t eld_unet_workspace_bytes(int N, int H, int W, int in_ch, int out_ch) {
+    Plan P;
+    if (make_plan(P, N, H, W, in_ch, out_ch)) return 0;
+    return P.total * sizeof(float);
+}
+
+extern "C" int eld_unet_forward(const float* x, const float* params, float* out, void* ws, size_t ws_bytes, int N, int H, int W,
+                                int in_ch, int out_ch, void* stream) {
+    if (N == 0) return 0;
+    Plan P;
+    RC(make_plan(P, N, H, W, in_ch, out_ch));
+    if (!x || !params || !out || !ws) return ELD_EINVAL;
+    if (ws_bytes < P.total * sizeof(float)) return ELD_EWS;
+    return unet_forward(P, x, params, out, (float*)ws, as_stream(stream));
+}
+
+extern "C" int eld_unet_backward(const float* dout, const float* params, float* grads, void* ws, size_t ws_bytes, int N, int H, int W,
+                                 int in_ch, int out_ch, void* stream) {
+    if (N == 0) return 0;
+    Plan P;
+    RC(make_plan(P, N, H, W, in_ch, out_ch));
+    if (!dout || !params || !grads || !ws) return ELD_EINVAL;
+    if (ws_bytes < P.total * sizeof(float)) return ELD_EWS;
+    return unet_backward(P, dout, params, grads, (float*)ws, as_stream(stream));
+}
+
+extern "C" size_t eld_l1_workspace_bytes(void) { return l1_ws_floats() * sizeof(float); }
+
+extern "C" int eld_l1_loss(const float* out, const float* target, float* dout, float* loss, void* ws, size_t n, float grad_scale, void* stream) {
+    if (!out || !target || !loss || !ws || n == 0) return ELD_EINVAL;
+    return launch_l1(out, target, dout, loss, (float*)ws, n, grad_scale, as_stream(stream));
+}
+
+extern "C" int eld_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1,
+                             double beta2, double eps, double weight_decay, int step, double grad_scale, void* stream) {
+    if (n == 0) return 0;
+    if (!params || !grads || !exp_avg || !exp_avg_sq || step < 1) return ELD_EINVAL;
+    return launch_adam(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, as_stream(stream));
+}
+
+// ---- single layers -----------------------------------------------------------------------------------
+extern "C" size_t eld_layer_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
+    if (N < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return 0;
+    const int cinp = (Cin + 15) / 16 * 16;
+    size_t f = (size_t)9 * Cout * cinp + 64;                                // one packed weight set
+    size_t p = 0, q;
+    if (Cout % 32 == 0) { q = wgrad_geom(CONV_3X3, Cout, Cin, N, H, W).floats; p = q > p ? q : p; }
+    if (Cin % 32 == 0) { q = wgrad_geom(CONV_GATHER2X2, Cin, Cout, N, H, W).floats; p = q > p ? q : p; }
+    q = colsum_ws_floats(Cout > Cin ? Cout : Cin); p = q > p ? q : p;
+    return (align_up(f, 64) + align_up(p, 64)) * sizeof(float);
+}
+
+static int layer_ws(void* ws, size_t ws_bytes, int N, int H, int W, int Cin, int Cout, float** pack, float** part) {
+    const size_t need = eld_layer_workspace_bytes(N, H, W, Cin, Cout);
+    if (!ws || need == 0) return ELD_EINVAL;
+    if (ws_bytes < need) return ELD_EWS;
+    const int cinp = (Cin + 15) / 16 * 16;
+    *pack = (float*)ws;
+    *part = (float*)ws + align_up((size_t)9 * Cout * cinp + 64, 64);
+    return 0;
+}
+
+extern "C" int eld_conv3x3_forward(const float* in0, int C0, const float* in1, int C1, const float* w, const float* bias, float* out, int N,
+                                   int H, int W, int Cout, int lrelu, void* ws, size_t ws_bytes, void* stream) {
+    if (N == 0) return 0;
+    if (!in0 || !w || !bias || !out || (C0 + C1) % 16 || C0 % 16 || Cout % 32) return ELD_EINVAL;
+    float *pack, *part;
+    RC(layer_ws(ws, ws_bytes, N, H, W, C0 + C1, Cout, &pack, &part));
+    hipStream_t st = as_stream(stream);
+    RC(launch_pack(w, pack, PACK_CONV_FWD, Cout, C0 + C1, C0 + C1, 9, st));
+    return conv_fwd(in0, C0, in1, C1, pack, bias, out, N, H, W, Cout, lrelu, st);
+}
+
+extern "C" int eld_conv3x3_backward_data(const float* g, const float* w, float* din0, float* din1, int split, const float* act0, const float* act1,
+                                         int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    if (N == 0) return 0;
+    if (!g || !w || !din0 || Cin % 32 || Cout % 16 || split % 32 || split > Cin || (split < Cin && !din1)) return ELD_EINVAL;
+    float *pack, *part;
+    RC(layer_ws(ws, ws_bytes, N, H, W, Cin, Cout, &pack, &part));
+    hipStream_t st = as_stream(stream);
+    RC(launch_pack(w, pack, PACK_CONV_BWD, Cout, Cin, Cin, 9, st));
+    return conv_bwd_data(g, pack, din0, din1, split, act0, act1, N, H, W, Cin, Cout, st);
+}
+
+extern "C" int eld_conv3x3_backward_weight(const float* g, const float* x0, int C0, const float* x1, int C1, float* dw, float* db, int N, int H,
+                                           int W, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    if (N == 0) return 0;
+    if (!g || !x0 || !dw || Cout % 32 || C0 % 4 || C1 % 4) return ELD_EINVAL;
+    float *pack, *part;
+    RC(layer_ws(ws, ws_bytes, N, H, W, C0 + C1, Cout, &pack, &part));
+    return conv_wgrad(g, Cout, x0, C0, x1, C1, C0 + C1, dw, db, part, N, H, W, as_stream(stream));
+}
+
+extern "C" int eld_convt2x2_forward(const float* in, const float* w, const float* bias, float* out, int N, int H, int W, int Cin, int Cout,
+                                    void* ws, size_t ws_bytes, void* stream) {
+    if (N == 0) return 0;
+    if (!in || !w || !bias || !out || Cin % 16 || Cout % 8) return ELD_EINVAL;
+    float *pack, *part;
+    RC(layer_ws(ws, ws_bytes, N, H, W, Cin, Cout, &pack, &part));
+    hipStream_t st = as_stream(stream);
+    RC(launch_pack(w, pack, PACK_CONVT_FWD, Cout, Cin, Cin, 4, st));
+    return convt_fwd(in, pack, bias, out, N, H, W, Cin, Cout, st);
+}
+
+extern "C" int eld_convt2x2_backward_data(const float* dout, const float* w, const float* act, float* din, int N, int H, int W, int Cin, int Cout,
+                                          void* ws, size_t ws_bytes, void* stream) {
+    if (N == 0) return 0;
+    if (!dout || !w || !din || Cin % 32 || Cout % 16) return ELD_EINVAL;
+    float *pack, *part;
+    RC(layer_ws(ws, ws_bytes, N, H, W, Cin, Cout, &pack, &part));
+    hipStream_t st = as_stream(stream);
+    RC(launch_pack(w, pack, PACK_CONVT_BWD, Cout, Cin, Cin, 4, st));
+    return convt_bwd_data(dout, pack, act, din, N, H, W, Cin, Cout, st);
+}
+
+extern "C" int eld_convt2x2_backward_weight(const float* in, const float* dout, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
+                                            void* ws, size_t ws_bytes, void* stream) {
+    if (N == 0) return 0;
+    if (!in || !dout || !dw || Cin % 32 || Cout % 4) return ELD_EINVAL;
+    float *pack, *part;
+    RC(layer_ws(ws, ws_bytes, N, H, W, Cin, Cout, &pack, &part));
+    return convt_wgrad(in, dout, dw, db, part, N, H, W, Cin, Cout, as_stream(stream));
+}
+
+extern "C" int eld_maxpool2x2_forward(const float* in, float* out, int N, int Ho, int Wo, int C, void* stream) {
+    if (N == 0) return 0;
+    if (!in || !out || C % 4) return ELD_EINVAL;
+    return launch_maxpool_fwd(in, out, N, Ho, Wo, C, as_stream(stream));
+}
+
+extern "C" int eld_maxpool2x2_backward(const float* act, const float* dp, const float* skip, float* g, int N, int Ho, int Wo, int C, void* stream) {
+    if (N == 0) return 0;
+    if (!act || !dp || !g || C % 4) return ELD_EINVAL;
+    return launch_maxpool_bwd(act, dp, skip, g, N, Ho, Wo, C, as_stream(stream));
+}

@@ -1,0 +1,20 @@
+// unet_misc.h -- launchers of the HBM-bound U-Net step kernels (internal).
+#pragma once
+#include "conv.h"
+
+enum PackKind { PACK_CONV_FWD = 0, PACK_CONV_BWD = 1, PACK_CONVT_FWD = 2, PACK_CONVT_BWD = 3 };
+
+int launch_nchw_to_nhwc16(const float* x, float* y, int N, int C, int H, int W, hipStream_t st);
+int launch_maxpool_fwd(const float* in, float* out, int N, int Ho, int Wo, int C, hipStream_t st);
+int launch_maxpool_bwd(const float* act, const float* dp, const float* skip, float* g, int N, int Ho, int Wo, int C, hipStream_t st);
+int launch_head_fwd(const float* in, const float* w, const float* b, float* out, int N, int H, int W, int OC, hipStream_t st);
+size_t head_bwd_ws_floats();
+int launch_head_bwd(const float* dout, const float* act, const float* w, float* g, float* dw, float* db, float* part,
+                    int N, int H, int W, int OC, hipStream_t st);
+size_t colsum_ws_floats(int C);
+int launch_colsum(const float* x, float* out, float* part, size_t P, int C, hipStream_t st);
+int launch_pack(const float* src, float* dst, int kind, int Cout, int Cin, int Cinp, int T, hipStream_t st);
+size_t l1_ws_floats();
+int launch_l1(const float* out, const float* tgt, float* dout, float* loss, float* part, size_t n, float grad_scale, hipStream_t st);
+int launch_adam(float* p, const float* g, float* m, float* v, size_t n, double lr, double b1, double b2, double eps, double wd,
+                int step, double gscale, hipStream_t st);

@@ -1,0 +1,408 @@
+// unet_misc.hip -- the HBM-bound pieces of the U-Net step (gfx950): layout conversion at the two
+// ends of the network, 2x2 max-pool forward/backward, the 1x1 head (conv10_1) forward/backward,
+// weight packing, column sums, L1 loss and Adam.  Every kernel streams its operands once with
+// 16-byte lane accesses.  Reference ops: models/arch/Unet.py:13,46,51-63,88 (pool, conv10_1),
+// models/losses.py:32 (L1Loss), models/ELD_model.py:400-401,475 (Adam).
+#include "unet_misc.h"
+
+// ------------------------------------------------------------------------------------------------
+// NCHW (C <= 16 planes) -> NHWC with 16 channels (zero padded): input of conv1_1
+// ------------------------------------------------------------------------------------------------
+__global__ void nchw_to_nhwc16_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, size_t HW) {
+    const size_t total = (size_t)N * HW;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = p / HW, q = p - n * HW;
+        float v[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = c < C ? x[(n * C + c) * HW + q] : 0.f;
+        float4* o = reinterpret_cast<float4*>(y + p * 16);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+    }
+}
+
+int launch_nchw_to_nhwc16(const float* x, float* y, int N, int C, int H, int W, hipStream_t st) {
+    const size_t total = (size_t)N * H * W;
+    if (!total) return 0;
+    hipLaunchKernelGGL(nchw_to_nhwc16_kernel, dim3((unsigned)min((total + 255) / 256, (size_t)16384)), dim3(256), 0, st, x, y, N, C, (size_t)H * W);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2x2 max pool, NHWC.  One thread = one output pixel x 4 channels (float4).
+// ------------------------------------------------------------------------------------------------
+__global__ void maxpool_fwd_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int Ho, int Wo, int C) {
+    const int C4 = C / 4;
+    const size_t total = (size_t)N * Ho * Wo * C4;
+    const int Wi = 2 * Wo;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        size_t p = i / C4;
+        const int xo = (int)(p % Wo); p /= Wo;
+        const int yo = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        const float4* src = reinterpret_cast<const float4*>(in + (((size_t)n * 2 * Ho + 2 * yo) * Wi + 2 * xo) * C) + c4;
+        const float4 a = src[0], b = src[C4], c = src[(size_t)Wi * C4], d = src[(size_t)Wi * C4 + C4];
+        float4 r;
+        r.x = fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x));
+        r.y = fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y));
+        r.z = fmaxf(fmaxf(a.z, b.z), fmaxf(c.z, d.z));
+        r.w = fmaxf(fmaxf(a.w, b.w), fmaxf(c.w, d.w));
+        reinterpret_cast<float4*>(out)[i] = r;
+    }
+}
+
+int launch_maxpool_fwd(const float* in, float* out, int N, int Ho, int Wo, int C, hipStream_t st) {
+    const size_t total = (size_t)N * Ho * Wo * (C / 4);
+    if (!total) return 0;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)min((total + 255) / 256, (size_t)32768)), dim3(256), 0, st, in, out, N, Ho, Wo, C);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
+// Backward of pool fused with the skip-connection add and the LeakyReLU slope of the pooled tensor:
+//   g[pos] = (route(dp)[pos] + skip[pos]) * slope(act[pos])
+// route: the whole gradient goes to the FIRST maximum in row-major window order (what torch's CPU
+// max_pool2d backward does; all-equal window -> [1,0,0,0]).
+// one channel of one 2x2 window: routed pool gradient + skip gradient, times the LeakyReLU slope
+#define POOL_BWD_1(F)                                                                          \
+    {                                                                                          \
+        const float mx = fmaxf(fmaxf(a.F, b.F), fmaxf(c.F, d.F));                              \
+        const int sel = a.F == mx ? 0 : (b.F == mx ? 1 : (c.F == mx ? 2 : 3));                 \
+        ga.F = ((sel == 0 ? gp.F : 0.f) + sa.F) * lrelu_slope(a.F);                            \
+        gb.F = ((sel == 1 ? gp.F : 0.f) + sb.F) * lrelu_slope(b.F);                            \
+        gc.F = ((sel == 2 ? gp.F : 0.f) + sc.F) * lrelu_slope(c.F);                            \
+        gd.F = ((sel == 3 ? gp.F : 0.f) + sd.F) * lrelu_slope(d.F);                            \
+    }
+
+__global__ void maxpool_bwd_kernel(const float* __restrict__ act, const float* __restrict__ dp, const float* __restrict__ skip,
+                                   float* __restrict__ g, int N, int Ho, int Wo, int C) {
+    const int C4 = C / 4;
+    const size_t total = (size_t)N * Ho * Wo * C4;
+    const int Wi = 2 * Wo;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        size_t p = i / C4;
+        const int xo = (int)(p % Wo); p /= Wo;
+        const int yo = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        const size_t base = ((((size_t)n * 2 * Ho + 2 * yo) * Wi + 2 * xo) * C) / 4 + c4;
+        const size_t o1 = C4, o2 = (size_t)Wi * C4, o3 = o2 + C4;
+        const float4* A = reinterpret_cast<const float4*>(act);
+        const float4 a = A[base], b = A[base + o1], c = A[base + o2], d = A[base + o3];
+        const float4 gp = reinterpret_cast<const float4*>(dp)[i];
+        float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa, sc = sa, sd = sa;
+        if (skip) {
+            const float4* S = reinterpret_cast<const float4*>(skip);
+            sa = S[base]; sb = S[base + o1]; sc = S[base + o2]; sd = S[base + o3];
+        }
+        float4 ga, gb, gc, gd;
+        POOL_BWD_1(x) POOL_BWD_1(y) POOL_BWD_1(z) POOL_BWD_1(w)
+        float4* G = reinterpret_cast<float4*>(g);
+        G[base] = ga; G[base + o1] = gb; G[base + o2] = gc; G[base + o3] = gd;
+    }
+}
+
+int launch_maxpool_bwd(const float* act, const float* dp, const float* skip, float* g, int N, int Ho, int Wo, int C, hipStream_t st) {
+    const size_t total = (size_t)N * Ho * Wo * (C / 4);
+    if (!total) return 0;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)min((total + 255) / 256, (size_t)32768)), dim3(256), 0, st, act, dp, skip, g, N, Ho, Wo, C);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv10_1: 1x1, 32 -> OC (<= 4), no activation; NHWC in, NCHW out (Unet.py:46,88)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ b,
+                                                       float* __restrict__ out, int N, size_t HW, int OC) {
+    __shared__ float sw[4 * 32 + 4];
+    for (int i = threadIdx.x; i < 4 * 32 + 4; i += 256) {
+        float v = 0.f;
+        if (i < 128) { if (i / 32 < OC) v = w[i]; } else if (i - 128 < OC) v = b[i - 128];
+        sw[i] = v;
+    }
+    __syncthreads();
+    const size_t total = (size_t)N * HW;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+        const float4* src = reinterpret_cast<const float4*>(in + p * 32);
+        float acc[4] = {sw[128], sw[129], sw[130], sw[131]};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float4 v = src[k];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                acc[o] = fmaf(v.x, sw[o * 32 + 4 * k], acc[o]);
+                acc[o] = fmaf(v.y, sw[o * 32 + 4 * k + 1], acc[o]);
+                acc[o] = fmaf(v.z, sw[o * 32 + 4 * k + 2], acc[o]);
+                acc[o] = fmaf(v.w, sw[o * 32 + 4 * k + 3], acc[o]);
+            }
+        }
+        const size_t n = p / HW, q = p - n * HW;
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+            if (o < OC) out[(n * OC + o) * HW + q] = acc[o];
+    }
+}
+
+int launch_head_fwd(const float* in, const float* w, const float* b, float* out, int N, int H, int W, int OC, hipStream_t st) {
+    const size_t total = (size_t)N * H * W;
+    if (!total) return 0;
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)min((total + 255) / 256, (size_t)16384)), dim3(256), 0, st, in, w, b, out, N, (size_t)H * W, OC);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
+// backward: g[p][c] = (sum_o W[o][c] d[o][p]) * slope(act[p][c]);  dW[o][c] = sum_p d[o][p] act[p][c];  db[o] = sum_p d[o][p]
+// per-block partials [nblocks][132] -> reduced by head_bwd_reduce_kernel in fixed order.
+#define HEAD_BLOCKS 1024
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ act, const float* __restrict__ w,
+                                                       float* __restrict__ g, float* __restrict__ part, int N, size_t HW, int OC) {
+    __shared__ float sw[128];
+    __shared__ float red[4][132];
+    for (int i = threadIdx.x; i < 128; i += 256) sw[i] = (i / 32 < OC) ? w[i] : 0.f;
+    __syncthreads();
+    float dw[4][32];
+    float db[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int c = 0; c < 32; ++c) dw[o][c] = 0.f;
+    const size_t total = (size_t)N * HW;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = p / HW, q = p - n * HW;
+        float d[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) { d[o] = o < OC ? dout[(n * OC + o) * HW + q] : 0.f; db[o] += d[o]; }
+        const float4* A = reinterpret_cast<const float4*>(act + p * 32);
+        float4* G = reinterpret_cast<float4*>(g + p * 32);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float4 a = A[k];
+            const float av[4] = {a.x, a.y, a.z, a.w};
+            float gv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = 4 * k + j;
+                float s = 0.f;
+#pragma unroll
+                for (int o = 0; o < 4; ++o) { s = fmaf(sw[o * 32 + c], d[o], s); dw[o][c] = fmaf(d[o], av[j], dw[o][c]); }
+                gv[j] = s * lrelu_slope(av[j]);
+            }
+            G[k] = make_float4(gv[0], gv[1], gv[2], gv[3]);
+        }
+    }
+    // block reduction: wave shuffle then across the 4 waves
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            float v = dw[o][c];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0) red[wave][o * 32 + c] = v;
+        }
+        float v = db[o];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[wave][128 + o] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 132)
+        part[(size_t)blockIdx.x * 132 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ void head_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nblocks, int OC) {
+    const int t = threadIdx.x;
+    if (t >= 132) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * 132 + t];
+    if (t < 128) { if (t / 32 < OC) dw[t] = s; } else if (t - 128 < OC) db[t - 128] = s;
+}
+
+size_t head_bwd_ws_floats() { return (size_t)HEAD_BLOCKS * 132; }
+
+int launch_head_bwd(const float* dout, const float* act, const float* w, float* g, float* dw, float* db, float* part,
+                    int N, int H, int W, int OC, hipStream_t st) {
+    const size_t total = (size_t)N * H * W;
+    if (!total) return 0;
+    const int nb = (int)min((total + 255) / 256, (size_t)HEAD_BLOCKS);
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(nb), dim3(256), 0, st, dout, act, w, g, part, N, (size_t)H * W, OC);
+    ELD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3(1), dim3(192), 0, st, part, dw, db, nb, OC);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// column sums of an NHWC matrix [P][C] -> [C]  (bias gradient of the transposed convs)
+// ------------------------------------------------------------------------------------------------
+#define COLSUM_BLOCKS 512
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ part, size_t P, int C) {
+    // thread t handles channel (t % C4)*4.. of pixels t / C4 + k*(256/C4 * gridDim)
+    const int C4 = C / 4;
+    const int ppb = 256 / C4;                  // pixels per block-iteration (C4 <= 128 -> ppb >= 2); threads beyond ppb*C4 idle
+    const int c4 = threadIdx.x % C4, pl = threadIdx.x / C4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pl < ppb) {
+        for (size_t p = (size_t)blockIdx.x * ppb + pl; p < P; p += (size_t)gridDim.x * ppb) {
+            const float4 v = reinterpret_cast<const float4*>(x + p * C)[c4];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    __shared__ float4 sh[256];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < C4) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < ppb; ++k) { const float4 v = sh[k * C4 + threadIdx.x]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        reinterpret_cast<float4*>(part + (size_t)blockIdx.x * C)[threadIdx.x] = t;
+    }
+}
+
+__global__ void colsum_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nblocks, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * C + c];
+    out[c] = s;
+}
+
+size_t colsum_ws_floats(int C) { return (size_t)COLSUM_BLOCKS * C; }
+
+int launch_colsum(const float* x, float* out, float* part, size_t P, int C, hipStream_t st) {
+    if (C % 4 || C > 512) return ELD_EINVAL;
+    const int ppb = 256 / (C / 4);
+    const int nb = (int)min((P + ppb - 1) / ppb, (size_t)COLSUM_BLOCKS);
+    if (nb == 0) return 0;
+    hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, st, x, part, P, C);
+    ELD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, out, nb, C);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing (tiny: 7.76 M parameters in total)
+//   PACK_CONV_FWD : dst[t][co][ci_p] = src[co][ci][t]        (zero for ci >= Cin)       src OIHW
+//   PACK_CONV_BWD : dst[t][ci][co]   = src[co][ci][T-1-t]    (flipped taps, transposed)
+//   PACK_CONVT_FWD: dst[tap*Cout+co][ci] = src[ci][co][tap]                              src (Cin,Cout,2,2)
+//   PACK_CONVT_BWD: dst[tap][ci][co]     = src[ci][co][tap]
+// ------------------------------------------------------------------------------------------------
+__global__ void pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int kind, int Cout, int Cin, int Cinp, int T) {
+    size_t total;
+    if (kind == PACK_CONV_FWD) total = (size_t)T * Cout * Cinp; else total = (size_t)T * Cout * Cin;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    if (kind == PACK_CONV_FWD) {
+        const int ci = (int)(i % Cinp); const int co = (int)((i / Cinp) % Cout); const int t = (int)(i / ((size_t)Cinp * Cout));
+        dst[i] = ci < Cin ? src[((size_t)co * Cin + ci) * T + t] : 0.f;
+    } else if (kind == PACK_CONV_BWD) {
+        const int co = (int)(i % Cout); const int ci = (int)((i / Cout) % Cin); const int t = (int)(i / ((size_t)Cout * Cin));
+        dst[i] = src[((size_t)co * Cin + ci) * T + (T - 1 - t)];
+    } else if (kind == PACK_CONVT_FWD) {
+        const int ci = (int)(i % Cin); const int co = (int)((i / Cin) % Cout); const int t = (int)(i / ((size_t)Cin * Cout));
+        dst[i] = src[((size_t)ci * Cout + co) * T + t];
+    } else {
+        const int co = (int)(i % Cout); const int ci = (int)((i / Cout) % Cin); const int t = (int)(i / ((size_t)Cout * Cin));
+        dst[i] = src[((size_t)ci * Cout + co) * T + t];
+    }
+}
+
+int launch_pack(const float* src, float* dst, int kind, int Cout, int Cin, int Cinp, int T, hipStream_t st) {
+    const size_t total = (size_t)T * Cout * (kind == PACK_CONV_FWD ? Cinp : Cin);
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, dst, kind, Cout, Cin, Cinp, T);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// L1 loss (mean |out - target|) forward + backward in one pass; two-pass deterministic reduction.
+//   dout = sign(out - target) * scale / numel     (torch: sign(0) = 0)
+// ------------------------------------------------------------------------------------------------
+#define L1_BLOCKS 1024
+__global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ out, const float* __restrict__ tgt, float* __restrict__ dout,
+                                                 float* __restrict__ part, size_t n, float gscale) {
+    float s = 0.f;
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 a = reinterpret_cast<const float4*>(out)[i], b = reinterpret_cast<const float4*>(tgt)[i];
+        const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
+        s += fabsf(d0) + fabsf(d1) + fabsf(d2) + fabsf(d3);
+        if (dout) {
+            float4 g;
+            g.x = d0 > 0.f ? gscale : (d0 < 0.f ? -gscale : 0.f);
+            g.y = d1 > 0.f ? gscale : (d1 < 0.f ? -gscale : 0.f);
+            g.z = d2 > 0.f ? gscale : (d2 < 0.f ? -gscale : 0.f);
+            g.w = d3 > 0.f ? gscale : (d3 < 0.f ? -gscale : 0.f);
+            reinterpret_cast<float4*>(dout)[i] = g;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = n4 * 4 + threadIdx.x;
+        const float d = out[i] - tgt[i];
+        s += fabsf(d);
+        if (dout) dout[i] = d > 0.f ? gscale : (d < 0.f ? -gscale : 0.f);
+    }
+    __shared__ float sh[4];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ void l1_reduce_kernel(const float* __restrict__ part, float* __restrict__ loss, int nblocks, float inv_n) {
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += (double)part[b];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = (float)(sh[0] * (double)inv_n);
+}
+
+size_t l1_ws_floats() { return L1_BLOCKS; }
+
+int launch_l1(const float* out, const float* tgt, float* dout, float* loss, float* part, size_t n, float grad_scale, hipStream_t st) {
+    if (n == 0) return ELD_EINVAL;
+    const int nb = (int)min((n / 4 + 255) / 256 + 1, (size_t)L1_BLOCKS);
+    hipLaunchKernelGGL(l1_kernel, dim3(nb), dim3(256), 0, st, out, tgt, dout, part, n, grad_scale / (float)n);
+    ELD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(l1_reduce_kernel, dim3(1), dim3(256), 0, st, part, loss, nb, 1.0f / (float)n);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Adam over one flat parameter buffer (torch.optim.Adam semantics, amsgrad off, weight decay wd
+// added to the gradient):  m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+//   p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// ------------------------------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                            float step_size, float b1, float b2, float eps, float wd, float bc2_sqrt, float gscale) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float gi = g[i] * gscale;
+    if (wd != 0.f) gi = gi + wd * p[i];
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = __builtin_sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+}
+
+// scalars are formed in double on the host exactly as torch/optim/adam.py does, then rounded to float
+int launch_adam(float* p, const float* g, float* m, float* v, size_t n, double lr, double b1, double b2, double eps, double wd,
+                int step, double gscale, hipStream_t st) {
+    if (!n) return 0;
+    const double bc1 = 1.0 - pow(b1, (double)step);
+    const double bc2 = 1.0 - pow(b2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n, (float)(lr / bc1), (float)b1,
+                       (float)b2, (float)eps, (float)wd, (float)sqrt(bc2), (float)gscale);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}

@@ -97,6 +97,62 @@ int eld_philox_words(uint32_t* out, uint32_t n, uint32_t index0, uint64_t sample
 int eld_pack_bayer(const float* mosaic, float* packed, int N, int h, int w, void* stream);
 int eld_unpack_bayer(const float* packed, float* mosaic, int N, int h, int w, void* stream);
 
+
+/* ====================================================================================================
+ * U-Net ("See-in-the-Dark", 5 scales) -- replaces UNetSeeInDark.forward (models/arch/Unet.py:48-91) and
+ * the autograd backward that ELDModel.backward_G triggers (models/ELD_model.py:411-420).
+ *
+ * Parameters live in ONE flat float32 buffer, tensors in the reference's named_parameters() order
+ * (conv1_1.weight, conv1_1.bias, ... conv5_2, upv6, conv6_1, conv6_2, ... upv9, conv9_1, conv9_2, conv10_1),
+ * each in the reference's own layout (Conv2d OIHW, ConvTranspose2d (Cin,Cout,2,2)), so a state_dict
+ * maps onto it by plain views (models/ELD_model.py:516-523) and a data-parallel gradient all-reduce is
+ * one contiguous buffer.  Activations are kept NHWC float32 in the caller-provided workspace.
+ * x / out / dout are NCHW float32 like the reference's tensors.  H and W must be multiples of 16.
+ * ==================================================================================================== */
+#define ELD_UNET_NTENSORS 46
+
+/* offsets[i] = first float of tensor i in the flat buffer, offsets[46] = total count (7,760,484 for 4->4). */
+int eld_unet_param_offsets(int in_ch, int out_ch, int64_t* offsets /* [ELD_UNET_NTENSORS+1] */);
+/* bytes of scratch eld_unet_forward/backward need for this shape (packed weights, activations, gradients, partials) */
+size_t eld_unet_workspace_bytes(int N, int H, int W, int in_ch, int out_ch);
+int eld_unet_forward(const float* x, const float* params, float* out, void* ws, size_t ws_bytes,
+                     int N, int H, int W, int in_ch, int out_ch, void* stream);
+/* Needs the workspace exactly as eld_unet_forward left it (saved activations).  Writes every element of grads. */
+int eld_unet_backward(const float* dout, const float* params, float* grads, void* ws, size_t ws_bytes,
+                      int N, int H, int W, int in_ch, int out_ch, void* stream);
+
+/* mean |out-target| (nn.L1Loss, models/losses.py:32) and, if dout != NULL, its gradient times grad_scale.
+ * ws: eld_l1_workspace_bytes() bytes.  loss: one device float. */
+size_t eld_l1_workspace_bytes(void);
+int eld_l1_loss(const float* out, const float* target, float* dout, float* loss, void* ws, size_t n, float grad_scale, void* stream);
+/* torch.optim.Adam step over a flat buffer (models/ELD_model.py:400-401,475); step counts from 1;
+ * the gradient is multiplied by grad_scale first (1/world_size after a sum all-reduce). */
+int eld_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1,
+                  double beta2, double eps, double weight_decay, int step, double grad_scale, void* stream);
+
+/* ---- single layers on NHWC float32 tensors with reference-layout weights; used by the parity tests ---- */
+size_t eld_layer_workspace_bytes(int N, int H, int W, int Cin, int Cout);
+/* out = [lrelu](conv3x3(cat[in0,in1]) + bias).  nn.Conv2d(k=3,p=1) + torch.max(0.2x,x)  (Unet.py:11-44,102-104) */
+int eld_conv3x3_forward(const float* in0, int C0, const float* in1, int C1, const float* w_oihw, const float* bias,
+                        float* out, int N, int H, int W, int Cout, int lrelu, void* ws, size_t ws_bytes, void* stream);
+/* din = conv3x3_backward_data(g); channels [0,split) -> din0, [split,Cin) -> din1; optionally times the LeakyReLU
+ * slope of the saved post-activation tensors act0/act1 (NULL = no activation in front). */
+int eld_conv3x3_backward_data(const float* g, const float* w_oihw, float* din0, float* din1, int split, const float* act0,
+                              const float* act1, int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+/* dw (OIHW), db from g (grad of the pre-activation output) and the layer input cat[x0,x1]. */
+int eld_conv3x3_backward_weight(const float* g, const float* x0, int C0, const float* x1, int C1, float* dw, float* db,
+                                int N, int H, int W, int Cout, void* ws, size_t ws_bytes, void* stream);
+/* nn.ConvTranspose2d(Cin,Cout,2,stride=2) (Unet.py:30,34,38,42): in [N,H,W,Cin] -> out [N,2H,2W,Cout]. */
+int eld_convt2x2_forward(const float* in, const float* w, const float* bias, float* out, int N, int H, int W, int Cin, int Cout,
+                         void* ws, size_t ws_bytes, void* stream);
+int eld_convt2x2_backward_data(const float* dout, const float* w, const float* act, float* din, int N, int H, int W, int Cin,
+                               int Cout, void* ws, size_t ws_bytes, void* stream);
+int eld_convt2x2_backward_weight(const float* in, const float* dout, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
+                                 void* ws, size_t ws_bytes, void* stream);
+/* nn.MaxPool2d(2) (Unet.py:13): in [N,2Ho,2Wo,C] -> out [N,Ho,Wo,C]; backward = (routed dp + skip) * slope(act). */
+int eld_maxpool2x2_forward(const float* in, float* out, int N, int Ho, int Wo, int C, void* stream);
+int eld_maxpool2x2_backward(const float* act, const float* dp, const float* skip, float* g, int N, int Ho, int Wo, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

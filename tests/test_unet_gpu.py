@@ -1,0 +1,276 @@
+"""GPU parity tests of the U-Net kernels and of the whole forward/backward, through the C ABI.
+Checker = torch CPU float32/float64 (oracle/unet_ref.py, pinned to the reference's golden output).
+Tolerance: fp32 within 1e-5 (BASELINE.json north_star) on O(1) data; where the contraction is long
+(K up to 4608) the bound is scaled by the fp64-measured magnitude sum|a*b|*2^-23*sqrt(K)-class term."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+import torch.nn.functional as F      # noqa: E402
+
+from oracle import unet_ref as U     # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope='module')
+def lib(eld_lib):
+    assert torch.cuda.is_available()
+    return eld_lib
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def ws_for(lib, N, H, W, Cin, Cout):
+    n = lib.eld_layer_workspace_bytes(N, H, W, Cin, Cout)
+    assert n > 0
+    return torch.empty(n, dtype=torch.uint8, device='cuda')
+
+
+def close(got, ref64, tol=1e-5, scale=None):
+    """|got - ref| <= tol * (1 + scale) elementwise; scale = magnitude of the accumulated terms (fp64)."""
+    got = got.detach().cpu().double()
+    err = (got - ref64).abs()
+    bound = tol * (1.0 + (scale if scale is not None else ref64.abs()))
+    bad = (err > bound)
+    assert not bad.any(), 'max err %.3e (bound %.3e) at %d elements' % (float(err.max()), float(bound.max() if torch.is_tensor(bound) else bound), int(bad.sum()))
+
+
+CASES = [  # N, H, W, C0, C1, Cout
+    (2, 20, 37, 32, 0, 32), (1, 9, 133, 64, 0, 64), (1, 16, 40, 32, 32, 32), (2, 12, 33, 64, 64, 64),
+    (1, 8, 34, 16, 0, 32), (1, 7, 31, 128, 0, 256), (1, 5, 17, 512, 0, 64),
+]
+
+
+@pytest.mark.parametrize('N,H,W,C0,C1,Cout', CASES)
+@pytest.mark.parametrize('act', [1, 0])
+def test_conv3x3_forward(lib, N, H, W, C0, C1, Cout, act):
+    from eld_amd import _lib as L
+    g = torch.Generator().manual_seed(H * W + C0 + Cout)
+    x = torch.randn(N, C0 + C1, H, W, generator=g)
+    w = torch.randn(Cout, C0 + C1, 3, 3, generator=g) / np.sqrt(9 * (C0 + C1))
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    mag = F.conv2d(x.double().abs(), w.double().abs(), b.double().abs(), padding=1)
+    if act:
+        ref = torch.max(0.2 * ref, ref)
+    x0 = nhwc(x[:, :C0]).cuda()
+    x1 = nhwc(x[:, C0:]).cuda() if C1 else None
+    out = torch.empty(N, H, W, Cout, device='cuda')
+    ws = ws_for(lib, N, H, W, C0 + C1, Cout)
+    L.check(lib.eld_conv3x3_forward(L.dptr(x0), C0, L.dptr(x1), C1, L.dptr(w.cuda()), L.dptr(b.cuda()), L.dptr(out), N, H, W, Cout, act,
+                                    L.dptr(ws), ws.numel(), L.cur_stream()))
+    close(nchw(out), ref, tol=2e-6, scale=mag)
+    ref32 = F.conv2d(x, w, b, padding=1)
+    if act:
+        ref32 = torch.max(0.2 * ref32, ref32)
+    assert (nchw(out).cpu() - ref32).abs().max() < 1e-5 * (1 + float(mag.max()))
+
+
+@pytest.mark.parametrize('N,H,W,Cin,Cout,split', [(2, 20, 37, 32, 32, 32), (1, 16, 40, 64, 32, 32), (1, 9, 133, 128, 64, 64),
+                                                     (1, 6, 18, 256, 512, 256), (1, 8, 32, 32, 64, 32)])
+def test_conv3x3_backward_data(lib, N, H, W, Cin, Cout, split):
+    from eld_amd import _lib as L
+    g = torch.Generator().manual_seed(7 + Cin)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(9 * Cout)
+    gy = torch.randn(N, Cout, H, W, generator=g)
+    act = torch.randn(N, Cin, H, W, generator=g)
+    act[:, :, ::3, ::5] = 0.0                                   # exercise the tie slope 0.6
+    ref = torch.nn.grad.conv2d_input((N, Cin, H, W), w.double(), gy.double(), padding=1)
+    mag = torch.nn.grad.conv2d_input((N, Cin, H, W), w.double().abs(), gy.double().abs(), padding=1)
+    slope = torch.where(act > 0, 1.0, torch.where(act < 0, 0.2, 0.6)).double()
+    d0 = torch.empty(N, H, W, split, device='cuda')
+    d1 = torch.empty(N, H, W, Cin - split, device='cuda') if split < Cin else None
+    a0 = nhwc(act[:, :split]).cuda()
+    ws = ws_for(lib, N, H, W, Cin, Cout)
+    L.check(lib.eld_conv3x3_backward_data(L.dptr(nhwc(gy).cuda()), L.dptr(w.cuda()), L.dptr(d0), L.dptr(d1), split, L.dptr(a0), None,
+                                          N, H, W, Cin, Cout, L.dptr(ws), ws.numel(), L.cur_stream()))
+    close(nchw(d0), ref[:, :split] * slope[:, :split], tol=2e-6, scale=mag[:, :split])
+    if d1 is not None:
+        close(nchw(d1), ref[:, split:], tol=2e-6, scale=mag[:, split:])      # second half: no activation in front
+
+
+@pytest.mark.parametrize('N,H,W,C0,C1,Cout', CASES + [(2, 64, 96, 32, 0, 32), (1, 21, 70, 16, 0, 32)])
+def test_conv3x3_backward_weight(lib, N, H, W, C0, C1, Cout):
+    from eld_amd import _lib as L
+    g = torch.Generator().manual_seed(11 + H)
+    x = torch.randn(N, C0 + C1, H, W, generator=g)
+    gy = torch.randn(N, Cout, H, W, generator=g)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, C0 + C1, 3, 3), gy.double(), padding=1)
+    mag = torch.nn.grad.conv2d_weight(x.double().abs(), (Cout, C0 + C1, 3, 3), gy.double().abs(), padding=1)
+    x0 = nhwc(x[:, :C0]).cuda()
+    x1 = nhwc(x[:, C0:]).cuda() if C1 else None
+    dw = torch.full((Cout, C0 + C1, 3, 3), float('nan'), device='cuda')
+    db = torch.full((Cout,), float('nan'), device='cuda')
+    ws = ws_for(lib, N, H, W, C0 + C1, Cout)
+    for _ in range(2):      # run twice: bit-stable (fixed reduction order, no atomics)
+        L.check(lib.eld_conv3x3_backward_weight(L.dptr(nhwc(gy).cuda()), L.dptr(x0), C0, L.dptr(x1), C1, L.dptr(dw), L.dptr(db), N, H, W, Cout,
+                                                L.dptr(ws), ws.numel(), L.cur_stream()))
+        cur = (dw.clone(), db.clone())
+        if _:
+            assert torch.equal(cur[0], prev[0]) and torch.equal(cur[1], prev[1])
+        prev = cur
+    close(dw, ref, tol=2e-6, scale=mag)
+    close(db, gy.double().sum(dim=(0, 2, 3)), tol=2e-6, scale=gy.double().abs().sum(dim=(0, 2, 3)))
+
+
+@pytest.mark.parametrize('N,H,W,Cin,Cout', [(2, 10, 19, 64, 32), (1, 5, 33, 512, 256), (1, 8, 8, 128, 64)])
+def test_conv_transpose2x2(lib, N, H, W, Cin, Cout):
+    from eld_amd import _lib as L
+    g = torch.Generator().manual_seed(3 + Cin)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    x[:, :, ::2, ::3] = 0.0
+    w = torch.randn(Cin, Cout, 2, 2, generator=g) / np.sqrt(Cin)
+    b = torch.randn(Cout, generator=g)
+    gy = torch.randn(N, Cout, 2 * H, 2 * W, generator=g)
+    ws = ws_for(lib, N, H, W, Cin, Cout)
+    xd = x.double().requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    bd = b.double().requires_grad_(True)
+    ref = F.conv_transpose2d(xd, wd, bd, stride=2)
+    ref.backward(gy.double())
+    out = torch.empty(N, 2 * H, 2 * W, Cout, device='cuda')
+    L.check(lib.eld_convt2x2_forward(L.dptr(nhwc(x).cuda()), L.dptr(w.cuda()), L.dptr(b.cuda()), L.dptr(out), N, H, W, Cin, Cout,
+                                     L.dptr(ws), ws.numel(), L.cur_stream()))
+    mag = F.conv_transpose2d(x.double().abs(), w.double().abs(), b.double().abs(), stride=2)
+    close(nchw(out), ref.detach(), tol=2e-6, scale=mag)
+    din = torch.empty(N, H, W, Cin, device='cuda')
+    gyd = nhwc(gy).cuda()
+    L.check(lib.eld_convt2x2_backward_data(L.dptr(gyd), L.dptr(w.cuda()), L.dptr(nhwc(x).cuda()), L.dptr(din), N, H, W, Cin, Cout,
+                                           L.dptr(ws), ws.numel(), L.cur_stream()))
+    slope = torch.where(x > 0, 1.0, torch.where(x < 0, 0.2, 0.6)).double()
+    magd = F.conv2d(gy.double().abs(), w.double().abs().permute(0, 1, 2, 3), stride=2)       # |gy| * |w| summed: conv with (Cin,Cout,2,2)
+    close(nchw(din), xd.grad * slope, tol=2e-6, scale=magd)
+    dw = torch.empty(Cin, Cout, 2, 2, device='cuda')
+    db = torch.empty(Cout, device='cuda')
+    L.check(lib.eld_convt2x2_backward_weight(L.dptr(nhwc(x).cuda()), L.dptr(gyd), L.dptr(dw), L.dptr(db), N, H, W, Cin, Cout,
+                                             L.dptr(ws), ws.numel(), L.cur_stream()))
+    close(dw, wd.grad, tol=2e-6, scale=wd.grad.abs() + float(np.sqrt(N * H * W)) * 3)
+    close(db, bd.grad, tol=2e-6, scale=gy.double().abs().sum(dim=(0, 2, 3)))
+
+
+def test_maxpool(lib):
+    from eld_amd import _lib as L
+    g = torch.Generator().manual_seed(1)
+    N, Ho, Wo, C = 2, 9, 13, 64
+    x = torch.randn(N, C, 2 * Ho, 2 * Wo, generator=g).round(decimals=1)        # coarse values -> plenty of ties
+    x[0, :, :2, :2] = 1.5                                                        # all-equal window
+    x[:, :, 4:6, 4:6] = 0.0                                                      # tie + zero activation
+    dp = torch.randn(N, C, Ho, Wo, generator=g)
+    skip = torch.randn(N, C, 2 * Ho, 2 * Wo, generator=g)
+    out = torch.empty(N, Ho, Wo, C, device='cuda')
+    L.check(lib.eld_maxpool2x2_forward(L.dptr(nhwc(x).cuda()), L.dptr(out), N, Ho, Wo, C, L.cur_stream()))
+    assert torch.equal(nchw(out).cpu(), F.max_pool2d(x, 2))
+    xr = x.clone().requires_grad_(True)
+    F.max_pool2d(xr, 2).backward(dp)
+    slope = torch.where(x > 0, 1.0, torch.where(x < 0, 0.2, 0.6))
+    for sk in (skip, None):
+        gout = torch.empty(N, 2 * Ho, 2 * Wo, C, device='cuda')
+        L.check(lib.eld_maxpool2x2_backward(L.dptr(nhwc(x).cuda()), L.dptr(nhwc(dp).cuda()), L.dptr(nhwc(sk).cuda()) if sk is not None else None,
+                                            L.dptr(gout), N, Ho, Wo, C, L.cur_stream()))
+        ref = (xr.grad + (sk if sk is not None else 0)) * slope
+        assert torch.equal(nchw(gout).cpu(), ref)
+
+
+def test_l1_and_adam(lib):
+    from eld_amd import _lib as L
+    g = torch.Generator().manual_seed(2)
+    n = 4 * 37 * 53 + 3
+    out = torch.randn(n, generator=g)
+    tgt = torch.randn(n, generator=g)
+    tgt[:10] = out[:10]
+    dout = torch.empty(n, device='cuda')
+    loss = torch.zeros(1, device='cuda')
+    ws = torch.empty(lib.eld_l1_workspace_bytes(), dtype=torch.uint8, device='cuda')
+    L.check(lib.eld_l1_loss(L.dptr(out.cuda()), L.dptr(tgt.cuda()), L.dptr(dout), L.dptr(loss), L.dptr(ws), n, 1.0, L.cur_stream()))
+    o = out.clone().requires_grad_(True)
+    lref = F.l1_loss(o, tgt)
+    lref.backward()
+    assert abs(float(loss) - float(lref)) < 1e-6
+    assert torch.equal(dout.cpu(), o.grad)
+    # Adam: 5 steps vs torch.optim.Adam on CPU
+    p = torch.randn(10007, generator=g)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-4, betas=(0.9, 0.999))
+    pd, m, v = p.cuda(), torch.zeros(10007, device='cuda'), torch.zeros(10007, device='cuda')
+    for step in range(1, 6):
+        gr = torch.randn(10007, generator=g) * 0.01
+        pr.grad = gr.clone()
+        opt.step()
+        L.check(lib.eld_adam_step(L.dptr(pd), L.dptr(gr.cuda()), L.dptr(m), L.dptr(v), 10007, 1e-4, 0.9, 0.999, 1e-8, 0.0, step, 1.0, L.cur_stream()))
+    assert (pd.cpu() - pr.detach()).abs().max() < 2e-7
+
+
+# ------------------------------------------------------------------------------------------------ whole network
+def test_unet_forward_backward_vs_reference_golden(lib, golden_dir):
+    """Same seeded init as the reference module, same input: output within 1e-5, L1 gradients of all 46 tensors."""
+    from eld_amd.unet import UNetSeeInDark
+    d = np.load(os.path.join(golden_dir, 'unet.npz'))
+    torch.manual_seed(2018)
+    net = UNetSeeInDark(4, 4)
+    names = [n for n, _ in net.named_parameters()]
+    assert names == [str(n) for n in d['names']]
+    if str(d['torch_version']) == torch.__version__:
+        wsum = np.array([float(p.detach().double().sum()) for _, p in net.named_parameters()])
+        assert np.array_equal(wsum, d['wsum'])
+    net = net.cuda()
+    x, t = torch.from_numpy(d['x']).cuda(), torch.from_numpy(d['t']).cuda()
+    out = net(x)
+    assert out.shape == (2, 4, 32, 48)
+    assert float((out.detach().cpu() - torch.from_numpy(d['out'])).abs().max()) <= 1e-5
+    loss = torch.nn.L1Loss()(out, t)                       # the reference's own criterion (models/losses.py:32)
+    loss.backward()
+    assert abs(float(loss) - float(d['loss'])) < 1e-6
+    gsum = np.array([float(p.grad.double().sum()) for _, p in net.named_parameters()])
+    gabs = np.array([float(p.grad.double().abs().sum()) for _, p in net.named_parameters()])
+    assert np.allclose(gabs, d['gabs'], rtol=2e-4, atol=1e-7), np.max(np.abs(gabs - d['gabs']) / (d['gabs'] + 1e-12))
+    assert np.allclose(gsum, d['gsum'], rtol=0, atol=2e-4 * np.maximum(d['gabs'], 1e-6).max())
+    for k in ('conv1_1.weight', 'conv1_1.bias', 'conv10_1.weight', 'conv10_1.bias', 'upv9.bias', 'conv9_2.bias'):
+        ref = d['grad_' + k.replace('.', '__')]
+        got = dict(net.named_parameters())[k].grad.cpu().numpy()
+        assert np.max(np.abs(got - ref)) <= 1e-5 * (1 + np.abs(ref).max()), k
+
+
+@pytest.mark.parametrize('shape', [(1, 4, 16, 16), (3, 4, 48, 80), (1, 4, 64, 144)])
+def test_unet_all_gradients_vs_oracle(lib, shape):
+    from eld_amd.unet import UNetSeeInDark
+    torch.manual_seed(7)
+    net = UNetSeeInDark(4, 4)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    x, t = torch.rand(*shape, generator=g), torch.rand(*shape, generator=g)
+    out_ref, loss_ref, grads = U.loss_and_grads({k: v.double() for k, v in sd.items()}, x.double(), t.double())
+    net = net.cuda()
+    out = net(x.cuda())
+    loss = torch.nn.functional.l1_loss(out, t.cuda())
+    loss.backward()
+    assert float((out.detach().cpu().double() - out_ref).abs().max()) <= 1e-5
+    assert abs(float(loss) - loss_ref) < 1e-6
+    for n, p in net.named_parameters():
+        ref = grads[n]
+        err = float((p.grad.cpu().double() - ref).abs().max())
+        assert err <= 1e-5 * (1 + float(ref.abs().max())) + 2e-4 * float(ref.abs().max()), (n, err, float(ref.abs().max()))
+    # eval-mode forward (no autograd) gives the same bits; state_dict round-trips through the reference key set
+    with torch.no_grad():
+        assert torch.equal(net(x.cuda()), out.detach())
+    net2 = UNetSeeInDark(4, 4)
+    net2.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+    net2 = net2.cuda()
+    with torch.no_grad():
+        assert torch.equal(net2(x.cuda()), out.detach())
+
+
+def test_unet_rejects_bad_input(lib):
+    from eld_amd.unet import UNetSeeInDark
+    net = UNetSeeInDark(4, 4).cuda()
+    with pytest.raises(RuntimeError):
+        net(torch.rand(1, 4, 30, 32, device='cuda'))
+    with pytest.raises(RuntimeError):
+        net(torch.rand(1, 4, 32, 32))
