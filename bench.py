@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path on MI355X: noise synthesis + U-Net training step, raw megapixels/s.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic clean raw already resident in HBM:
+  fused HIP sampler (full ELD model 'PGRU': Poisson shot + Tukey-lambda read + row + quantisation, SonyA7S2
+  parameters, + clip) -> U-Net forward (fp32, exact-fp32 MFMA) -> L1 loss -> U-Net backward -> [RCCL gradient
+  all-reduce] -> Adam.  Workload = BASELINE.json configs[1]: 4x1424x2128 packed raw per image, fp32, one image
+  per GPU (weak scaling: the per-GPU batch is fixed as N grows).
+Prints ONE JSON line (rank 0).  value = total raw pixels of all ranks / wall time of the timed K steps
+(barrier + device sync on both sides, MAX over ranks).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np          # noqa: E402
+import torch                # noqa: E402
+
+H_FULL, W_FULL = 1424, 2128
+FLOP_FWD_PER_PIX = 92288.0          # 2*MAC of the U-Net forward per raw pixel
+FLOP_STEP_PER_PIX = 276300.0        # forward + backward-data + backward-weight (no bwd-data for conv1_1)
+PEAK_F32_MFMA_TF = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_clean(n, h, w, device, seed):
+    """Clean packed raw on the LMDB uint16 grid, dark-heavy: floor(65535*U^2.2)/65535."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    u = torch.rand(n, 4, h, w, device=device, generator=g)
+    return (torch.floor(65535.0 * u ** 2.2) / 65535.0).contiguous()
+
+
+def make_opt(local_rank):
+    return types.SimpleNamespace(gpu_ids=[local_rank], isTrain=True, checkpoints_dir='/tmp/eld_amd_bench', name='bench', netG='unet',
+                                 channels=4, stage_in='raw', stage_out='raw', lr=1e-4, beta1=0.9, wd=0.0, loss='l1', resume=False,
+                                 no_log=True, chop=False, model='eld_model')
+
+
+def timed_events(fn, reps):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def cpu_baseline(h, w, seed=2018):
+    """Reference-style CPU path timed on this box's host cores (bounded sample): the NumPy sampler port on one
+    full 4x1424x2128 image (single-threaded NumPy, like noise.py) + one torch-CPU U-Net training step
+    (forward + L1 + backward + Adam, all host cores) on a 4x512x512 crop; combined per-pixel."""
+    from oracle import noise_ref as O
+    from oracle import unet_ref as U
+    rs = np.random.RandomState(seed)
+    y = (np.floor(65535.0 * rs.uniform(size=(4, h, w)) ** 2.2) / 65535.0).astype(np.float32)
+    p = O.Params(K=2.288, g_scale=6.451, ratio=208.98, tl_lambda=-0.14285714, tl_scale=3.3, row_scale=0.9)
+    flags = O.SHOT_POISSON | O.READ_TL | O.ROW | O.QUANT | O.CLIP
+    t0 = time.time()
+    O.noise_numpy_full(y, p, flags, rng=rs)
+    t_noise = time.time() - t0
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ch, cw = 512, 512
+    sd = U.seeded_state_dict(4, 4, seed=seed)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    opt = torch.optim.Adam(list(params.values()), lr=1e-4)
+    x = torch.from_numpy(y[None, :, :ch, :cw].copy())
+    t_unet = None
+    for it in range(2):                 # one warm-up, one timed
+        t0 = time.time()
+        opt.zero_grad()
+        loss = torch.nn.functional.l1_loss(U.unet_forward(params, x), x)
+        loss.backward()
+        opt.step()
+        t_unet = time.time() - t0
+    per_pix = t_noise / (4.0 * h * w) + t_unet / (4.0 * ch * cw)
+    return {'value': round(1e-6 / per_pix, 4), 'unit': 'raw MPix/s', 'cores': cores, 'kind': 'port',
+            'sample': 'NumPy sampler port (1 thread) on one 4x%dx%d image: %.2f s; torch-CPU fp32 U-Net step (%d threads) on one '
+                      '4x%dx%d crop: %.2f s; combined per pixel' % (h, w, t_noise, cores, ch, cw, t_unet),
+            'sampler_mpix_s': round(4.0 * h * w / t_noise / 1e6, 3), 'unet_step_mpix_s': round(4.0 * ch * cw / t_unet / 1e6, 4)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=1, help='images per GPU')
+    ap.add_argument('--height', type=int, default=H_FULL)
+    ap.add_argument('--width', type=int, default=W_FULL)
+    ap.add_argument('--noise', default='PGRU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from eld_amd import dist as D
+    world, rank, local = D.init()
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)' % (args.gpus, world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: eld_amd has no CPU fallback')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    import eld_amd
+    eld_amd.load_library()
+    from eld_amd import _lib as L
+    from eld_amd.model import ELDModel
+    from eld_amd.noise import NoiseModel, NoiseParams, sample_noise, model_flags
+
+    B, Hh, Ww = args.batch, args.height, args.width
+    np.random.seed(2018)
+    torch.manual_seed(2018)
+    import io
+    import contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        nm = NoiseModel(model=args.noise, include=4)               # SonyA7S2
+    model = ELDModel()
+    model.initialize(make_opt(local))
+    model.set_noise_model(nm)
+    clean = synth_clean(B, Hh, Ww, dev, seed=1234 + rank)           # resident in HBM before the timed region
+    total_steps = args.steps + args.warmup
+    plists = [[nm._sample_params() for _ in range(B)] for _ in range(total_steps)]     # _sample_params semantics, host side
+
+    def step(i):
+        ids = [(i * world * B) + rank + world * k for k in range(B)]      # global sample indices
+        model.set_input({'target': clean, 'params': plists[i], 'sample_ids': ids}, 'train')
+        model.optimize_parameters()
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total_steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = model.get_current_errors().get('Pixel')
+
+    pix_per_step = world * B * 4.0 * Hh * Ww
+    res = {
+        'metric': 'raw megapixels/sec (noise-synth + U-Net step)', 'value': round(pix_per_step * args.steps / dt / 1e6, 3),
+        'unit': 'raw MPix/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'BASELINE.json configs[1]: full ELD noise model (%s, SonyA7S2 params) on 4x%dx%d packed raw + U-Net fp32 '
+                               'train step (fwd, L1, bwd, Adam)' % (args.noise, Hh, Ww),
+                   'images_per_gpu': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world, 'final_loss': loss},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernels, measured live with HIP events on the launch stream ----------------------
+        net = model.netG
+        x = model.input
+        dout = torch.ones(B, 4, Hh, Ww, device=dev) / (B * 4.0 * Hh * Ww)
+        state = {}
+
+        def fwd():
+            state['k'] = net._engine_forward(x, save=True)[1]
+
+        def bwd():
+            net._engine_backward(dout, state['k'], tuple(x.shape), grads=model.optimizer_G.grads)
+        fwd(); bwd(); torch.cuda.synchronize()
+        t_f = timed_events(fwd, 3)
+        t_b = timed_events(bwd, 3)
+        flop_step = FLOP_STEP_PER_PIX * B * 4.0 * Hh * Ww
+        ach = flop_step / ((t_f + t_b) * 1e-3) / 1e12
+        res['roofline'] = {'bound': 'mfma', 'kernel': 'U-Net convolution launches of one step (conv_igemm_kernel fwd/bwd-data + wgrad_kernel), '
+                           'timed as eld_unet_forward + eld_unet_backward', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TF,
+                           'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F32_MFMA_TF, 4), 'traffic': None,
+                           'fwd_ms': round(t_f, 3), 'bwd_ms': round(t_b, 3),
+                           'fwd_tflops': round(FLOP_FWD_PER_PIX * B * 4.0 * Hh * Ww / (t_f * 1e-3) / 1e12, 2)}
+        # sampler alone (HBM-bound: 8 B per raw pixel), batch of 8 resident images
+        nb = 8
+        yb = synth_clean(nb, Hh, Ww, dev, seed=99)
+        zb = torch.empty_like(yb)
+        pl = [NoiseParams(2.288, 6.451, 15583, 208.98, tl_lambda=-0.14285714, tl_scale=3.3, row_scale=0.9)] * nb
+        fl = model_flags(args.noise) | L.CLIP
+
+        def samp():
+            sample_noise(yb, pl, fl, 2018, list(range(nb)), out=zb)
+        samp(); torch.cuda.synchronize()
+        t_s = timed_events(samp, 10)
+        gbs = 8.0 * yb.numel() / (t_s * 1e-3) / 1e9
+        res['roofline_sampler'] = {'bound': 'hbm', 'kernel': 'noise_kernel (%s+clip), %d images per launch, K=2.288 ratio=208.98' % (args.noise, nb),
+                                   'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
+                                   'traffic': None, 'ms_per_launch': round(t_s, 4), 'mpix_s': round(yb.numel() / (t_s * 1e-3) / 1e6, 1)}
+        del yb, zb
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(Hh, Ww)
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

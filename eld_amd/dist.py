@@ -1,0 +1,79 @@
+"""Data-parallel plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on
+ROCm; "gloo" for the CPU tests).  The reference is single-device (models/ELD_model.py:187-190); sharding
+by image over ranks is new functionality.
+
+The only exchange step of the path is the gradient all-reduce: all 7,760,484 fp32 gradients live in ONE
+flat buffer (eld_amd.unet), so the reduction is a handful of large contiguous RCCL calls -- xGMI is
+point-to-point (7 links x ~153 GB/s per GPU) and a ring all-reduce is per-link bound, so few large
+buckets beat per-tensor calls.  The engine's backward is one stream-ordered call; the 31 MB reduction
+(~0.4 ms as a ring over one link) is small against the >= 20 ms fp32 step at the benchmark size, so it is
+issued right after the backward.  Gradient averaging (sum / world) is folded into the fused Adam's
+grad_scale, so no extra pass over the gradients is made.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+BUCKET_FLOATS = 4 * 1024 * 1024      # 16 MiB buckets
+
+
+def env_world():
+    return int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
+
+
+def init(backend=None):
+    """Initialise the default process group from the torchrun environment (no-op for world size 1)."""
+    world, rank, local = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return world, rank, local
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def allreduce_sum_(flat, bucket=BUCKET_FLOATS):
+    """In-place SUM all-reduce of a flat gradient buffer in large contiguous buckets.  Returns the
+    world size (the caller divides -- the fused Adam takes it as grad_scale = 1/world)."""
+    w = world_size()
+    if w == 1:
+        return 1
+    handles = []
+    for o in range(0, flat.numel(), bucket):
+        handles.append(dist.all_reduce(flat[o:o + bucket], op=dist.ReduceOp.SUM, async_op=True))
+    for h in handles:
+        h.wait()
+    return w
+
+
+def broadcast_(flat, src=0):
+    if world_size() > 1:
+        dist.broadcast(flat, src=src)
+
+
+def shard_indices(n, rank_=None, world=None):
+    """Image shard of this rank: indices rank, rank+world, ... (global sample index = Philox sample id,
+    so the union over ranks is identical for every world size)."""
+    r = rank() if rank_ is None else rank_
+    w = world_size() if world is None else world
+    return list(range(r, n, w))
+
+
+def allreduce_mean_scalar(x):
+    if world_size() == 1:
+        return x
+    t = x.detach().clone()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t / world_size()

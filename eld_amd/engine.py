@@ -1,0 +1,97 @@
+"""Epoch driver: mirror of the reference's Engine (engine.py:10-128) over eld_amd.model.ELDModel.
+
+Same surface -- Engine(opt), train(loader), eval(loader, dataset_name, ...), set_learning_rate(lr),
+epoch / iterations properties, checkpoint cadence -- minus the tensorboard / progress-bar plumbing of
+util/util.py, which is outside the hot path.  In data-parallel runs every rank executes the same loop on
+its shard of each batch; rank 0 logs and saves.
+"""
+import os
+import time
+
+import torch
+
+from . import dist as D
+from . import model as models
+
+
+class AverageMeters:                     # util/util.py:146-173 (running means), minimal
+    def __init__(self):
+        self.sum, self.n = {}, {}
+
+    def update(self, dic):
+        for k, v in dic.items():
+            self.sum[k] = self.sum.get(k, 0.0) + float(v)
+            self.n[k] = self.n.get(k, 0) + 1
+
+    def __getitem__(self, k):
+        return self.sum[k] / max(self.n[k], 1)
+
+    def __str__(self):
+        return ' | '.join('%s: %.4f' % (k, self[k]) for k in self.sum)
+
+
+class Engine(object):
+    def __init__(self, opt):
+        self.opt = opt
+        self.best_val_loss = 1e6
+        self.basedir = os.path.join(getattr(opt, 'checkpoints_dir', './checkpoints'), opt.name)      # engine.py:19-21
+        if D.rank() == 0:
+            os.makedirs(self.basedir, exist_ok=True)
+        self.model = getattr(models, getattr(opt, 'model', 'eld_model'))()                          # engine.py:26
+        self.model.initialize(opt)
+
+    def train(self, train_loader, **kwargs):         # engine.py:31-72
+        if D.rank() == 0:
+            print('\nEpoch: %d' % self.epoch)
+        avg_meters = AverageMeters()
+        model = self.model
+        t0 = time.time()
+        log_every = max(1, int(getattr(self.opt, 'print_freq', 1)))
+        for i, data in enumerate(train_loader):
+            model.set_input(data, mode='train')
+            model.optimize_parameters(**kwargs)
+            if i % log_every == 0:                   # the reference reads loss.item() every iteration (ELD_model.py:480)
+                avg_meters.update(model.get_current_errors())
+            self.iterations += 1
+        self.epoch += 1
+        if not getattr(self.opt, 'no_log', False):
+            if self.epoch % getattr(self.opt, 'save_epoch_freq', 100) == 0:
+                model.save()
+            model.save(label='latest')
+            if D.rank() == 0:
+                print('Time Taken: %d sec  [%s]' % (time.time() - t0, avg_meters))
+        model.update_learning_rate()
+        return avg_meters
+
+    def eval(self, val_loader, dataset_name, savedir=None, loss_key=None, **kwargs):       # engine.py:75-99
+        avg_meters = AverageMeters()
+        with torch.no_grad():
+            for data in val_loader:
+                avg_meters.update(self.model.eval(data, savedir=savedir, **kwargs))
+        if loss_key is not None and avg_meters[loss_key] < self.best_val_loss:
+            self.best_val_loss = avg_meters[loss_key]
+            self.model.save(label='best_{}_{}'.format(loss_key, dataset_name))
+        return avg_meters
+
+    def set_learning_rate(self, lr):                 # engine.py:109-112
+        for optimizer in self.model.optimizers:
+            if D.rank() == 0:
+                print('[i] set learning rate to {}'.format(lr))
+            for g in optimizer.param_groups:
+                g['lr'] = lr
+
+    @property
+    def iterations(self):
+        return self.model.iterations
+
+    @iterations.setter
+    def iterations(self, i):
+        self.model.iterations = i
+
+    @property
+    def epoch(self):
+        return self.model.epoch
+
+    @epoch.setter
+    def epoch(self, e):
+        self.model.epoch = e

@@ -1,0 +1,271 @@
+"""Model plugin: mirror of the reference's ELDModel (models/ELD_model.py:172-523, models/base_model.py)
+for the raw->raw path, with the whole training iteration on the MI355X:
+
+    set_input        device transfer (ELD_model.py:173-200); when the batch carries no 'input' the noisy
+                     input is synthesised ON DEVICE from 'target' by the fused sampler + clip
+                     (what SynDataset.__getitem__ does per sample on the CPU, sid_dataset.py:259-280)
+    optimize_parameters   forward -> L1 -> backward -> [RCCL all-reduce] -> Adam  (ELD_model.py:469-475),
+                     five calls into the C ABI, no autograd graph
+    get_current_errors    OrderedDict(Pixel=loss.item())                         (ELD_model.py:477-482)
+    save / load / state_dict   the reference's checkpoint dict {'netG','opt_g','epoch','iterations'} with a
+                     torch-Adam-shaped 'opt_g' (ELD_model.py:492-523, base_model.py:55-66)
+
+`eld_model()` is the factory `models.__dict__[opt.model]()` resolves (engine.py:26, models/__init__.py:3-4).
+The sRGB stages (--stage_in/out srgb, util/process.py) are outside the hot path and raise.
+"""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import dist as D
+from . import unet as arch_unet
+from .noise import NoiseModel, sample_noise, model_flags
+
+ARCH = {'unet': arch_unet.unet}          # the `arch.__dict__[opt.netG]` registry (ELD_model.py:391)
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (ELD_model.py:400-401) as ONE HIP launch over the flat parameter buffer.
+    It is a real torch Optimizer: `param_groups` is what Engine.set_learning_rate edits (engine.py:109-112),
+    and state_dict()/load_state_dict() speak torch Adam's per-parameter format so checkpoints interchange."""
+
+    def __init__(self, net, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.net = net
+        super().__init__(list(net.parameters()), dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        flat = net.flat_params
+        self.exp_avg = torch.zeros_like(flat)
+        self.exp_avg_sq = torch.zeros_like(flat)
+        self.step_count = 0
+        self.grads = torch.zeros_like(flat)        # flat gradient buffer the engine writes and RCCL reduces
+
+    @torch.no_grad()
+    def step(self, grad_scale=1.0):
+        g = self.param_groups[0]
+        self.step_count += 1
+        flat = self.net.flat_params
+        L.check(L.lib().eld_adam_step(L.dptr(flat), L.dptr(self.grads), L.dptr(self.exp_avg), L.dptr(self.exp_avg_sq), flat.numel(),
+                                      float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
+                                      float(g['weight_decay']), self.step_count, float(grad_scale), L.cur_stream()), 'eld_adam_step')
+
+    def zero_grad(self, set_to_none=True):          # the engine overwrites every gradient element each step
+        pass
+
+    def state_dict(self):
+        offs = self.net._offsets
+        state = {}
+        for i, (a, b) in enumerate(zip(offs[:-1], offs[1:])):
+            shape = self.net._plist[i].shape
+            if self.step_count > 0:
+                state[i] = {'step': torch.tensor(float(self.step_count)), 'exp_avg': self.exp_avg[a:b].view(shape).clone(),
+                            'exp_avg_sq': self.exp_avg_sq[a:b].view(shape).clone()}
+        g = dict(self.param_groups[0])
+        g['params'] = list(range(len(offs) - 1))
+        for k, v in dict(amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None).items():
+            g.setdefault(k, v)
+        return {'state': state, 'param_groups': [g]}
+
+    def load_state_dict(self, sd):
+        offs = self.net._offsets
+        pg = sd['param_groups'][0]
+        for k in ('lr', 'betas', 'eps', 'weight_decay', 'initial_lr'):
+            if k in pg:
+                self.param_groups[0][k] = pg[k]
+        self.step_count = 0
+        for i, st in sd['state'].items():
+            a, b = offs[int(i)], offs[int(i) + 1]
+            self.exp_avg[a:b].copy_(st['exp_avg'].reshape(-1))
+            self.exp_avg_sq[a:b].copy_(st['exp_avg_sq'].reshape(-1))
+            self.step_count = int(float(st['step']))
+
+
+class ELDModel:
+    def name(self):
+        return self.__class__.__name__.lower()
+
+    # ---- BaseModel.initialize (base_model.py:10-16) + ELDModel.initialize (ELD_model.py:370-409) ----------
+    def initialize(self, opt):
+        self.opt = opt
+        self.gpu_ids = opt.gpu_ids
+        self.isTrain = opt.isTrain
+        self.save_dir = os.path.join(getattr(opt, 'checkpoints_dir', './checkpoints'), opt.name)
+        self.epoch = 0
+        self.iterations = 0
+        if not torch.cuda.is_available() or not self.gpu_ids:
+            raise RuntimeError('eld_amd.model.ELDModel needs a GPU (gpu_ids=%r): there is no CPU fallback' % (self.gpu_ids,))
+        self.device = torch.device('cuda', self.gpu_ids[0] if isinstance(self.gpu_ids, (list, tuple)) else int(self.gpu_ids))
+        torch.cuda.set_device(self.device)
+        if getattr(opt, 'stage_in', 'raw') != 'raw' or getattr(opt, 'stage_out', 'raw') != 'raw':
+            raise NotImplementedError('sRGB stages are outside the MI355X hot path (raw->raw only)')
+        ch = getattr(opt, 'channels', 4)
+        self.netG = ARCH[getattr(opt, 'netG', 'unet')](ch, ch).to(self.device)
+        self.world, self.rank = D.world_size(), D.rank()
+        if self.world > 1:
+            D.broadcast_(self.netG.flat_params, 0)          # identical replicas
+        self.loss_pixel = None
+        self.loss_name = getattr(opt, 'loss', 'l1')
+        if self.loss_name != 'l1':
+            raise NotImplementedError("only --loss l1 (the reference's default, train_options.py) is fused")
+        if self.isTrain:
+            self.optimizer_G = FusedAdam(self.netG, lr=opt.lr, betas=(getattr(opt, 'beta1', 0.9), 0.999),
+                                         weight_decay=getattr(opt, 'wd', 0.0))
+            for g in self.optimizer_G.param_groups:          # base_model.py:68-74
+                g['initial_lr'] = opt.lr
+            self.optimizers = [self.optimizer_G]
+            self.schedulers = []
+        self._l1_ws = torch.empty(L.lib().eld_l1_workspace_bytes(), dtype=torch.uint8, device=self.device)
+        self._loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.noise_model = None
+        self._sample_counter = 0
+        if getattr(opt, 'resume', False):
+            self.load(self, getattr(opt, 'resume_epoch', None))
+
+    def set_noise_model(self, noise_model):
+        """Attach the noise plugin used for on-device synthesis of the training input."""
+        self.noise_model = noise_model
+
+    # ---- ELD_model.py:173-200 -----------------------------------------------------------------------------
+    def set_input(self, data, mode='train'):
+        mode = mode.lower()
+        if mode not in ('train', 'eval', 'test'):
+            raise NotImplementedError('Mode [%s] is not implemented' % mode)
+        target = data.get('target') if mode != 'test' else None
+        inp = data.get('input')
+        if target is not None:
+            target = target.to(device=self.device, non_blocking=True)
+        if inp is not None:
+            inp = inp.to(device=self.device, non_blocking=True)
+        elif mode == 'train':
+            inp = self.synthesize(target, data.get('params'), data.get('sample_ids'))
+        else:
+            raise KeyError('input')
+        self.input, self.target = inp, target
+        self.data_name = data.get('fn')
+
+    def synthesize(self, clean, params=None, sample_ids=None):
+        """noisy = clip(noise_model(clean)) on device, one Philox sample id per image (global index:
+        rank-strided so that a given global batch gets the same noise for every world size)."""
+        nm = self.noise_model
+        if nm is None:
+            raise RuntimeError('no noise model attached (set_noise_model) and the batch has no "input"')
+        N = clean.shape[0]
+        if params is None:
+            params = [nm._sample_params() for _ in range(N)]
+        if sample_ids is None:
+            base = self._sample_counter * self.world
+            sample_ids = [base + self.rank + self.world * i for i in range(N)]
+            self._sample_counter += N
+        return sample_noise(clean.contiguous().float(), params, model_flags(nm.model) | L.CLIP, nm.seed, sample_ids)
+
+    # ---- ELD_model.py:422-432 -------------------------------------------------------------------------------
+    def forward(self):
+        if getattr(self.opt, 'chop', False):
+            self.output = self.forward_chop(self.input)
+        else:
+            self.output = self.netG(self.input)
+        return self.output
+
+    def forward_chop(self, x, base=16):              # ELD_model.py:434-467, same tile arithmetic
+        b, c, h, w = x.size()
+        h_half, w_half = h // 2, w // 2
+        shave_h = np.ceil(h_half / base) * base - h_half
+        shave_w = np.ceil(w_half / base) * base - w_half
+        shave_h = shave_h if shave_h >= 10 else shave_h + base
+        shave_w = shave_w if shave_w >= 10 else shave_w + base
+        h_size, w_size = int(h_half + shave_h), int(w_half + shave_w)
+        tiles = [x[:, :, 0:h_size, 0:w_size], x[:, :, 0:h_size, (w - w_size):w],
+                 x[:, :, (h - h_size):h, 0:w_size], x[:, :, (h - h_size):h, (w - w_size):w]]
+        with torch.no_grad():
+            outs = [self.netG(t.contiguous()) for t in tiles]
+        out = x.new_empty(b, outs[0].shape[1], h, w)
+        out[:, :, 0:h_half, 0:w_half] = outs[0][:, :, 0:h_half, 0:w_half]
+        out[:, :, 0:h_half, w_half:w] = outs[1][:, :, 0:h_half, (w_size - w + w_half):w_size]
+        out[:, :, h_half:h, 0:w_half] = outs[2][:, :, (h_size - h + h_half):h_size, 0:w_half]
+        out[:, :, h_half:h, w_half:w] = outs[3][:, :, (h_size - h + h_half):h_size, (w_size - w + w_half):w_size]
+        return out
+
+    # ---- ELD_model.py:469-475: the training iteration -------------------------------------------------------
+    def optimize_parameters(self, **kwargs):
+        net, opt = self.netG, self.optimizer_G
+        x = self.input.contiguous().float()
+        out, key, _ = net._engine_forward(x, save=True)                       # forward()
+        self.output = out
+        dout = torch.empty_like(out)
+        L.check(L.lib().eld_l1_loss(L.dptr(out), L.dptr(self.target.contiguous()), L.dptr(dout), L.dptr(self._loss_buf), L.dptr(self._l1_ws),
+                                    out.numel(), 1.0, L.cur_stream()), 'eld_l1_loss')           # backward_G(): L1 + its gradient
+        net._engine_backward(dout, key, tuple(x.shape), grads=opt.grads)      # loss.backward()
+        w = D.allreduce_sum_(opt.grads)                                       # data-parallel exchange (new)
+        opt.step(grad_scale=1.0 / w)                                          # optimizer_G.step()
+        self.loss_pixel = self._loss_buf
+
+    def get_current_errors(self):                    # ELD_model.py:477-482 (one device sync per call, as the reference)
+        ret = OrderedDict()
+        if self.loss_pixel is not None:
+            ret['Pixel'] = float(D.allreduce_mean_scalar(self.loss_pixel).item())
+        return ret
+
+    def update_learning_rate(self):                  # base_model.py:44-48 (no schedulers in the reference either)
+        lr = self.optimizers[0].param_groups[0]['lr']
+        if self.rank == 0:
+            print('learning rate = %.7f' % lr)
+
+    # ---- evaluation: forward only; PSNR as util/index.py:76-81 on the x255-clipped tensors --------------------
+    @torch.no_grad()
+    def eval(self, data, savedir=None, suffix=None, correct=False, crop=True, frame_id=None):
+        self.set_input(data, 'eval')
+        if crop:                                     # ELD_model.py:219-223
+            def cc(t):
+                _, _, h, w = t.shape
+                y0, x0 = h // 2 - 256, w // 2 - 256
+                return t[:, :, y0:y0 + 512, x0:x0 + 512].contiguous()
+            self.input, self.target = cc(self.input), cc(self.target)
+        out = self.forward()
+        if correct:                                  # IlluminanceCorrect, ELD_model.py:138-169
+            out = illuminance_correct(out, self.target)
+        a = torch.clamp(out[0] * 255.0, 0, 255)      # tensor2im, ELD_model.py:23-38
+        b = torch.clamp(self.target[0] * 255.0, 0, 255)
+        mse = torch.mean((a.double() - b.double()) ** 2)
+        return {'PSNR': float(10.0 * torch.log10(255.0 ** 2 / mse))}
+
+    # ---- checkpoints (base_model.py:55-66, ELD_model.py:492-523) -----------------------------------------------
+    def state_dict(self):
+        return {'netG': self.netG.state_dict(), 'opt_g': self.optimizer_G.state_dict(), 'epoch': self.epoch, 'iterations': self.iterations}
+
+    def save(self, label=None):
+        if self.rank != 0:
+            return
+        os.makedirs(self.save_dir, exist_ok=True)
+        name = 'model_%03d_%08d.pt' % (self.epoch, self.iterations) if label is None else 'model_' + label + '.pt'
+        torch.save(self.state_dict(), os.path.join(self.save_dir, name))
+
+    @staticmethod
+    def load(model, resume_epoch=None):
+        path = getattr(model.opt, 'model_path', None)
+        if path is None:
+            path = os.path.join(model.save_dir, 'model_latest.pt') if resume_epoch is None else \
+                sorted(f for f in (os.path.join(model.save_dir, n) for n in os.listdir(model.save_dir)) if ('model_%03d' % resume_epoch) in f)[-1]
+        sd = torch.load(path, map_location='cpu')
+        model.netG.load_state_dict(sd['netG'])
+        model.epoch, model.iterations = sd['epoch'], sd['iterations']
+        if model.isTrain:
+            model.optimizer_G.load_state_dict(sd['opt_g'])
+        print('Resume from epoch %d, iteration %d' % (model.epoch, model.iterations))
+        return sd
+
+
+def illuminance_correct(predict, source):
+    """ELD_model.py:138-169: alpha = <p,s>/<p,p> over source != 1 on the [0,1]-clamped prediction, per image."""
+    outs = []
+    for i in range(predict.shape[0]):
+        p = torch.clamp(predict[i:i + 1], 0, 1)
+        s = source[i:i + 1] if source.shape[0] != 1 else source
+        m = s != 1
+        pc, sc = p[m], s[m]
+        outs.append(torch.dot(pc, sc) / torch.dot(pc, pc) * p)
+    return torch.cat(outs, 0)
+
+
+def eld_model():                                     # models/__init__.py:3-4
+    return ELDModel()

@@ -352,6 +352,29 @@ def noise_philox(y, p, flags, seed, sample_id):
     return noise_arith(y, p, flags, **v), v
 
 
+def noise_numpy_full(y, p, flags, rng=None):
+    """[unpinned terms] CPU port of the FULL model the way the reference would write it: NumPy legacy
+    RandomState draws (np.random.poisson as noise.py:159, scipy-free Tukey-lambda quantile of a uniform
+    draw, one randn per sensor row, uniform quantisation).  Used as bench.py's cpu_baseline ("port")."""
+    rs = np.random if rng is None else rng
+    v = {}
+    C, H, W = y.shape
+    if flags & SHOT_POISSON:
+        v['counts'] = rs.poisson(poisson_lambda(y, p))
+    elif flags & SHOT_GAUSS:
+        v['n_shot'] = rs.randn(*y.shape).astype(F32)
+    if flags & READ_GAUSS:
+        v['n_read'] = rs.randn(*y.shape).astype(F32)
+    if flags & READ_TL:
+        v['t_tl'] = tukey_lambda_quantile(rs.uniform(size=y.shape).astype(F32).clip(1e-7, 1 - 1e-7), p['tl_lambda'])
+    if flags & ROW:
+        nr = rs.randn(2 * H).astype(F32)
+        v['n_row'] = np.broadcast_to(nr[sensor_row_index(C, H)][:, :, None], y.shape)
+    if flags & QUANT:
+        v['u_q'] = rs.uniform(size=y.shape).astype(F32)
+    return noise_arith(y, p, flags, **v)
+
+
 # --------------------------------------------------------------------------------------
 # integer / indexing helpers either side of the sampler (bit-exact)
 # --------------------------------------------------------------------------------------
