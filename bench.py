@@ -69,9 +69,9 @@ def cpu_baseline(h, w, seed=2018):
     t0 = time.time()
     O.noise_numpy_full(y, p, flags, rng=rs)
     t_noise = time.time() - t0
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)     # torch-CPU convs stop scaling (and oversubscribe) beyond a few dozen threads
     torch.set_num_threads(cores)
-    ch, cw = 512, 512
+    ch, cw = 256, 256
     sd = U.seeded_state_dict(4, 4, seed=seed)
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     opt = torch.optim.Adam(list(params.values()), lr=1e-4)

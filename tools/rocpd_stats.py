@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 rocpd SQLite result (kernel trace) into the per-kernel stats table that
+`rocprofv3 --stats` prints: calls, total/avg/min/max duration, share.  Usage: rocpd_stats.py results.db [out.md]"""
+import sqlite3
+import sys
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+    name_col = 'name' if 'name' in cols else [c for c in cols if 'name' in c][0]
+    rows = cur.execute("select %s, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels group by %s order by 3 desc" % (name_col, name_col)).fetchall()
+    tot = sum(r[2] for r in rows) or 1
+    lines = ['| kernel | calls | total ms | avg us | min us | max us | % |', '|---|---|---|---|---|---|---|']
+    for n, c, s, a, mn, mx in rows:
+        lines.append('| `%s` | %d | %.3f | %.1f | %.1f | %.1f | %.2f |' % (n[:110], c, s / 1e6, a / 1e3, mn / 1e3, mx / 1e3, 100.0 * s / tot))
+    out = '\n'.join(lines)
+    print(out)
+    if len(sys.argv) > 2:
+        open(sys.argv[2], 'w').write(out + '\n')
+
+
+if __name__ == '__main__':
+    main()
