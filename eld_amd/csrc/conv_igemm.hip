@@ -39,7 +39,7 @@ struct Geo {
 };
 
 template <int MODE, int BN, int RPW>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     using G = Geo<MODE, RPW>;
     constexpr int TH = G::TH, TAPS = G::TAPS, A_PIX = G::A_PIX, NT = BN / 32;
     constexpr int A_WORDS = A_PIX * PS, B_ROWS = TAPS * BN;
@@ -50,132 +50,217 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 31, hi = lane >> 5;
     const int NB = a.Nout / BN;
-    const int bid = blockIdx.x;
-    const int nb = bid % NB;
-    int tile = bid / NB;
-    const int tx = tile % a.tiles_x;
-    tile /= a.tiles_x;
-    const int ty = tile % a.tiles_y;
-    const int img = tile / a.tiles_y;
     const int Cin = a.C0 + a.C1;
-    const int y0 = ty * TH, x0 = tx * TW;
     const int Hs = MODE == CONV_GATHER2X2 ? 2 * a.H : a.H;     // source dims
     const int Ws = MODE == CONV_GATHER2X2 ? 2 * a.W : a.W;
+    const int total_tiles = a.tiles_x * a.tiles_y * a.N * NB;
 
-    f32x16 acc[RPW][NT];
+    // Persistent workgroup: walks tiles blockIdx.x, +gridDim.x, ... and streams (tile, chunk) work items
+    // through a register-staged software pipeline (write-after-barrier): the global loads of the NEXT work
+    // item -- the next K chunk, or the first chunk of the next tile -- are issued before the MFMA phase of
+    // the current one and land in registers while the matrix pipe works; they go to LDS after the barrier
+    // that retires the current reads.  The pipeline therefore never drains between tiles; only the
+    // ds_write pass, two barriers per chunk and the epilogue stores are not covered by MFMA work.
+    constexpr int A_UNITS = A_PIX * 4, B_UNITS = B_ROWS * 4;
+    constexpr int A_IT = (A_UNITS + 255) / 256, B_IT = (B_UNITS + 255) / 256;
+    float4 ra[A_IT], rb[B_IT];
+    // Staging loads are buffer loads: one 32-bit byte offset per load (instead of a 64-bit address pair),
+    // the descriptor in SGPRs, the per-chunk channel offset in the scalar offset, and hardware range
+    // checking returns zeros for the OOB marker offset -> the conv's zero padding costs no predicate.
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    unsigned a_voff[A_IT];       // load side: byte offset of the staging unit inside the image, OOB = zero fill
+    unsigned b_voff[B_IT];       // byte offset of the weight unit inside the n-block's slab (chunk offset is scalar)
+    int l_nb = 0, l_img = 0;     // load side: tile being loaded (workgroup-uniform -> SGPRs)
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (int)((size_t)TAPS * a.Nout * Cin * 4), 0x00020000);
 #pragma unroll
-    for (int r = 0; r < RPW; ++r)
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[r][t][i] = 0.f;
+    for (int it = 0; it < B_IT; ++it) {
+        const int u = tid + it * 256;
+        const int row = u >> 2, part = u & 3;
+        const int tap = row / BN, n = row - tap * BN;
+        b_voff[it] = u < B_UNITS ? (unsigned)(((tap * a.Nout + n) * Cin + part * 4) * 4) : OOB;
+    }
 
-    for (int c0 = 0; c0 < Cin; c0 += CK) {
-        const float* src;
-        int Cs, cs;
-        if (c0 < a.C0) { src = a.in0; Cs = a.C0; cs = c0; } else { src = a.in1; Cs = a.C1; cs = c0 - a.C0; }
-        __syncthreads();
-        // ---- stage A: input tile, 4 float4 per pixel ------------------------------------------
-        for (int u = tid; u < A_PIX * 4; u += 256) {
+    auto decode = [&](int t, int& nb, int& img, int& y0, int& x0) {
+        nb = t % NB;
+        int r = t / NB;
+        const int tx = r % a.tiles_x;
+        r /= a.tiles_x;
+        const int ty = r % a.tiles_y;
+        img = r / a.tiles_y;
+        y0 = ty * TH; x0 = tx * TW;
+    };
+    auto setup_load = [&](int t) {
+        int y0, x0;
+        decode(t, l_nb, l_img, y0, x0);
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int u = tid + it * 256;
             const int hp = u >> 2, part = u & 3;
-            int gy, gx;
-            bool ok;
+            int gy = 0, gx = 0;
+            bool ok = u < A_UNITS;
             if (MODE == CONV_3X3) {
                 const int hy = hp / (TW + 2), hx = hp - hy * (TW + 2);
                 gy = y0 + hy - 1; gx = x0 + hx - 1;
-                ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                ok = ok && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
             } else if (MODE == CONV_1X1) {
                 const int py = hp / TW, px = hp - py * TW;
                 gy = y0 + py; gx = x0 + px;
-                ok = gy < a.H && gx < a.W;
+                ok = ok && gy < a.H && gx < a.W;
             } else {
                 const int tap = hp / (TH * TW), lp = hp - tap * (TH * TW);
                 const int py = lp / TW, px = lp - py * TW;
-                ok = (y0 + py) < a.H && (x0 + px) < a.W;
+                ok = ok && (y0 + py) < a.H && (x0 + px) < a.W;
                 gy = 2 * (y0 + py) + (tap >> 1); gx = 2 * (x0 + px) + (tap & 1);
             }
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) v = *reinterpret_cast<const float4*>(src + ((size_t)(img * Hs + gy) * Ws + gx) * Cs + cs + part * 4);
-            *reinterpret_cast<float4*>(ldsA + hp * PS + part * 4) = v;
+            a_voff[it] = ok ? (unsigned)(gy * Ws + gx) * 4u + (unsigned)part : OOB;     // in float4 units of a 16-channel pixel; scaled below
         }
-        // ---- stage B: weights [taps][BN][16] ----------------------------------------------------
-        for (int u = tid; u < B_ROWS * 4; u += 256) {
-            const int row = u >> 2, part = u & 3;
-            const int tap = row / BN, n = row - tap * BN;
-            const float4 v = *reinterpret_cast<const float4*>(a.wp + ((size_t)tap * a.Nout + nb * BN + n) * Cin + c0 + part * 4);
-            *reinterpret_cast<float4*>(ldsB + row * PS + part * 4) = v;
+    };
+    auto load_chunk = [&](int c0) {
+        const float* src;
+        int Cs, cs;
+        if (c0 < a.C0) { src = a.in0; Cs = a.C0; cs = c0; } else { src = a.in1; Cs = a.C1; cs = c0 - a.C0; }
+        const size_t img_elems = (size_t)Hs * Ws * Cs;
+        const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)l_img * img_elems), 0, (int)(img_elems * 4), 0x00020000);
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            // byte offset = (pixel*Cs + part*4)*4 ; a_voff = pixel*4 + part
+            const unsigned pixel = a_voff[it] >> 2, part = a_voff[it] & 3u;
+            const unsigned off = a_voff[it] == OOB ? OOB : (pixel * (unsigned)Cs + part * 4u) * 4u;
+            ra[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)off, cs * 4, 0));
         }
-        __syncthreads();
-        // ---- MFMA over taps x 8 k-steps -----------------------------------------------------------
+        const int wsoff = (l_nb * BN * Cin + c0) * 4;
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            int aoff[RPW];
+        for (int it = 0; it < B_IT; ++it)
+            rb[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)b_voff[it], wsoff, 0));
+    };
+    auto store_chunk = [&]() {
 #pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                const int row = wave * RPW + r;
-                if (MODE == CONV_3X3) aoff[r] = ((row + tap / 3) * (TW + 2) + m + tap % 3) * PS + hi * 8;
-                else if (MODE == CONV_1X1) aoff[r] = (row * TW + m) * PS + hi * 8;
-                else aoff[r] = (tap * TH * TW + row * TW + m) * PS + hi * 8;
+        for (int it = 0; it < A_IT; ++it) {
+            const int u = tid + it * 256;
+            if (u < A_UNITS) *reinterpret_cast<float4*>(ldsA + (u >> 2) * PS + (u & 3) * 4) = ra[it];
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int u = tid + it * 256;
+            if (u < B_UNITS) *reinterpret_cast<float4*>(ldsB + (u >> 2) * PS + (u & 3) * 4) = rb[it];
+        }
+    };
+
+    int t = blockIdx.x;
+    if (t >= total_tiles) return;
+    setup_load(t);
+    load_chunk(0);
+    for (;;) {
+        int nb, img, y0, x0;             // compute / epilogue side of the current tile
+        decode(t, nb, img, y0, x0);
+        const int t_next = t + gridDim.x;
+        f32x16 acc[RPW][NT];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[r][tt][i] = 0.f;
+
+        for (int c0 = 0; c0 < Cin; c0 += CK) {
+            __syncthreads();                 // every wave is done reading the previous chunk
+            store_chunk();
+            __syncthreads();
+            if (c0 + CK < Cin) {
+                load_chunk(c0 + CK);         // in flight during the MFMA phase below
+            } else if (t_next < total_tiles) {
+                setup_load(t_next);
+                load_chunk(0);
             }
+            // ---- MFMA over taps x 8 k-steps; fragments of group g+1 are read from LDS while group g's
+            //      16 MFMAs occupy the matrix pipe (explicit register double-buffering) --------------------
+            float4 fa[2][RPW], fb[2][NT];
+            auto read_group = [&](int g, float4 (&A)[RPW], float4 (&B)[NT]) {
+                const int tap = g >> 1, q = g & 1;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                float4 av[RPW], bv[NT];
+                for (int r = 0; r < RPW; ++r) {
+                    const int row = wave * RPW + r;
+                    int off;
+                    if (MODE == CONV_3X3) off = ((row + tap / 3) * (TW + 2) + m + tap % 3) * PS + hi * 8;
+                    else if (MODE == CONV_1X1) off = (row * TW + m) * PS + hi * 8;
+                    else off = (tap * TH * TW + row * TW + m) * PS + hi * 8;
+                    A[r] = *reinterpret_cast<const float4*>(ldsA + off + q * 4);
+                }
 #pragma unroll
-                for (int r = 0; r < RPW; ++r) av[r] = *reinterpret_cast<const float4*>(ldsA + aoff[r] + q * 4);
+                for (int tt = 0; tt < NT; ++tt) B[tt] = *reinterpret_cast<const float4*>(ldsB + ((tap * BN + tt * 32 + m) * PS + hi * 8) + q * 4);
+            };
+            read_group(0, fa[0], fb[0]);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const float4*>(ldsB + ((tap * BN + t * 32 + m) * PS + hi * 8) + q * 4);
+            for (int g = 0; g < 2 * TAPS; ++g) {
+                const int cur = g & 1;
+                if (g + 1 < 2 * TAPS) read_group(g + 1, fa[cur ^ 1], fb[cur ^ 1]);
+                __builtin_amdgcn_sched_barrier(0);      // keep the prefetch reads ABOVE this group's MFMAs
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
                     for (int r = 0; r < RPW; ++r) {
-                        const float af = kk == 0 ? av[r].x : kk == 1 ? av[r].y : kk == 2 ? av[r].z : av[r].w;
+                        const float af = kk == 0 ? fa[cur][r].x : kk == 1 ? fa[cur][r].y : kk == 2 ? fa[cur][r].z : fa[cur][r].w;
 #pragma unroll
-                        for (int t = 0; t < NT; ++t) {
-                            const float bf = kk == 0 ? bv[t].x : kk == 1 ? bv[t].y : kk == 2 ? bv[t].z : bv[t].w;
-                            acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[r][t], 0, 0, 0);
+                        for (int tt = 0; tt < NT; ++tt) {
+                            const float bf = kk == 0 ? fb[cur][tt].x : kk == 1 ? fb[cur][tt].y : kk == 2 ? fb[cur][tt].z : fb[cur][tt].w;
+                            acc[r][tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[r][tt], 0, 0, 0);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+
+        // ---- epilogue: D layout col = lane&31 (channel), row = (i&3) + 8*(i>>2) + 4*hi (pixel x) --------
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int y = y0 + wave * RPW + r;
+            if (y >= a.H) continue;
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                const int n = nb * BN + tt * 32 + m;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int x = x0 + (i & 3) + 8 * (i >> 2) + 4 * hi;
+                    if (x >= a.W) continue;
+                    float v = acc[r][tt][i];
+                    const size_t pix = (size_t)(img * a.H + y) * a.W + x;
+                    if (a.epi == EPI_FWD) {
+                        v += a.bias[n];
+                        if (a.lrelu) v = fmaxf(0.2f * v, v);
+                        a.out0[pix * a.Nout + n] = v;
+                    } else if (a.epi == EPI_CONVT_FWD) {
+                        const int tap = n / a.Cout_t, co = n - tap * a.Cout_t;
+                        const size_t op = (size_t)(img * 2 * a.H + 2 * y + (tap >> 1)) * (2 * a.W) + 2 * x + (tap & 1);
+                        a.out0[op * a.Cout_t + co] = v + a.bias[co];
+                    } else {
+                        if (n < a.split) {
+                            const size_t idx = pix * a.split + n;
+                            if (a.act0) v *= lrelu_slope(a.act0[idx]);
+                            a.out0[idx] = v;
+                        } else {
+                            const size_t idx = pix * (a.Nout - a.split) + (n - a.split);
+                            if (a.act1) v *= lrelu_slope(a.act1[idx]);
+                            a.out1[idx] = v;
                         }
                     }
                 }
             }
         }
+        if (t_next >= total_tiles) break;
+        t = t_next;
     }
+}
 
-    // ---- epilogue: D layout col = lane&31 (channel), row = (i&3) + 8*(i>>2) + 4*hi (pixel x) ------------
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-        const int y = y0 + wave * RPW + r;
-        if (y >= a.H) continue;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int n = nb * BN + t * 32 + m;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int x = x0 + (i & 3) + 8 * (i >> 2) + 4 * hi;
-                if (x >= a.W) continue;
-                float v = acc[r][t][i];
-                const size_t pix = (size_t)(img * a.H + y) * a.W + x;
-                if (a.epi == EPI_FWD) {
-                    v += a.bias[n];
-                    if (a.lrelu) v = fmaxf(0.2f * v, v);
-                    a.out0[pix * a.Nout + n] = v;
-                } else if (a.epi == EPI_CONVT_FWD) {
-                    const int tap = n / a.Cout_t, co = n - tap * a.Cout_t;
-                    const size_t op = (size_t)(img * 2 * a.H + 2 * y + (tap >> 1)) * (2 * a.W) + 2 * x + (tap & 1);
-                    a.out0[op * a.Cout_t + co] = v + a.bias[co];
-                } else {
-                    if (n < a.split) {
-                        const size_t idx = pix * a.split + n;
-                        if (a.act0) v *= lrelu_slope(a.act0[idx]);
-                        a.out0[idx] = v;
-                    } else {
-                        const size_t idx = pix * (a.Nout - a.split) + (n - a.split);
-                        if (a.act1) v *= lrelu_slope(a.act1[idx]);
-                        a.out1[idx] = v;
-                    }
-                }
-            }
-        }
+static int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        if (n <= 0) n = 256;
     }
+    return n;
 }
 
 template <int MODE, int BN, int RPW>
@@ -184,9 +269,9 @@ static int launch_t(ConvArgs a, hipStream_t st) {
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + G::TH - 1) / G::TH;
     const size_t lds_bytes = (size_t)(G::A_PIX + G::TAPS * BN) * PS * sizeof(float);
-    const long long blocks = (long long)a.tiles_x * a.tiles_y * a.N * (a.Nout / BN);
-    if (blocks <= 0) return 0;
-    if (blocks > 0x7fffffffLL) return ELD_ENOTSUP;
+    const long long tiles = (long long)a.tiles_x * a.tiles_y * a.N * (a.Nout / BN);
+    if (tiles <= 0) return 0;
+    if (tiles > 0x7fffffffLL) return ELD_ENOTSUP;
     auto kern = conv_igemm_kernel<MODE, BN, RPW>;
     static bool attr_set = false;     // per instantiation
     if (!attr_set) {
@@ -194,7 +279,13 @@ static int launch_t(ConvArgs a, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
+    // persistent grid: as many workgroups as are co-resident (LDS: 160 KiB per CU; registers: 2 waves per SIMD)
+    int per_cu = (int)((160 * 1024) / lds_bytes);
+    if (per_cu > 2) per_cu = 2;
+    if (per_cu < 1) per_cu = 1;
+    long long grid = (long long)num_cus() * per_cu;
+    if (grid > tiles) grid = tiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, st, a);
     ELD_LAUNCH_CHECK();
     return 0;
 }

@@ -60,24 +60,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 
     const int tiles_per_img = a.tiles_x * a.tiles_y;
     const int ntiles = tiles_per_img * a.N;
-    for (int tile = ps; tile < ntiles; tile += a.psplit) {
+    // register-staged pipeline: tile t+1's global loads are in flight during tile t's MFMA phase
+    constexpr int G_UNITS = TPIX * (COB / 4), X_UNITS = X_PIX * (JB / 4);
+    constexpr int G_IT = (G_UNITS + 255) / 256, X_IT = (X_UNITS + 255) / 256;
+    float4 rg[G_IT], rx[X_IT];
+    auto load_tile = [&](int tile) {
         const int img = tile / tiles_per_img;
         const int trem = tile - img * tiles_per_img;
         const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
         const int y0 = ty * TH, x0 = tx * TW;
-        __syncthreads();
-        // ---- stage G tile [TPIX][COB] (zeros outside the image) -----------------------------------
-        for (int u = tid; u < TPIX * (COB / 4); u += 256) {
+#pragma unroll
+        for (int it = 0; it < G_IT; ++it) {
+            const int u = tid + it * 256;
             const int lp = u / (COB / 4), part = u - lp * (COB / 4);
             const int py = lp / TW, px = lp - py * TW;
             const int gy = y0 + py, gx = x0 + px;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy < a.H && gx < a.W)
-                v = *reinterpret_cast<const float4*>(a.g + ((size_t)(img * a.H + gy) * a.W + gx) * a.CA + i0 + part * 4);
-            *reinterpret_cast<float4*>(ldsG + lp * COB + part * 4) = v;
+            rg[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u < G_UNITS && gy < a.H && gx < a.W)
+                rg[it] = *reinterpret_cast<const float4*>(a.g + ((size_t)(img * a.H + gy) * a.W + gx) * a.CA + i0 + part * 4);
         }
-        // ---- stage X tile [X_PIX][JB] -----------------------------------------------------------------
-        for (int u = tid; u < X_PIX * (JB / 4); u += 256) {
+#pragma unroll
+        for (int it = 0; it < X_IT; ++it) {
+            const int u = tid + it * 256;
             const int hp = u / (JB / 4), part = u - hp * (JB / 4);
             int gy, gx; bool ok;
             if (MODE == CONV_3X3) {
@@ -90,14 +94,32 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
                 ok = (y0 + py) < a.H && (x0 + px) < a.W;
                 gy = 2 * (y0 + py) + (tap >> 1); gx = 2 * (x0 + px) + (tap & 1);
             }
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok && part * 4 < jvalid)
-                v = *reinterpret_cast<const float4*>(xsrc + ((size_t)(img * Hx + gy) * Wx + gx) * Cs + cs + part * 4);
-            *reinterpret_cast<float4*>(ldsX + hp * JB + part * 4) = v;
+            rx[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u < X_UNITS && ok && part * 4 < jvalid)
+                rx[it] = *reinterpret_cast<const float4*>(xsrc + ((size_t)(img * Hx + gy) * Wx + gx) * Cs + cs + part * 4);
         }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < G_IT; ++it) {
+            const int u = tid + it * 256;
+            if (u < G_UNITS) *reinterpret_cast<float4*>(ldsG + u * 4) = rg[it];          // [lp][COB] is unit-linear
+        }
+#pragma unroll
+        for (int it = 0; it < X_IT; ++it) {
+            const int u = tid + it * 256;
+            if (u < X_UNITS) *reinterpret_cast<float4*>(ldsX + u * 4) = rx[it];          // [hp][JB] is unit-linear
+        }
+    };
+
+    if (ps < ntiles) load_tile(ps);
+    for (int tile = ps; tile < ntiles; tile += a.psplit) {
         __syncthreads();
+        store_tile();
+        __syncthreads();
+        if (tile + a.psplit < ntiles) load_tile(tile + a.psplit);
         // ---- K loop over this wave's pixels: lanes 0-31 take pixel s, lanes 32-63 pixel s + KS ---------
-#pragma unroll 2
+#pragma unroll 1
         for (int s = 0; s < KS; ++s) {
             const int lp = wpix * PW + s + hi * KS;
             const float av = ldsG[lp * COB + wco * 32 + m];
