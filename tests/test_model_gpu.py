@@ -1,0 +1,216 @@
+"""GPU tests of the model / engine plugins: the fused training iteration (sampler -> U-Net -> L1 -> backward ->
+Adam) against the CPU oracle, checkpoint interchange with torch's Adam, the autograd drop-in path, data-parallel
+semantics and the epoch driver.  Reference surface: models/ELD_model.py:172-523, engine.py:10-128."""
+import os
+import types
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip('torch')
+
+from oracle import noise_ref as O      # noqa: E402  (checker only)
+from oracle import unet_ref as U       # noqa: E402
+
+
+def make_opt(tmp, **kw):
+    d = dict(gpu_ids=[0], isTrain=True, checkpoints_dir=str(tmp), name='t', netG='unet', channels=4, stage_in='raw', stage_out='raw',
+             lr=1e-4, beta1=0.9, wd=0.0, loss='l1', resume=False, chop=False, no_log=False, save_epoch_freq=2, model='eld_model')
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+def new_model(tmp, seed=2018, **kw):
+    from eld_amd.model import ELDModel
+    torch.manual_seed(seed)
+    m = ELDModel()
+    m.initialize(make_opt(tmp, **kw))
+    return m
+
+
+def batch(shape=(2, 4, 32, 48), seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(*shape, generator=g), torch.rand(*shape, generator=g)
+
+
+def test_training_steps_match_oracle(eld_lib, tmp_path):
+    """3 fused iterations == 3 iterations of (torch-CPU forward, L1, backward, torch.optim.Adam) from the same init."""
+    m = new_model(tmp_path)
+    sd = {k: v.detach().cpu().clone() for k, v in m.netG.state_dict().items()}
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    opt = torch.optim.Adam(list(params.values()), lr=1e-4, betas=(0.9, 0.999))
+    for it in range(3):
+        x, t = batch(seed=it)
+        m.set_input({'input': x, 'target': t}, 'train')
+        m.optimize_parameters()
+        loss = m.get_current_errors()['Pixel']
+        opt.zero_grad()
+        lref = torch.nn.functional.l1_loss(U.unet_forward(params, x), t)
+        lref.backward()
+        opt.step()
+        assert abs(loss - float(lref)) < 2e-6 * (it + 1) + 1e-6, (it, loss, float(lref))
+    got = m.netG.state_dict()
+    for k, v in params.items():
+        # Adam's first steps move every weight by ~lr regardless of gradient scale: compare the UPDATE, sign-stable part
+        d_ref = v.detach() - sd[k]
+        d_got = got[k].cpu() - sd[k]
+        assert float((d_got - d_ref).abs().max()) < 3e-5, k       # |update| <= 3e-4 after 3 steps; tiny-gradient elements may flip
+
+
+def test_on_device_synthesis_matches_sampler_and_oracle(eld_lib, tmp_path):
+    from eld_amd.noise import NoiseModel, NoiseParams, sample_noise, model_flags
+    from eld_amd import _lib as L
+    m = new_model(tmp_path)
+    nm = NoiseModel(model='PGRU', include=4)
+    m.set_noise_model(nm)
+    t = (torch.floor(65535 * torch.rand(2, 4, 32, 48) ** 2.2) / 65535)
+    p = [NoiseParams(2.288, 6.451, 15583, 208.98, tl_lambda=-0.14285714, tl_scale=3.3, row_scale=0.9)] * 2
+    m.set_input({'target': t, 'params': p, 'sample_ids': [7, 8]}, 'train')
+    flags = model_flags('PGRU') | L.CLIP
+    dump = torch.zeros(L.NPLANES, t.numel(), device='cuda')
+    z = sample_noise(t.cuda(), p, flags, nm.seed, [7, 8], dump=dump)
+    assert torch.equal(m.input, z) and float(m.input.min()) >= 0 and float(m.input.max()) <= 1
+    dv = dump.cpu().numpy()
+    op = O.Params(K=2.288, g_scale=6.451, ratio=208.98, tl_lambda=-0.14285714, tl_scale=3.3, row_scale=0.9)
+    for i in range(2):
+        v = {k: dv[j].reshape(t.shape)[i] for k, j in L.PLANE.items()}
+        assert np.array_equal(z[i].cpu().numpy(), O.noise_arith(t[i].numpy(), op, flags, **v))
+    # default ids are global, rank-strided and advance with the step
+    np.random.seed(1)
+    m.set_input({'target': t}, 'train')
+    a = m.input.clone()
+    m.set_input({'target': t}, 'train')
+    assert not torch.equal(a, m.input)
+    m.optimize_parameters()
+    assert np.isfinite(m.get_current_errors()['Pixel'])
+
+
+def test_checkpoint_interchange_with_torch_adam(eld_lib, tmp_path):
+    from eld_amd.unet import UNetSeeInDark
+    m = new_model(tmp_path)
+    x, t = batch()
+    for _ in range(2):
+        m.set_input({'input': x, 'target': t}, 'train')
+        m.optimize_parameters()
+    m.epoch, m.iterations = 3, 77
+    m.save(label='latest')
+    path = os.path.join(str(tmp_path), 't', 'model_latest.pt')
+    sd = torch.load(path, map_location='cpu')
+    assert set(sd) == {'netG', 'opt_g', 'epoch', 'iterations'} and sd['epoch'] == 3 and sd['iterations'] == 77
+    assert len(sd['netG']) == 46 and sd['netG']['upv6.weight'].shape == (512, 256, 2, 2)
+    # (a) the reference's own way of loading it: plain module + torch.optim.Adam (ELD_model.py:492-514)
+    net = UNetSeeInDark(4, 4)
+    net.load_state_dict(sd['netG'])
+    topt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.999))
+    topt.load_state_dict(sd['opt_g'])
+    st = topt.state[list(net.parameters())[0]]
+    assert float(st['step']) == 2.0 and st['exp_avg'].shape == (32, 4, 3, 3)
+    # (b) resume in a fresh fused model and continue identically
+    m2 = new_model(tmp_path, seed=1, resume=True, resume_epoch=None)
+    assert m2.epoch == 3 and m2.iterations == 77 and m2.optimizer_G.step_count == 2
+    assert torch.equal(m2.netG.flat_params, m.netG.flat_params) and torch.equal(m2.optimizer_G.exp_avg, m.optimizer_G.exp_avg)
+    for mm in (m, m2):
+        mm.set_input({'input': x, 'target': t}, 'train')
+        mm.optimize_parameters()
+    assert torch.equal(m2.netG.flat_params, m.netG.flat_params)
+    # (c) a torch-Adam state dict loads into the fused optimizer
+    m.optimizer_G.load_state_dict(topt.state_dict())
+    assert m.optimizer_G.step_count == 2
+
+
+def test_autograd_dropin_path_equals_fused_path(eld_lib, tmp_path):
+    """arch plugin inside the reference's own loop shape: netG(x) -> nn.L1Loss -> backward -> torch.optim.Adam.step."""
+    from eld_amd.unet import unet
+    torch.manual_seed(5)
+    net = unet(4, 4).cuda()
+    m = new_model(tmp_path, seed=5)
+    assert torch.equal(net.flat_params, m.netG.flat_params)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=0.0)
+    crit = torch.nn.L1Loss()
+    for it in range(2):
+        x, t = batch(seed=10 + it)
+        out = net(x.cuda())
+        opt.zero_grad()
+        loss = crit(out, t.cuda())
+        loss.backward()
+        opt.step()
+        m.set_input({'input': x, 'target': t}, 'train')
+        m.optimize_parameters()
+        assert abs(float(loss) - m.get_current_errors()['Pixel']) < 1e-6
+        assert torch.equal(m.output, out.detach())
+    assert float((net.flat_params - m.netG.flat_params).abs().max()) < 1e-6
+
+
+def test_data_parallel_semantics_on_one_gpu(eld_lib, tmp_path):
+    """sum-all-reduce of per-rank gradients with grad_scale = 1/world == gradient of the global-batch mean loss
+    (equal shard sizes): checked by linearity of the engine's backward on one device."""
+    m = new_model(tmp_path)
+    x, t = batch(shape=(2, 4, 32, 32))
+    net = m.netG
+    def grads(xb, tb):
+        out, key, _ = net._engine_forward(xb.cuda(), save=True)
+        dout = torch.sign(out - tb.cuda()) / out.numel()
+        return net._engine_backward(dout.contiguous(), key, tuple(xb.shape)).clone()
+    g_full = grads(x, t)
+    g0, g1 = grads(x[:1], t[:1]), grads(x[1:], t[1:])
+    ref = 0.5 * (g0 + g1)
+    assert float((g_full - ref).abs().max()) <= 1e-6 + 1e-4 * float(ref.abs().max())
+
+
+def test_forward_chop_and_eval_psnr(eld_lib, tmp_path):
+    m = new_model(tmp_path, chop=True)
+    sd = {k: v.detach().cpu() for k, v in m.netG.state_dict().items()}
+    x, t = batch(shape=(1, 4, 64, 96), seed=4)
+    m.set_input({'input': x, 'target': t, 'fn': ['a']}, 'eval')
+    with torch.no_grad():
+        out = m.forward().cpu()
+    # oracle chop (ELD_model.py:434-467): h_half=32 -> h_size 48; w_half=48 -> w_size 64
+    hs, ws_ = 48, 64
+    tiles = [x[:, :, :hs, :ws_], x[:, :, :hs, 96 - ws_:], x[:, :, 64 - hs:, :ws_], x[:, :, 64 - hs:, 96 - ws_:]]
+    with torch.no_grad():
+        o = [U.unet_forward(sd, tt) for tt in tiles]
+    ref = torch.empty(1, 4, 64, 96)
+    ref[:, :, :32, :48] = o[0][:, :, :32, :48]
+    ref[:, :, :32, 48:] = o[1][:, :, :32, ws_ - 48:]
+    ref[:, :, 32:, :48] = o[2][:, :, hs - 32:, :48]
+    ref[:, :, 32:, 48:] = o[3][:, :, hs - 32:, ws_ - 48:]
+    assert float((out - ref).abs().max()) < 1e-5
+    m.opt.chop = False
+    r = m.eval({'input': x, 'target': t, 'fn': ['a']}, crop=False, correct=True)
+    with torch.no_grad():
+        pred = torch.clamp(U.unet_forward(sd, x), 0, 1)
+    alpha = torch.dot(pred[t != 1], t[t != 1]) / torch.dot(pred[t != 1], pred[t != 1])
+    a = np.clip((alpha * pred)[0].numpy() * 255.0, 0, 255)
+    b = np.clip(t[0].numpy() * 255.0, 0, 255)
+    psnr = 10 * np.log10(255.0 ** 2 / np.mean((a.astype(np.float64) - b) ** 2))
+    assert abs(r['PSNR'] - psnr) < 1e-3
+
+
+def test_engine_train_loop(eld_lib, tmp_path, capsys):
+    from eld_amd.engine import Engine
+    torch.manual_seed(0)
+    eng = Engine(make_opt(tmp_path))
+    assert eng.epoch == 0 and eng.iterations == 0
+    eng.set_learning_rate(5e-5)
+    assert eng.model.optimizers[0].param_groups[0]['lr'] == 5e-5
+    loader = [dict(zip(('input', 'target'), batch(shape=(1, 4, 32, 32), seed=s))) for s in range(3)]
+    meters = eng.train(loader)
+    assert eng.epoch == 1 and eng.iterations == 3 and np.isfinite(meters['Pixel'])
+    first = meters['Pixel']
+    for _ in range(3):
+        meters = eng.train(loader)
+    assert eng.epoch == 4 and eng.iterations == 12
+    assert meters['Pixel'] < first                                    # it learns
+    files = sorted(os.listdir(os.path.join(str(tmp_path), 't')))
+    assert 'model_latest.pt' in files and any(f.startswith('model_002_') for f in files) and any(f.startswith('model_004_') for f in files)
+    out = capsys.readouterr().out
+    assert 'learning rate = 0.0000500' in out and 'Epoch: 0' in out
+
+
+def test_model_requires_gpu_and_raw_stage(eld_lib, tmp_path):
+    from eld_amd.model import ELDModel
+    with pytest.raises(RuntimeError):
+        ELDModel().initialize(make_opt(tmp_path, gpu_ids=[]))
+    with pytest.raises(NotImplementedError):
+        ELDModel().initialize(make_opt(tmp_path, stage_in='srgb'))
