@@ -138,7 +138,10 @@ def test_autograd_dropin_path_equals_fused_path(eld_lib, tmp_path):
         m.set_input({'input': x, 'target': t}, 'train')
         m.optimize_parameters()
         assert abs(float(loss) - m.get_current_errors()['Pixel']) < 1e-6
-        assert torch.equal(m.output, out.detach())
+        if it == 0:
+            assert torch.equal(m.output, out.detach())          # same engine, same weights: same bits
+        else:                                                   # torch Adam vs fused Adam differ by a few ulp per weight
+            assert float((m.output - out.detach()).abs().max()) < 1e-5
     assert float((net.flat_params - m.netG.flat_params).abs().max()) < 1e-6
 
 
