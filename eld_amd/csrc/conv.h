@@ -30,6 +30,7 @@ struct ConvArgs {
     const float* act1;
     int Cout_t;         // EPI_CONVT_FWD: real Cout (Nout = 4*Cout_t, n = tap*Cout_t + co)
     int tiles_x, tiles_y;
+    int dbg;            // ablation switches for tools/ (env ELD_CONV_DBG): 1 skip epilogue, 2 skip MFMA, 4 skip staging loads
 };
 
 // d/dx max(0.2x, x) as autograd computes it for torch.max(0.2*x, x) (models/arch/Unet.py:102-104):

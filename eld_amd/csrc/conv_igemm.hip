@@ -25,6 +25,7 @@
 // is >= 18k cycles of matrix work per wave against ~60 KB of staged operands: the kernel is
 // MFMA-bound and a plain stage -> barrier -> compute -> barrier loop with >= 2 workgroups per CU
 // (LDS <= 80 KB each) keeps the matrix pipe busy while the other workgroup stages.
+#include <stdlib.h>
 #include "conv.h"
 
 #define CK 16
@@ -54,6 +55,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     const int Hs = MODE == CONV_GATHER2X2 ? 2 * a.H : a.H;     // source dims
     const int Ws = MODE == CONV_GATHER2X2 ? 2 * a.W : a.W;
     const int total_tiles = a.tiles_x * a.tiles_y * a.N * NB;
+    const int Cs0 = a.C0;                                       // channels per source tensor
 
     // Persistent workgroup: walks tiles blockIdx.x, +gridDim.x, ... and streams (tile, chunk) work items
     // through a register-staged software pipeline (write-after-barrier): the global loads of the NEXT work
@@ -112,22 +114,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
                 ok = ok && (y0 + py) < a.H && (x0 + px) < a.W;
                 gy = 2 * (y0 + py) + (tap >> 1); gx = 2 * (x0 + px) + (tap & 1);
             }
-            a_voff[it] = ok ? (unsigned)(gy * Ws + gx) * 4u + (unsigned)part : OOB;     // in float4 units of a 16-channel pixel; scaled below
+            a_voff[it] = ok ? ((unsigned)(gy * Ws + gx) * (unsigned)Cs0 + (unsigned)part * 4u) * 4u : OOB;     // final byte offset
         }
     };
     auto load_chunk = [&](int c0) {
-        const float* src;
-        int Cs, cs;
-        if (c0 < a.C0) { src = a.in0; Cs = a.C0; cs = c0; } else { src = a.in1; Cs = a.C1; cs = c0 - a.C0; }
-        const size_t img_elems = (size_t)Hs * Ws * Cs;
+        // both concat sources have the same channel count (checked at launch), so one set of offsets serves both
+        const float* src = c0 < a.C0 ? a.in0 : a.in1;
+        const int cs = c0 < a.C0 ? c0 : c0 - a.C0;
+        const size_t img_elems = (size_t)Hs * Ws * Cs0;
         const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)l_img * img_elems), 0, (int)(img_elems * 4), 0x00020000);
 #pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            // byte offset = (pixel*Cs + part*4)*4 ; a_voff = pixel*4 + part
-            const unsigned pixel = a_voff[it] >> 2, part = a_voff[it] & 3u;
-            const unsigned off = a_voff[it] == OOB ? OOB : (pixel * (unsigned)Cs + part * 4u) * 4u;
-            ra[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)off, cs * 4, 0));
-        }
+        for (int it = 0; it < A_IT; ++it)
+            ra[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)a_voff[it], cs * 4, 0));
         const int wsoff = (l_nb * BN * Cin + c0) * 4;
 #pragma unroll
         for (int it = 0; it < B_IT; ++it)
@@ -150,6 +148,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     if (t >= total_tiles) return;
     setup_load(t);
     load_chunk(0);
+    // De-phase the co-resident workgroups: the grid is (#CUs x 2) persistent workgroups doing identical work per
+    // tile, so without an offset both workgroups of a CU sit in their epilogue (matrix pipe idle) at the same
+    // time.  The second wave of workgroups starts half a tile late; the offset persists because tile times are equal.
+    if ((a.dbg & 8) == 0 && (int)blockIdx.x >= (int)gridDim.x / 2) {
+        const int naps = (Cin / CK) * TAPS * RPW * NT * 8 * 64 / 2 / (64 * 64);      // half of the tile's MFMA cycles, in 4096-cycle naps
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(64);
+    }
     for (;;) {
         int nb, img, y0, x0;             // compute / epilogue side of the current tile
         decode(t, nb, img, y0, x0);
@@ -166,12 +171,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
             __syncthreads();                 // every wave is done reading the previous chunk
             store_chunk();
             __syncthreads();
-            if (c0 + CK < Cin) {
-                load_chunk(c0 + CK);         // in flight during the MFMA phase below
-            } else if (t_next < total_tiles) {
-                setup_load(t_next);
-                load_chunk(0);
+            if (!(a.dbg & 4)) {
+                if (c0 + CK < Cin) {
+                    load_chunk(c0 + CK);         // in flight during the MFMA phase below
+                } else if (t_next < total_tiles) {
+                    setup_load(t_next);
+                    load_chunk(0);
+                }
             }
+            if (a.dbg & 2) continue;
             // ---- MFMA over taps x 8 k-steps; fragments of group g+1 are read from LDS while group g's
             //      16 MFMAs occupy the matrix pipe (explicit register double-buffering) --------------------
             float4 fa[2][RPW], fb[2][NT];
@@ -211,38 +219,71 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
             }
         }
 
-        // ---- epilogue: D layout col = lane&31 (channel), row = (i&3) + 8*(i>>2) + 4*hi (pixel x) --------
+        // ---- epilogue: D layout col = lane&31 (channel), row = (i&3) + 8*(i>>2) + 4*hi (pixel x).
+        //      Per 32x32 accumulator tile: every load (bias, saved activations) is issued and consumed BEFORE the
+        //      first store, and interior tiles take a branch-free path -- otherwise the compiler re-waits vmcnt(0) inside
+        //      every exec-masked bounds-check block, which serialises the stores on their own completion.
+        const bool interior = x0 + TW <= a.W;
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             const int y = y0 + wave * RPW + r;
-            if (y >= a.H) continue;
+            if (y >= a.H || (a.dbg & 1)) continue;
+            const size_t rowpix = (size_t)(img * a.H + y) * a.W;
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
                 const int n = nb * BN + tt * 32 + m;
+                const int xb = x0 + 4 * hi;
+                float v[16];
+                float* dst;
+                size_t pstride;          // elements between horizontally adjacent pixels in dst
+                if (a.epi == EPI_FWD) {
+                    const float bias = a.bias[n];
+                    dst = a.out0 + (rowpix + xb) * a.Nout + n;
+                    pstride = a.Nout;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int x = x0 + (i & 3) + 8 * (i >> 2) + 4 * hi;
-                    if (x >= a.W) continue;
-                    float v = acc[r][tt][i];
-                    const size_t pix = (size_t)(img * a.H + y) * a.W + x;
-                    if (a.epi == EPI_FWD) {
-                        v += a.bias[n];
-                        if (a.lrelu) v = fmaxf(0.2f * v, v);
-                        a.out0[pix * a.Nout + n] = v;
-                    } else if (a.epi == EPI_CONVT_FWD) {
-                        const int tap = n / a.Cout_t, co = n - tap * a.Cout_t;
-                        const size_t op = (size_t)(img * 2 * a.H + 2 * y + (tap >> 1)) * (2 * a.W) + 2 * x + (tap & 1);
-                        a.out0[op * a.Cout_t + co] = v + a.bias[co];
-                    } else {
-                        if (n < a.split) {
-                            const size_t idx = pix * a.split + n;
-                            if (a.act0) v *= lrelu_slope(a.act0[idx]);
-                            a.out0[idx] = v;
-                        } else {
-                            const size_t idx = pix * (a.Nout - a.split) + (n - a.split);
-                            if (a.act1) v *= lrelu_slope(a.act1[idx]);
-                            a.out1[idx] = v;
+                    for (int i = 0; i < 16; ++i) {
+                        float t = acc[r][tt][i] + bias;
+                        v[i] = a.lrelu ? fmaxf(0.2f * t, t) : t;
+                    }
+                } else if (a.epi == EPI_CONVT_FWD) {
+                    const int tap = n / a.Cout_t, co = n - tap * a.Cout_t;
+                    const float bias = a.bias[co];
+                    dst = a.out0 + ((size_t)(img * 2 * a.H + 2 * y + (tap >> 1)) * (2 * a.W) + 2 * xb + (tap & 1)) * a.Cout_t + co;
+                    pstride = 2 * (size_t)a.Cout_t;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) v[i] = acc[r][tt][i] + bias;
+                } else {
+                    const bool lo = n < a.split;
+                    const int C = lo ? a.split : a.Nout - a.split;
+                    const int nn = lo ? n : n - a.split;
+                    dst = (lo ? a.out0 : a.out1) + (rowpix + xb) * C + nn;
+                    pstride = C;
+                    const float* act = lo ? a.act0 : a.act1;
+                    if (act) {
+                        const float* ap = act + (rowpix + xb) * C + nn;
+                        float s[16];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int dx = (i & 3) + 8 * (i >> 2);
+                            s[i] = (interior || xb + dx < a.W) ? ap[(size_t)dx * C] : 0.f;
                         }
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) v[i] = acc[r][tt][i] * lrelu_slope(s[i]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) v[i] = acc[r][tt][i];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(v[i]));      // values are final here: no load result is consumed below
+                if (interior) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) dst[(size_t)((i & 3) + 8 * (i >> 2)) * pstride] = v[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int dx = (i & 3) + 8 * (i >> 2);
+                        if (xb + dx < a.W) dst[(size_t)dx * pstride] = v[i];
                     }
                 }
             }
@@ -290,9 +331,14 @@ static int launch_t(ConvArgs a, hipStream_t st) {
     return 0;
 }
 
-int launch_conv(const ConvArgs& a, int mode, hipStream_t st) {
+int launch_conv(const ConvArgs& a_in, int mode, hipStream_t st) {
+    ConvArgs a = a_in;
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("ELD_CONV_DBG"); dbg = e ? atoi(e) : 0; }
+    a.dbg = dbg;
     const int Cin = a.C0 + a.C1;
     if (Cin % CK || a.C0 % CK || a.Nout % 32) return ELD_EINVAL;
+    if (a.C1 != 0 && a.C1 != a.C0) return ELD_ENOTSUP;          // virtual concat of two equally wide tensors (all the U-Net needs)
     if (a.epi == EPI_GRAD && (a.split % 32)) return ELD_EINVAL;
     const bool n64 = a.Nout % 64 == 0;
     switch (mode) {
