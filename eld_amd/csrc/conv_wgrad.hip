@@ -60,24 +60,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 
     const int tiles_per_img = a.tiles_x * a.tiles_y;
     const int ntiles = tiles_per_img * a.N;
-    // register-staged pipeline: tile t+1's global loads are in flight during tile t's MFMA phase
+    // Register-staged pipeline: tile t+1's global loads (buffer loads: 32-bit offsets, SGPR descriptor, hardware
+    // zero-fill for the out-of-image marker) are in flight during tile t's MFMA phase and go to LDS after the barrier.
     constexpr int G_UNITS = TPIX * (COB / 4), X_UNITS = X_PIX * (JB / 4);
     constexpr int G_IT = (G_UNITS + 255) / 256, X_IT = (X_UNITS + 255) / 256;
+    constexpr unsigned OOB = 0xFFFFFFF0u;
     float4 rg[G_IT], rx[X_IT];
+    const size_t g_img = (size_t)a.H * a.W * a.CA, x_img = (size_t)Hx * Wx * Cs;
     auto load_tile = [&](int tile) {
         const int img = tile / tiles_per_img;
         const int trem = tile - img * tiles_per_img;
         const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
         const int y0 = ty * TH, x0 = tx * TW;
+        const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)(a.g + (size_t)img * g_img), 0, (int)(g_img * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(xsrc + (size_t)img * x_img), 0, (int)(x_img * 4), 0x00020000);
+        unsigned og[G_IT], ox[X_IT];
 #pragma unroll
         for (int it = 0; it < G_IT; ++it) {
             const int u = tid + it * 256;
             const int lp = u / (COB / 4), part = u - lp * (COB / 4);
             const int py = lp / TW, px = lp - py * TW;
             const int gy = y0 + py, gx = x0 + px;
-            rg[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (u < G_UNITS && gy < a.H && gx < a.W)
-                rg[it] = *reinterpret_cast<const float4*>(a.g + ((size_t)(img * a.H + gy) * a.W + gx) * a.CA + i0 + part * 4);
+            og[it] = (u < G_UNITS && gy < a.H && gx < a.W) ? (unsigned)((gy * a.W + gx) * a.CA + part * 4) * 4u : OOB;
         }
 #pragma unroll
         for (int it = 0; it < X_IT; ++it) {
@@ -94,10 +98,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
                 ok = (y0 + py) < a.H && (x0 + px) < a.W;
                 gy = 2 * (y0 + py) + (tap >> 1); gx = 2 * (x0 + px) + (tap & 1);
             }
-            rx[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (u < X_UNITS && ok && part * 4 < jvalid)
-                rx[it] = *reinterpret_cast<const float4*>(xsrc + ((size_t)(img * Hx + gy) * Wx + gx) * Cs + cs + part * 4);
+            ox[it] = (u < X_UNITS && ok && part * 4 < jvalid) ? (unsigned)((gy * Wx + gx) * Cs + part * 4) * 4u : OOB;
         }
+#pragma unroll
+        for (int it = 0; it < G_IT; ++it) rg[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, (int)og[it], i0 * 4, 0));
+#pragma unroll
+        for (int it = 0; it < X_IT; ++it) rx[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)ox[it], cs * 4, 0));
     };
     auto store_tile = [&]() {
 #pragma unroll
@@ -112,27 +118,39 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
         }
     };
 
+    // LDS read bases of this lane: step s of the K loop reads pixel lp0 + s (no row wrap inside a wave's slice),
+    // so every read is base + compile-time offset.
+    const int lp0 = wpix * PW + hi * KS;
+    const int py0 = lp0 / TW, px0 = lp0 - py0 * TW;
+    const float* gbase = ldsG + lp0 * COB + wco * 32 + m;
+    const float* xbase = ldsX + (MODE == CONV_3X3 ? (py0 * (TW + 2) + px0) : lp0) * JB + m;
+
     if (ps < ntiles) load_tile(ps);
     for (int tile = ps; tile < ntiles; tile += a.psplit) {
         __syncthreads();
         store_tile();
         __syncthreads();
         if (tile + a.psplit < ntiles) load_tile(tile + a.psplit);
-        // ---- K loop over this wave's pixels: lanes 0-31 take pixel s, lanes 32-63 pixel s + KS ---------
-#pragma unroll 1
-        for (int s = 0; s < KS; ++s) {
-            const int lp = wpix * PW + s + hi * KS;
-            const float av = ldsG[lp * COB + wco * 32 + m];
-            bsum += av;
-            const int py = lp / TW, px = lp - py * TW;
+        // ---- K loop, fully unrolled; operands of step s+1 are read from LDS under step s's MFMAs -------------
+        float fa[2], fb[2][TAPS];
+        auto read_step = [&](int s_, float& A, float (&B)[TAPS]) {
+            A = gbase[s_ * COB];
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) {
-                int xp;
-                if (MODE == CONV_3X3) xp = (py + t / 3) * (TW + 2) + px + t % 3;
-                else xp = t * TPIX + lp;
-                const float bv = ldsX[xp * JB + m];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                const int toff = MODE == CONV_3X3 ? ((t / 3) * (TW + 2) + t % 3) : t * TPIX;
+                B[t] = xbase[(toff + s_) * JB];
             }
+        };
+        read_step(0, fa[0], fb[0]);
+#pragma unroll
+        for (int s_ = 0; s_ < KS; ++s_) {
+            const int cur = s_ & 1;
+            if (s_ + 1 < KS) read_step(s_ + 1, fa[cur ^ 1], fb[cur ^ 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            bsum += fa[cur];
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur], fb[cur][t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -207,33 +225,50 @@ int launch_wgrad(const WgradArgs& a, int mode, hipStream_t st) {
     return ELD_EINVAL;
 }
 
-// out[(i*CBr + j)*T + tap] = sum_s part[s][tap][i][j]; fixed summation order -> deterministic
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart, float* __restrict__ wgrad,
-                                    float* __restrict__ bgrad, int psplit, int T, int CA, int CBp, int CBr) {
+// out[(i*CBr + j)*T + tap] = sum_s part[s][tap][i][j].  Each output element is summed by SL lanes (slice k takes
+// partials k, k+SL, ...; slices are combined by a fixed xor-shuffle tree), so the order is fixed -> run-to-run
+// bit-stable, and small planes with many partials (the 32-channel layers) still fill the chip.
+template <int SL>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart, float* __restrict__ wgrad,
+                                                           float* __restrict__ bgrad, int psplit, int T, int CA, int CBp, int CBr) {
+    constexpr int EPW = 64 / SL;                 // elements per wave
     const size_t plane = (size_t)T * CA * CBp;
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e_in_wave = lane % EPW, slice = lane / EPW;
+    const size_t idx = ((size_t)blockIdx.x * 4 + wave) * EPW + e_in_wave;
+    float s = 0.f;
     if (idx < plane) {
+        const float* p = part + idx;
+#pragma unroll 4
+        for (int k = slice; k < psplit; k += SL) s += p[(size_t)k * plane];
+    }
+#pragma unroll
+    for (int off = EPW; off < 64; off <<= 1) s += __shfl_xor(s, off, 64);
+    if (slice == 0 && idx < plane) {
         const int j = (int)(idx % CBp);
         const int i = (int)((idx / CBp) % CA);
         const int t = (int)(idx / ((size_t)CBp * CA));
-        if (j < CBr) {
-            float s = 0.f;
-            for (int p = 0; p < psplit; ++p) s += part[p * plane + idx];
-            wgrad[((size_t)i * CBr + j) * T + t] = s;
-        }
+        if (j < CBr) wgrad[((size_t)i * CBr + j) * T + t] = s;
     }
-    if (bgrad && idx < (size_t)CA) {
-        float s = 0.f;
-        for (int p = 0; p < psplit; ++p) s += bpart[(size_t)p * CA + idx];
-        bgrad[idx] = s;
+    if (bgrad && blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < CA; c += 256) {
+            float b = 0.f;
+            for (int k = 0; k < psplit; ++k) b += bpart[(size_t)k * CA + c];
+            bgrad[c] = b;
+        }
     }
 }
 
 int launch_wgrad_reduce(const float* part, const float* bpart, float* wgrad, float* bgrad, int psplit, int T, int CA,
                         int CBp, int CBr, hipStream_t st) {
     const size_t plane = (size_t)T * CA * CBp;
-    const unsigned blocks = (unsigned)((plane + 255) / 256);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, part, bpart, wgrad, bgrad, psplit, T, CA, CBp, CBr);
+    if (psplit >= 32) {
+        const unsigned blocks = (unsigned)((plane + 4 * 4 - 1) / (4 * 4));          // 16 slices -> 4 elements per wave
+        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(blocks), dim3(256), 0, st, part, bpart, wgrad, bgrad, psplit, T, CA, CBp, CBr);
+    } else {
+        const unsigned blocks = (unsigned)((plane + 4 * 16 - 1) / (4 * 16));        // 4 slices -> 16 elements per wave
+        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st, part, bpart, wgrad, bgrad, psplit, T, CA, CBp, CBr);
+    }
     ELD_LAUNCH_CHECK();
     return 0;
 }

@@ -156,7 +156,7 @@ int launch_head_fwd(const float* in, const float* w, const float* b, float* out,
 
 // backward: g[p][c] = (sum_o W[o][c] d[o][p]) * slope(act[p][c]);  dW[o][c] = sum_p d[o][p] act[p][c];  db[o] = sum_p d[o][p]
 // per-block partials [nblocks][132] -> reduced by head_bwd_reduce_kernel in fixed order.
-#define HEAD_BLOCKS 1024
+#define HEAD_BLOCKS 512
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ act, const float* __restrict__ w,
                                                        float* __restrict__ g, float* __restrict__ part, int N, size_t HW, int OC) {
     __shared__ float sw[128];
@@ -212,11 +212,16 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
         part[(size_t)blockIdx.x * 132 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-__global__ void head_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nblocks, int OC) {
-    const int t = threadIdx.x;
-    if (t >= 132) return;
+// 132 outputs, 16 lanes each over the per-block partials; fixed shuffle tree
+__global__ __launch_bounds__(256) void head_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nblocks, int OC) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = (blockIdx.x * 4 + wave) * 4 + (lane & 3), slice = lane >> 2;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * 132 + t];
+    if (t < 132)
+        for (int b = slice; b < nblocks; b += 16) s += part[(size_t)b * 132 + t];
+#pragma unroll
+    for (int off = 4; off < 64; off <<= 1) s += __shfl_xor(s, off, 64);
+    if (slice != 0 || t >= 132) return;
     if (t < 128) { if (t / 32 < OC) dw[t] = s; } else if (t - 128 < OC) db[t - 128] = s;
 }
 
@@ -229,7 +234,7 @@ int launch_head_bwd(const float* dout, const float* act, const float* w, float* 
     const int nb = (int)min((total + 255) / 256, (size_t)HEAD_BLOCKS);
     hipLaunchKernelGGL(head_bwd_kernel, dim3(nb), dim3(256), 0, st, dout, act, w, g, part, N, (size_t)H * W, OC);
     ELD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3(1), dim3(192), 0, st, part, dw, db, nb, OC);
+    hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3((132 + 15) / 16), dim3(256), 0, st, part, dw, db, nb, OC);
     ELD_LAUNCH_CHECK();
     return 0;
 }
@@ -237,7 +242,7 @@ int launch_head_bwd(const float* dout, const float* act, const float* w, float* 
 // ------------------------------------------------------------------------------------------------
 // column sums of an NHWC matrix [P][C] -> [C]  (bias gradient of the transposed convs)
 // ------------------------------------------------------------------------------------------------
-#define COLSUM_BLOCKS 512
+#define COLSUM_BLOCKS 256
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ part, size_t P, int C) {
     // thread t handles channel (t % C4)*4.. of pixels t / C4 + k*(256/C4 * gridDim)
     const int C4 = C / 4;
@@ -260,12 +265,16 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     }
 }
 
-__global__ void colsum_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nblocks, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// one wave per 4 channels: 16 lanes per channel split the partials, fixed xor-shuffle tree (deterministic)
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nblocks, int C) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 4 + wave) * 4 + (lane & 3), slice = lane >> 2;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * C + c];
-    out[c] = s;
+    if (c < C)
+        for (int b = slice; b < nblocks; b += 16) s += part[(size_t)b * C + c];
+#pragma unroll
+    for (int off = 4; off < 64; off <<= 1) s += __shfl_xor(s, off, 64);
+    if (slice == 0 && c < C) out[c] = s;
 }
 
 size_t colsum_ws_floats(int C) { return (size_t)COLSUM_BLOCKS * C; }
@@ -277,7 +286,7 @@ int launch_colsum(const float* x, float* out, float* part, size_t P, int C, hipS
     if (nb == 0) return 0;
     hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, st, x, part, P, C);
     ELD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, out, nb, C);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, out, nb, C);
     ELD_LAUNCH_CHECK();
     return 0;
 }
