@@ -109,6 +109,7 @@ def main():
         raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)' % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: eld_amd has no CPU fallback')
+    local = local % torch.cuda.device_count()       # (ranks may share a GPU only in the gloo smoke test of the N>1 path)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     import eld_amd
