@@ -14,6 +14,7 @@
 //   * the float32 op sequence is exactly the reference's (one rounding per op, FMA contraction
 //     OFF for this translation unit), so with injected variates the output is bit-identical to
 //     the reference's NumPy evaluation.
+#include <stdlib.h>
 #include "philox.h"
 
 #pragma clang fp contract(off)
@@ -21,8 +22,12 @@
 #define NOISE_THREADS 256
 #define NOISE_ITERS 4
 #define GROUPS_PER_BLOCK (NOISE_THREADS * NOISE_ITERS)
+#define ELEMS_PER_BLOCK (GROUPS_PER_BLOCK * 4)
 #define MAX_LDS_ROWS 256
 #define RUNTIME_FLAGS 0xFFFFFFFFu
+#define INV_ITERS1 12          // inversion steps done in the dense first pass; leftovers go to the queue
+#define QP_CAP 1024            // PTRS rejections per 4096 pixels: 12-25 % of the PTRS draws (8 B entries)
+#define QI_CAP 256             // inversion leftovers (16 B entries); queue overflow is resolved in place
 
 struct NoiseArgs {
     const void* in;
@@ -35,13 +40,26 @@ struct NoiseArgs {
     FastDiv divW, divH;    // divW divides by W/4 in the vector kernel, by W in the scalar kernel
     uint32_t flags, in_dtype;
     PhiloxKey key;
+    uint32_t dbg;          // ablation switches (env ELD_NOISE_DBG): 1 skip queue drain, 2 skip inversion loop, 4 skip PTRS attempt 0, 8 skip phase 3 RNG
 };
 
 // ---------------------------------------------------------------------------------------------
-// Poisson(lam): CDF inversion (lam < 10) or PTRS transformed rejection (Hoermann 1993; the split
-// and the sampler NumPy's legacy RandomState.poisson uses, which is what noise.py:159 calls).
-// float32 throughout; oracle statement: oracle/noise_ref.py::_pois_inversion/_ptrs_attempt.
+// Poisson(lam): CDF inversion (lam < 10) or PTRS transformed rejection (Hoermann 1993; the split and
+// the sampler NumPy's legacy RandomState.poisson uses, which is what noise.py:159 calls).  float32
+// throughout; the CPU statement of exactly this word usage is oracle/noise_ref.py::_poisson_philox.
+//
+// Divergence control: the exact draw has data-dependent loops (inversion: ~lam steps; PTRS: slow accept
+// test and retries for ~15-20 % of the draws).  A workgroup therefore makes ONE dense pass over its 4096
+// pixels that resolves the cheap majority (INV_ITERS1 inversion steps jointly over 8 pixels per lane;
+// PTRS attempt 0 with its squeeze test from a single 32-bit word), pushes the rest into two LDS queues,
+// and then drains the queues with every lane busy.  Counts meet the rest of the pipeline through LDS.
 // ---------------------------------------------------------------------------------------------
+// The variate transforms below are NOT part of the reference's arithmetic (they replace NumPy's RNG internals), so they
+// may use FMA contraction and the hardware reciprocal / square root; only the op chain of noise.py:155-169 in phase 3
+// has to round like NumPy.
+#pragma clang fp contract(fast)
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 __device__ __forceinline__ float log1pmx(float x) {   // log1p(x) - x without cancellation
     if (fabsf(x) < 0.125f) {
         float s = 0.f;
@@ -61,65 +79,69 @@ __device__ __forceinline__ float log1pmx(float x) {   // log1p(x) - x without ca
 // -lam + k*log(lam) - lgamma(k+1), Stirling form (k >= 1), stable in float32
 __device__ __forceinline__ float pois_logpmf(float k, float lam) {
     if (k < 0.5f) return -lam;
-    const float x = (lam - k) / k;
-    const float rk = 1.0f / k, rk2 = rk * rk;
+    const float rk = frcp(k), rk2 = rk * rk;
+    const float x = (lam - k) * rk;
     const float corr = rk * ((1.f / 12.f) - rk2 * ((1.f / 360.f) - rk2 * (1.f / 1260.f)));
     return k * log1pmx(x) - 0.5f * __logf(6.2831853071795865f * k) - corr;
 }
 
-__device__ __forceinline__ float poisson_draw(float lam, uint32_t wu, uint32_t wv, uint32_t elem, const SamplerRng& rng) {
-    lam = fmaxf(lam, 0.f);
-    if (lam < 10.0f) {
-        const float u = u01(wu);
-        float p = __expf(-lam), F = p;
-        int k = 0;
-        while (u > F && k < 96) {
-            ++k;
-            p = p * (lam / (float)k);
-            F = F + p;
-        }
-        return (float)k;
+struct Ptrs {
+    float a, b, invalpha, vr;
+    __device__ __forceinline__ void init(float lam) {
+        const float slam = __builtin_amdgcn_sqrtf(lam);
+        b = 0.931f + 2.53f * slam;
+        a = -0.059f + 0.02483f * b;
+        invalpha = 1.1239f + 1.1328f * frcp(b - 3.4f);
+        vr = 0.9277f - 3.6224f * frcp(b - 2.0f);
     }
-    const float slam = __builtin_sqrtf(lam);
-    const float b = 0.931f + 2.53f * slam;
-    const float a = -0.059f + 0.02483f * b;
-    const float invalpha = 1.1239f + 1.1328f / (b - 3.4f);
-    const float vr = 0.9277f - 3.6224f / (b - 2.0f);
-    float U01 = u01(wu), V = u01(wv);
-    uint4 w = make_uint4(0, 0, 0, 0);
-    uint32_t iter = 0;
-    bool second = false;
-    float k = 0.f;
-    for (;;) {
+    __device__ __forceinline__ float k_of(float lam, float U01, float& us) const {
         const float U = U01 - 0.5f;
-        const float us = 0.5f - fabsf(U);
-        k = floorf((2.0f * a / us + b) * U + lam + 0.43f);
-        if (us >= 0.07f && V <= vr) break;
-        const bool rej = (k < 0.f) || (us < 0.013f && V > us);
-        if (!rej) {
-            const float lhs = __logf(V) + __logf(invalpha) - __logf(a / (us * us) + b);
-            if (lhs <= pois_logpmf(k, lam)) break;
-        }
-        if (!second) {
-            if (iter >= 64) { k = fmaxf(k, 0.f); break; }
-            w = rng.words(elem, STREAM_POIS_R, iter);
-            U01 = u01(w.x); V = u01(w.y);
-            second = true;
-        } else {
-            U01 = u01(w.z); V = u01(w.w);
-            second = false;
-            ++iter;
-        }
+        us = 0.5f - fabsf(U);
+        return floorf((2.0f * a * frcp(us) + b) * U + lam + 0.43f);
     }
-    return k;
+    __device__ __forceinline__ bool slow_accept(float lam, float k, float us, float V) const {
+        if ((k < 0.f) || (us < 0.013f && V > us)) return false;
+        const float lhs = __logf(V) + __logf(invalpha) - __logf(a * frcp(us * us) + b);
+        return lhs <= pois_logpmf(k, lam);
+    }
+};
+
+// finish a PTRS draw whose attempt 0 was rejected: attempts 2c+1, 2c+2 from retry call c of this element
+__device__ float ptrs_resolve(float lam, uint32_t elem, const SamplerRng& rng) {
+    Ptrs P;
+    P.init(lam);
+    float k = 0.f;
+    for (uint32_t call = 0; call < 64u; ++call) {
+        const uint4 r = rng.words(elem, STREAM_POIS_R, call);
+        float us;
+        k = P.k_of(lam, u01(r.x), us);
+        float V = u01(r.y);
+        if ((us >= 0.07f && V <= P.vr) || P.slow_accept(lam, k, us, V)) return k;
+        k = P.k_of(lam, u01(r.z), us);
+        V = u01(r.w);
+        if ((us >= 0.07f && V <= P.vr) || P.slow_accept(lam, k, us, V)) return k;
+    }
+    return fmaxf(k, 0.f);
 }
 
-// unit-scale Tukey-lambda quantile from one word: u = u01(w), 1-u = u01(~w) (exact complement)
-__device__ __forceinline__ float tukey_lambda(uint32_t w, float lam) {
+// finish an inversion draw after INV_ITERS1 steps (state p, r)
+__device__ float inv_resolve(float lam, float p, float r) {
+    int k = INV_ITERS1;
+    for (int it = INV_ITERS1 + 1; r > 0.f && it <= 96; ++it) {
+        ++k;
+        p = p * (lam * frcp((float)it));
+        r = r - p;
+    }
+    return (float)k;
+}
+
+// unit-scale Tukey-lambda quantile from one word: u = u01(w), 1-u = u01(~w) (exact complement); inv_lam = 1/lam (per image)
+__device__ __forceinline__ float tukey_lambda(uint32_t w, float lam, float inv_lam) {
     const float lu = __builtin_amdgcn_logf(u01(w)), lv = __builtin_amdgcn_logf(u01(~w));
     if (lam == 0.0f) return (lu - lv) * 0.6931471805599453f;
-    return (__builtin_amdgcn_exp2f(lam * lu) - __builtin_amdgcn_exp2f(lam * lv)) / lam;
+    return (__builtin_amdgcn_exp2f(lam * lu) - __builtin_amdgcn_exp2f(lam * lv)) * inv_lam;
 }
+#pragma clang fp contract(off)
 
 __device__ __forceinline__ uint32_t pick(const uint4& w, int j) { return j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w; }
 
@@ -128,9 +150,39 @@ __device__ __forceinline__ float row_normal(uint32_t srow, const SamplerRng& rng
     return box_muller(w.x, w.y).x;
 }
 
+template <bool VEC>
+__device__ __forceinline__ void load_y4(const NoiseArgs& a, size_t img_off, uint32_t e0, uint32_t nvalid, float (&y)[4]) {
+    if (VEC) {
+        if (a.in_dtype == ELD_IN_U16) {
+            const ushort4 q = *reinterpret_cast<const ushort4*>(static_cast<const uint16_t*>(a.in) + img_off + e0);
+            y[0] = (float)q.x / 65535.0f; y[1] = (float)q.y / 65535.0f; y[2] = (float)q.z / 65535.0f; y[3] = (float)q.w / 65535.0f;
+        } else {
+            const float4 q = *reinterpret_cast<const float4*>(static_cast<const float*>(a.in) + img_off + e0);
+            y[0] = q.x; y[1] = q.y; y[2] = q.z; y[3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            y[j] = 0.f;
+            if ((uint32_t)j < nvalid)
+                y[j] = (a.in_dtype == ELD_IN_U16) ? (float)static_cast<const uint16_t*>(a.in)[img_off + e0 + j] / 65535.0f
+                                                  : static_cast<const float*>(a.in)[img_off + e0 + j];
+        }
+    }
+    if (a.in_dtype == ELD_IN_U16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = fminf(fmaxf(y[j], 0.f), 1.f);   // lmdb_dataset.py:39
+    }
+}
+
 template <bool VEC, uint32_t TFLAGS, bool DEBUG>
 __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a) {
+    constexpr bool MAYBE_P = (TFLAGS == RUNTIME_FLAGS) || (TFLAGS & ELD_SHOT_POISSON);
     __shared__ float s_row[MAX_LDS_ROWS];
+    __shared__ float s_cnt[MAYBE_P ? ELEMS_PER_BLOCK : 1];
+    __shared__ uint2 s_qp[MAYBE_P ? QP_CAP : 1];
+    __shared__ uint4 s_qi[MAYBE_P ? QI_CAP : 1];
+    __shared__ uint32_t s_qn[2];
     const uint32_t flags = (TFLAGS == RUNTIME_FLAGS) ? a.flags : TFLAGS;
     const uint32_t n = blockIdx.y;
     const EldNoiseParams P = a.params[n];             // wave-uniform -> scalar loads
@@ -139,14 +191,19 @@ __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a)
     rng.sid_lo = P.sample_id_lo;
     rng.sid_hi = P.sample_id_hi;
 
+    const uint32_t tid = threadIdx.x;
     const uint32_t g_begin = blockIdx.x * GROUPS_PER_BLOCK;
     const uint32_t g_end = min(g_begin + GROUPS_PER_BLOCK, a.ngroups);
     const size_t img_off = (size_t)n * a.chw;
+    const bool inject = DEBUG && a.inject != nullptr;
+    const bool do_pois = MAYBE_P && (flags & ELD_SHOT_POISSON) && !inject;
+    const float S = P.saturation, ratio = P.ratio, K = P.K;
+
+    if (do_pois && tid < 2) s_qn[tid] = 0;
 
     // ---- row normals of this block's rows -> LDS ------------------------------------------------
     uint32_t r_first = 0;
     bool lds_rows = false;
-    const bool inject = DEBUG && a.inject != nullptr;
     if ((flags & ELD_ROW) && !inject) {
         const uint32_t e_first = g_begin * 4u, e_last = min(g_end * 4u, a.chw) - 1u;
         r_first = VEC ? fdiv_u32(g_begin, a.divW) : fdiv_u32(e_first, a.divW);
@@ -154,54 +211,152 @@ __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a)
         const uint32_t nrows = r_last - r_first + 1u;
         lds_rows = nrows <= MAX_LDS_ROWS;
         if (lds_rows) {
-            for (uint32_t t = threadIdx.x; t < nrows; t += NOISE_THREADS) {
+            for (uint32_t t = tid; t < nrows; t += NOISE_THREADS) {
                 const uint32_t r = r_first + t;
                 const uint32_t c = fdiv_u32(r, a.divH), h = r - c * a.H;
                 s_row[t] = row_normal(2u * h + (c >> 1), rng);
             }
-            __syncthreads();
         }
     }
+    __syncthreads();
 
-    const float S = P.saturation, ratio = P.ratio, K = P.K;
+    // ================================ phase 1 + 2: Poisson counts -> s_cnt ================================
+    if (do_pois) {
+        const float lam_c = (S * (1.0f / ratio)) * (1.0f / K);      // lam = y * lam_c  (oracle: poisson_lambda_fast)
+#pragma unroll 1
+        for (int half = 0; half < NOISE_ITERS / 2; ++half) {
+            float lam[8], p[8], r[8];
+            uint32_t w[8], wv[8];
+            int kk[8];
+            bool ok[8];
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi) {
+                const uint32_t g = g_begin + (half * 2 + gi) * NOISE_THREADS + tid;
+                const bool gv = g < g_end;
+                const uint32_t e0 = g * 4u;
+                const uint32_t nvalid = gv ? (VEC ? 4u : min(4u, a.chw - e0)) : 0u;
+                float y[4] = {0.f, 0.f, 0.f, 0.f};
+                uint4 wd = make_uint4(0, 0, 0, 0), wd2 = make_uint4(0, 0, 0, 0);
+                if (gv) {
+                    load_y4<VEC>(a, img_off, e0, nvalid, y);
+                    wd = rng.words(g, STREAM_POIS_U);
+                    wd2 = rng.words(g, STREAM_POIS_V);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = gi * 4 + j;
+                    ok[e] = (uint32_t)j < nvalid;
+                    lam[e] = fmaxf(y[j] * lam_c, 0.f);
+                    w[e] = pick(wd, j);
+                    wv[e] = pick(wd2, j);
+                }
+            }
+            // ---- inversion, INV_ITERS1 joint branch-free steps (lam < 10) -------------------------------
+            bool any_small = false;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool small = ok[e] && lam[e] < 10.0f;
+                p[e] = small ? __expf(-lam[e]) : 0.f;
+                r[e] = small ? u01(w[e]) - p[e] : -1.0f;
+                kk[e] = 0;
+                any_small |= small;
+            }
+            if (__any(any_small) && !(a.dbg & 2)) {
+#pragma unroll 1
+                for (int it = 1; it <= INV_ITERS1; ++it) {
+                    bool act = false;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) act |= r[e] > 0.f;
+                    if (!__any(act)) break;
+                    const float inv = __builtin_amdgcn_rcpf((float)it);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const bool go = r[e] > 0.f;
+                        kk[e] += go ? 1 : 0;
+                        p[e] = p[e] * (lam[e] * inv);
+                        r[e] = go ? r[e] - p[e] : r[e];
+                    }
+                }
+            }
+            // ---- PTRS attempt 0 (lam >= 10), complete: squeeze test, then the slow test where it fails ----------
+            //      kk[e] = count, pend bit set when the draw is still open (PTRS rejection / inversion leftover)
+            uint32_t pendP = 0, pendI = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (!ok[e]) continue;
+                if (lam[e] < 10.0f) {
+                    if (r[e] > 0.f) pendI |= 1u << e;
+                } else if (a.dbg & 4) {
+                    kk[e] = (int)lam[e];
+                } else {
+                    Ptrs T;
+                    T.init(lam[e]);
+                    float us;
+                    const float k0 = T.k_of(lam[e], u01(w[e]), us);
+                    const float V = u01(wv[e]);
+                    bool acc = us >= 0.07f && V <= T.vr;
+                    if (!acc) acc = T.slow_accept(lam[e], k0, us, V);
+                    kk[e] = (int)k0;
+                    if (!acc) pendP |= 1u << e;
+                }
+            }
+            // ---- one LDS atomic per lane per queue reserves the slots of its open draws --------------------------
+            uint32_t baseP = 0, baseI = 0;
+            if (pendP) baseP = atomicAdd(&s_qn[0], (uint32_t)__popc(pendP));
+            if (pendI) baseI = atomicAdd(&s_qn[1], (uint32_t)__popc(pendI));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (!ok[e]) continue;
+                const uint32_t le = (uint32_t)(half * 2 + (e >> 2)) * (NOISE_THREADS * 4u) + tid * 4u + (uint32_t)(e & 3);
+                if (pendP & (1u << e)) {
+                    const uint32_t pos = baseP + (uint32_t)__popc(pendP & ((1u << e) - 1u));
+                    if (pos < QP_CAP) s_qp[pos] = make_uint2(le, __float_as_uint(lam[e]));
+                    else s_cnt[le] = ptrs_resolve(lam[e], g_begin * 4u + le, rng);
+                } else if (pendI & (1u << e)) {
+                    const uint32_t pos = baseI + (uint32_t)__popc(pendI & ((1u << e) - 1u));
+                    if (pos < QI_CAP) s_qi[pos] = make_uint4(le, __float_as_uint(lam[e]), __float_as_uint(p[e]), __float_as_uint(r[e]));
+                    else s_cnt[le] = inv_resolve(lam[e], p[e], r[e]);
+                } else {
+                    s_cnt[le] = (float)kk[e];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: drain the queues with dense lanes -------------------------------------------------------
+        const uint32_t nP = (a.dbg & 1) ? 0u : min(s_qn[0], (uint32_t)QP_CAP), nI = (a.dbg & 1) ? 0u : min(s_qn[1], (uint32_t)QI_CAP);
+        for (uint32_t q = tid; q < nP; q += NOISE_THREADS) {
+            const uint2 en = s_qp[q];
+            s_cnt[en.x] = ptrs_resolve(__uint_as_float(en.y), g_begin * 4u + en.x, rng);
+        }
+        for (uint32_t q = tid; q < nI; q += NOISE_THREADS) {
+            const uint4 en = s_qi[q];
+            s_cnt[en.x] = inv_resolve(__uint_as_float(en.y), __uint_as_float(en.z), __uint_as_float(en.w));
+        }
+        __syncthreads();
+    }
+
+    // ================================ phase 3: the rest of the model + reference arithmetic ===================
     const float g_sigma = fmaxf(P.g_scale, 1e-10f);
-
+    const float inv_tl_lambda = P.tl_lambda != 0.f ? 1.0f / P.tl_lambda : 0.f;
 #pragma unroll 1
     for (int it = 0; it < NOISE_ITERS; ++it) {
-        const uint32_t g = g_begin + it * NOISE_THREADS + threadIdx.x;
+        const uint32_t g = g_begin + it * NOISE_THREADS + tid;
         if (g >= g_end) break;
         const uint32_t e0 = g * 4u;
         const uint32_t nvalid = VEC ? 4u : min(4u, a.chw - e0);
+        const uint32_t le0 = (uint32_t)it * (NOISE_THREADS * 4u) + tid * 4u;
 
-        float y[4];
-        if (VEC) {
-            if (a.in_dtype == ELD_IN_U16) {
-                const ushort4 q = *reinterpret_cast<const ushort4*>(static_cast<const uint16_t*>(a.in) + img_off + e0);
-                y[0] = (float)q.x / 65535.0f; y[1] = (float)q.y / 65535.0f; y[2] = (float)q.z / 65535.0f; y[3] = (float)q.w / 65535.0f;
-            } else {
-                const float4 q = *reinterpret_cast<const float4*>(static_cast<const float*>(a.in) + img_off + e0);
-                y[0] = q.x; y[1] = q.y; y[2] = q.z; y[3] = q.w;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                y[j] = 0.f;
-                if ((uint32_t)j < nvalid)
-                    y[j] = (a.in_dtype == ELD_IN_U16) ? (float)static_cast<const uint16_t*>(a.in)[img_off + e0 + j] / 65535.0f
-                                                      : static_cast<const float*>(a.in)[img_off + e0 + j];
-            }
-        }
-        if (a.in_dtype == ELD_IN_U16) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) y[j] = fminf(fmaxf(y[j], 0.f), 1.f);   // lmdb_dataset.py:39
-        }
+        float y[4] = {0.f, 0.f, 0.f, 0.f};
+        if (!do_pois || !(flags & ELD_SHOT_POISSON) || DEBUG) load_y4<VEC>(a, img_off, e0, nvalid, y);
+        float4 cnt4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (do_pois) cnt4 = *reinterpret_cast<const float4*>(&s_cnt[le0]);
 
         // one Philox call per needed stream per group
-        uint4 w_tl, w_q, w_pu, w_pv;
+        uint4 w_tl, w_q;
         float nrd[4], nsh[4];
         if (!inject) {
-            if (flags & ELD_READ_TL) w_tl = rng.words(g, STREAM_TL);
-            if (flags & ELD_QUANT) w_q = rng.words(g, STREAM_QUANT);
+            if (flags & ELD_READ_TL) w_tl = (a.dbg & 8) ? make_uint4(g, g * 3u, g * 5u, g * 7u) : rng.words(g, STREAM_TL);
+            if (flags & ELD_QUANT) w_q = (a.dbg & 8) ? make_uint4(g, g * 3u, g * 5u, g * 7u) : rng.words(g, STREAM_QUANT);
             if (flags & ELD_READ_GAUSS) {
                 const uint4 w = rng.words(g, STREAM_NREAD);
                 const float2 p0 = box_muller(w.x, w.y), p1 = box_muller(w.z, w.w);
@@ -211,10 +366,6 @@ __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a)
                 const uint4 w = rng.words(g, STREAM_NSHOT);
                 const float2 p0 = box_muller(w.x, w.y), p1 = box_muller(w.z, w.w);
                 nsh[0] = p0.x; nsh[1] = p0.y; nsh[2] = p1.x; nsh[3] = p1.y;
-            }
-            if (flags & ELD_SHOT_POISSON) {
-                w_pu = rng.words(g, STREAM_POIS_U);
-                w_pv = rng.words(g, STREAM_POIS_V);
             }
         }
 
@@ -231,25 +382,26 @@ __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a)
             if (!VEC && (flags & (ELD_ROW | ELD_CBIAS))) r = fdiv_u32(e, a.divW);
 
             float v_cnt = 0.f, v_nshot = 0.f, v_nread = 0.f, v_tl = 0.f, v_nrow = 0.f, v_uq = 0.f;
-            const float y1 = y[j] * S;            // noise.py:155
-            const float y2 = y1 / ratio;          // noise.py:156
             float zz;
             if (flags & ELD_SHOT_POISSON) {       // noise.py:158-159
-                v_cnt = inject ? a.inject[ELD_PLANE_COUNT * a.total + ge]
-                               : poisson_draw(y2 / K, pick(w_pu, j), pick(w_pv, j), e, rng);
+                v_cnt = inject ? a.inject[ELD_PLANE_COUNT * a.total + ge] : (j == 0 ? cnt4.x : j == 1 ? cnt4.y : j == 2 ? cnt4.z : cnt4.w);
                 zz = v_cnt * K;
-            } else if (flags & ELD_SHOT_GAUSS) {  // noise.py:160-161
-                v_nshot = inject ? a.inject[ELD_PLANE_NSHOT * a.total + ge] : nsh[j];
-                zz = y2 + v_nshot * __builtin_sqrtf(fmaxf(K * y2, 1e-10f));
-            } else {                              // noise.py:162-163
-                zz = y2;
+            } else {
+                const float y1 = y[j] * S;        // noise.py:155
+                const float y2 = y1 / ratio;      // noise.py:156
+                if (flags & ELD_SHOT_GAUSS) {     // noise.py:160-161
+                    v_nshot = inject ? a.inject[ELD_PLANE_NSHOT * a.total + ge] : nsh[j];
+                    zz = y2 + v_nshot * __builtin_sqrtf(fmaxf(K * y2, 1e-10f));
+                } else {                          // noise.py:162-163
+                    zz = y2;
+                }
             }
             if (flags & ELD_READ_GAUSS) {         // noise.py:165-166
                 v_nread = inject ? a.inject[ELD_PLANE_NREAD * a.total + ge] : nrd[j];
                 zz = zz + v_nread * g_sigma;
             }
             if (flags & ELD_READ_TL) {
-                v_tl = inject ? a.inject[ELD_PLANE_TL * a.total + ge] : tukey_lambda(pick(w_tl, j), P.tl_lambda);
+                v_tl = inject ? a.inject[ELD_PLANE_TL * a.total + ge] : tukey_lambda(pick(w_tl, j), P.tl_lambda, inv_tl_lambda);
                 zz = zz + v_tl * P.tl_scale;
             }
             if (flags & ELD_ROW) {
@@ -325,6 +477,9 @@ extern "C" int eld_noise_forward(const void* in, int in_dtype, float* out, const
     a.divH = make_fastdiv((uint32_t)H);
     a.flags = flags; a.in_dtype = (uint32_t)in_dtype;
     a.key.k0 = (uint32_t)seed; a.key.k1 = (uint32_t)(seed >> 32);
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("ELD_NOISE_DBG"); dbg = e ? atoi(e) : 0; }
+    a.dbg = (uint32_t)dbg;
 
     const size_t in_align = (in_dtype == ELD_IN_U16) ? 8 : 16;
     const bool vec = (W % 4 == 0) && ((uintptr_t)in % in_align == 0) && ((uintptr_t)out % 16 == 0);

@@ -49,7 +49,7 @@ __device__ __forceinline__ float u01_co(uint32_t w) { return (float)(w >> 8) * 0
 
 // two words -> two standard normals; sin/cos of 2*pi*u are the hardware v_sin/v_cos (argument in turns)
 __device__ __forceinline__ float2 box_muller(uint32_t wa, uint32_t wb) {
-    const float r = __builtin_sqrtf(-2.0f * __logf(u01(wa)));
+    const float r = __builtin_amdgcn_sqrtf(-2.0f * __logf(u01(wa)));     // hardware sqrt: an RNG transform, not reference arithmetic
     const float t = u01_co(wb);
     return make_float2(r * __builtin_amdgcn_cosf(t), r * __builtin_amdgcn_sinf(t));
 }

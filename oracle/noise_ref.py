@@ -247,42 +247,90 @@ POIS_SMALL = 10.0   # same regime split as NumPy's legacy sampler (inversion bel
 POIS_KMAX = 96
 
 
+def poisson_lambda_fast(y, p):
+    """Rate as the HIP sampler forms it on the Philox path: y * c with c = fp32(fp32(S*fp32(1/r)) * fp32(1/K)) --
+    one multiply per pixel instead of two IEEE divisions.  (The reference-order replay keeps poisson_lambda.)"""
+    S, r, K = F32(p['saturation']), F32(p['ratio']), F32(p['K'])
+    c = F32(F32(S * F32(F32(1.0) / r)) * F32(F32(1.0) / K))
+    return (np.asarray(y, F32) * c).astype(F32)
+
+
 def _pois_inversion(lam, u):
-    """lam < 10: CDF inversion by sequential search with one uniform (float32)."""
+    """lam < 10: CDF inversion by sequential search with one uniform (float32), in the form the kernel uses:
+    r = u - p0; while r > 0: k += 1; p *= lam * fp32(1/k); r -= p."""
     lam = np.asarray(lam, F32)
     p = np.exp(-lam).astype(F32)
-    F = p.copy()
+    r = (u - p).astype(F32)
     k = np.zeros(lam.shape, np.int32)
-    active = u > F
     it = 0
-    while active.any() and it < POIS_KMAX:
+    while (r > 0).any() and it < POIS_KMAX:
         it += 1
+        active = r > 0
         k = np.where(active, k + 1, k)
-        p = np.where(active, (p * (lam / k.astype(F32)).astype(F32)).astype(F32), p)
-        F = np.where(active, (F + p).astype(F32), F)
-        active = active & (u > F)
+        p = (p * (lam * F32(F32(1.0) / F32(it))).astype(F32)).astype(F32)
+        r = np.where(active, (r - p).astype(F32), r)
     return k
 
 
-def _ptrs_attempt(lam, U01, V):
-    """One PTRS attempt (Hoermann 1993, the transformed-rejection sampler NumPy's legacy
-    rk_poisson_ptrs uses), float32.  Returns (k, accepted)."""
+def _ptrs_consts(lam):
     slam = np.sqrt(lam).astype(F32)
-    loglam = np.log(lam).astype(F32)
     b = (F32(0.931) + F32(2.53) * slam).astype(F32)
     a = (F32(-0.059) + F32(0.02483) * b).astype(F32)
     invalpha = (F32(1.1239) + F32(1.1328) / (b - F32(3.4))).astype(F32)
     vr = (F32(0.9277) - F32(3.6224) / (b - F32(2.0))).astype(F32)
+    return a, b, invalpha, vr
+
+
+def _ptrs_k(lam, U01, a, b):
     U = (U01 - F32(0.5)).astype(F32)
     us = (F32(0.5) - np.abs(U)).astype(F32)
     k = np.floor(((F32(2) * a / us + b).astype(F32) * U + lam + F32(0.43)).astype(F32)).astype(F32)
-    fast = (us >= F32(0.07)) & (V <= vr)
+    return k, us
+
+
+def _ptrs_slow(lam, k, us, V, a, b, invalpha):
+    """Slow accept test of PTRS (Hoermann 1993; the transformed-rejection sampler NumPy's legacy
+    rk_poisson_ptrs uses), float32."""
     rej = (k < 0) | ((us < F32(0.013)) & (V > us))
     lhs = (np.log(V).astype(F32) + np.log(invalpha).astype(F32)
            - np.log((a / (us * us).astype(F32) + b).astype(F32)).astype(F32)).astype(F32)
-    rhs = _pois_logpmf(np.maximum(k, 0), lam, loglam)
-    slow = (~rej) & (lhs <= rhs)
-    return k.astype(np.int32), fast | ((~fast) & slow)
+    rhs = _pois_logpmf(np.maximum(k, 0), lam, None)
+    return (~rej) & (lhs <= rhs)
+
+
+def _ptrs_attempt(lam, U01, V):
+    a, b, invalpha, vr = _ptrs_consts(lam)
+    k, us = _ptrs_k(lam, U01, a, b)
+    ok = ((us >= F32(0.07)) & (V <= vr)) | _ptrs_slow(lam, k, us, V, a, b, invalpha)
+    return k.astype(np.int32), ok
+
+
+def _poisson_philox(lam, wu, wv, elem, seed, sample_id):
+    """Poisson counts under the sampler's word usage.  lam < 10: inversion with u01(wu).  Otherwise PTRS: attempt 0
+    takes U = u01(wu), V = u01(wv) (streams POIS_U / POIS_V, group e//4, word e%4); attempts 2k+1, 2k+2 take words
+    (x,y), (z,w) of the per-element retry call k (stream POIS_R, index = element, iter = k)."""
+    n = lam.size
+    k_out = np.zeros(n, np.int32)
+    small = lam < F32(POIS_SMALL)
+    k_out[small] = _pois_inversion(lam[small], px.u01(wu[small]))
+    idx = np.nonzero(~small)[0]
+    if idx.size == 0:
+        return k_out
+    k, ok = _ptrs_attempt(lam[idx], px.u01(wu[idx]), px.u01(wv[idx]))
+    k_out[idx[ok]] = k[ok]
+    rem = idx[~ok]
+    call = 0
+    while rem.size and call < 64:
+        words = px.sampler_words(elem[rem].astype(np.uint32), sample_id, px.STREAM_POIS_R, seed, it=np.uint32(call))
+        for a_ in (0, 2):
+            if not rem.size:
+                break
+            k, ok = _ptrs_attempt(lam[rem], px.u01(words[a_]), px.u01(words[a_ + 1]))
+            k_out[rem[ok]] = k[ok]
+            rem = rem[~ok]
+            words = tuple(x[~ok] for x in words)
+        call += 1
+    return k_out
 
 
 def philox_variates(shape, p, flags, seed, sample_id, y=None):
@@ -319,29 +367,8 @@ def philox_variates(shape, p, flags, seed, sample_id, y=None):
         out['row_normals'] = nrm                                   # (2H,)
         out['n_row'] = np.broadcast_to(nrm[rows][:, :, None], shape).astype(F32)
     if flags & SHOT_POISSON:
-        lam = poisson_lambda(y, p).reshape(-1)
-        wu = group_words(px.STREAM_POIS_U)
-        wv = group_words(px.STREAM_POIS_V)
-        k = np.zeros(n, np.int32)
-        small = lam < F32(POIS_SMALL)
-        k[small] = _pois_inversion(lam[small], px.u01(wu[small]))
-        big = ~small
-        idx = np.nonzero(big)[0]
-        kk, acc = _ptrs_attempt(lam[idx], px.u01(wu[idx]), px.u01(wv[idx]))
-        k[idx[acc]] = kk[acc]
-        pend = idx[~acc]
-        it = 0
-        while pend.size and it < 64:
-            w = px.sampler_words(pend.astype(np.uint32), sample_id, px.STREAM_POIS_R, seed, it=np.uint32(it))
-            for a in (0, 2):        # words (0,1) = attempt 1+2*it, words (2,3) = attempt 2+2*it
-                if not pend.size:
-                    break
-                kk, acc = _ptrs_attempt(lam[pend], px.u01(w[a]), px.u01(w[a + 1]))
-                k[pend[acc]] = kk[acc]
-                pend = pend[~acc]
-                w = tuple(x[~acc] for x in w)
-            it += 1
-        out['counts'] = k.reshape(shape)
+        lam = poisson_lambda_fast(y, p).reshape(-1)
+        out['counts'] = _poisson_philox(lam, group_words(px.STREAM_POIS_U), group_words(px.STREAM_POIS_V), e, seed, sample_id).reshape(shape)
     return out
 
 

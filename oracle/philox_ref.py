@@ -16,7 +16,7 @@ Streams (``index`` meaning in brackets):
     2 QUANT  [group]                word j   -> quantisation uniform
     3 NREAD  [group]                words    -> 4 normals (Gaussian read noise 'g')
     4 NSHOT  [group]                words    -> 4 normals (heteroscedastic shot 'p')
-    5 POIS_U [group]                word j   -> Poisson attempt-0 U
+    5 POIS_U [group]                word j   -> Poisson attempt-0 U (also the inversion uniform when lam < 10)
     6 POIS_V [group]                word j   -> Poisson attempt-0 V (PTRS only)
     7 POIS_R [element], iter        words (U,V),(U,V) -> attempts 1+2*iter, 2+2*iter
 """
