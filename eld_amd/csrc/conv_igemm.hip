@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
                         for (int tt = 0; tt < NT; ++tt) {
                             const float bf = kk == 0 ? fb[cur][tt].x : kk == 1 ? fb[cur][tt].y : kk == 2 ? fb[cur][tt].z : fb[cur][tt].w;
-                            acc[r][tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc[r][tt], 0, 0, 0);
+                            acc[r][tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf, af, acc[r][tt], 0, 0, 0);      // D[channel][pixel]
                         }
                     }
                 }
@@ -219,72 +219,77 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
             }
         }
 
-        // ---- epilogue: D layout col = lane&31 (channel), row = (i&3) + 8*(i>>2) + 4*hi (pixel x).
-        //      Per 32x32 accumulator tile: every load (bias, saved activations) is issued and consumed BEFORE the
-        //      first store, and interior tiles take a branch-free path -- otherwise the compiler re-waits vmcnt(0) inside
-        //      every exec-masked bounds-check block, which serialises the stores on their own completion.
-        const bool interior = x0 + TW <= a.W;
+        // ---- epilogue.  The MFMA ran as D[channel][pixel] (A = weights, B = pixels), so lane (m, hi) owns pixel
+        //      x0 + m and, in accumulator quad q, the four CONSECUTIVE channels 8q + 4hi .. +3 of its 32-channel block:
+        //      every access is one 16-byte dwordx4 per lane (4 per 32x32 tile), the bounds test is one lane mask, and
+        //      all loads (bias, saved activations) are issued before the first store.
+        {
+            const int x = x0 + m;
+            const bool xok = x < a.W;
 #pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-            const int y = y0 + wave * RPW + r;
-            if (y >= a.H || (a.dbg & 1)) continue;
-            const size_t rowpix = (size_t)(img * a.H + y) * a.W;
+            for (int r = 0; r < RPW; ++r) {
+                const int y = y0 + wave * RPW + r;
+                if (y >= a.H || (a.dbg & 1) || !xok) continue;
+                const size_t pix = (size_t)(img * a.H + y) * a.W + x;
 #pragma unroll
-            for (int tt = 0; tt < NT; ++tt) {
-                const int n = nb * BN + tt * 32 + m;
-                const int xb = x0 + 4 * hi;
-                float v[16];
-                float* dst;
-                size_t pstride;          // elements between horizontally adjacent pixels in dst
-                if (a.epi == EPI_FWD) {
-                    const float bias = a.bias[n];
-                    dst = a.out0 + (rowpix + xb) * a.Nout + n;
-                    pstride = a.Nout;
+                for (int tt = 0; tt < NT; ++tt) {
+                    const int nbase = nb * BN + tt * 32 + 4 * hi;          // + 8q
+                    float4 v[4];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        float t = acc[r][tt][i] + bias;
-                        v[i] = a.lrelu ? fmaxf(0.2f * t, t) : t;
-                    }
-                } else if (a.epi == EPI_CONVT_FWD) {
-                    const int tap = n / a.Cout_t, co = n - tap * a.Cout_t;
-                    const float bias = a.bias[co];
-                    dst = a.out0 + ((size_t)(img * 2 * a.H + 2 * y + (tap >> 1)) * (2 * a.W) + 2 * xb + (tap & 1)) * a.Cout_t + co;
-                    pstride = 2 * (size_t)a.Cout_t;
+                    for (int q = 0; q < 4; ++q) v[q] = make_float4(acc[r][tt][4 * q], acc[r][tt][4 * q + 1], acc[r][tt][4 * q + 2], acc[r][tt][4 * q + 3]);
+                    float* dst[4];
+                    if (a.epi == EPI_FWD) {
+                        float4 bs[4];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) v[i] = acc[r][tt][i] + bias;
-                } else {
-                    const bool lo = n < a.split;
-                    const int C = lo ? a.split : a.Nout - a.split;
-                    const int nn = lo ? n : n - a.split;
-                    dst = (lo ? a.out0 : a.out1) + (rowpix + xb) * C + nn;
-                    pstride = C;
-                    const float* act = lo ? a.act0 : a.act1;
-                    if (act) {
-                        const float* ap = act + (rowpix + xb) * C + nn;
-                        float s[16];
+                        for (int q = 0; q < 4; ++q) bs[q] = *reinterpret_cast<const float4*>(a.bias + nbase + 8 * q);
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const int dx = (i & 3) + 8 * (i >> 2);
-                            s[i] = (interior || xb + dx < a.W) ? ap[(size_t)dx * C] : 0.f;
+                        for (int q = 0; q < 4; ++q) {
+                            v[q].x += bs[q].x; v[q].y += bs[q].y; v[q].z += bs[q].z; v[q].w += bs[q].w;
+                            if (a.lrelu) {
+                                v[q].x = fmaxf(0.2f * v[q].x, v[q].x); v[q].y = fmaxf(0.2f * v[q].y, v[q].y);
+                                v[q].z = fmaxf(0.2f * v[q].z, v[q].z); v[q].w = fmaxf(0.2f * v[q].w, v[q].w);
+                            }
+                            dst[q] = a.out0 + pix * a.Nout + nbase + 8 * q;
+                        }
+                    } else if (a.epi == EPI_CONVT_FWD) {
+                        float4 bs[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int n = nbase + 8 * q;
+                            const int tap = n / a.Cout_t, co = n - tap * a.Cout_t;
+                            bs[q] = *reinterpret_cast<const float4*>(a.bias + co);
+                            dst[q] = a.out0 + ((size_t)(img * 2 * a.H + 2 * y + (tap >> 1)) * (2 * a.W) + 2 * x + (tap & 1)) * a.Cout_t + co;
                         }
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) v[i] = acc[r][tt][i] * lrelu_slope(s[i]);
+                        for (int q = 0; q < 4; ++q) { v[q].x += bs[q].x; v[q].y += bs[q].y; v[q].z += bs[q].z; v[q].w += bs[q].w; }
                     } else {
+                        float4 s[4];
+                        bool has[4];
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) v[i] = acc[r][tt][i];
+                        for (int q = 0; q < 4; ++q) {
+                            const int n = nbase + 8 * q;
+                            const bool lo = n < a.split;
+                            const int C = lo ? a.split : a.Nout - a.split;
+                            const size_t idx = pix * C + (lo ? n : n - a.split);
+                            dst[q] = (lo ? a.out0 : a.out1) + idx;
+                            const float* act = lo ? a.act0 : a.act1;
+                            has[q] = act != nullptr;
+                            s[q] = make_float4(1.f, 1.f, 1.f, 1.f);
+                            if (has[q]) s[q] = *reinterpret_cast<const float4*>(act + idx);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (has[q]) {
+                                v[q].x *= lrelu_slope(s[q].x); v[q].y *= lrelu_slope(s[q].y);
+                                v[q].z *= lrelu_slope(s[q].z); v[q].w *= lrelu_slope(s[q].w);
+                            }
                     }
-                }
 #pragma unroll
-                for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(v[i]));      // values are final here: no load result is consumed below
-                if (interior) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) dst[(size_t)((i & 3) + 8 * (i >> 2)) * pstride] = v[i];
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int dx = (i & 3) + 8 * (i >> 2);
-                        if (xb + dx < a.W) dst[(size_t)dx * pstride] = v[i];
+                    for (int q = 0; q < 4; ++q) {
+                        asm volatile("" : "+v"(v[q].x), "+v"(v[q].y), "+v"(v[q].z), "+v"(v[q].w));     // final values: no load result is consumed below
                     }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(dst[q]) = v[q];
                 }
             }
         }
@@ -340,6 +345,7 @@ int launch_conv(const ConvArgs& a_in, int mode, hipStream_t st) {
     if (Cin % CK || a.C0 % CK || a.Nout % 32) return ELD_EINVAL;
     if (a.C1 != 0 && a.C1 != a.C0) return ELD_ENOTSUP;          // virtual concat of two equally wide tensors (all the U-Net needs)
     if (a.epi == EPI_GRAD && (a.split % 32)) return ELD_EINVAL;
+    if (a.epi == EPI_CONVT_FWD && (a.Cout_t % 4)) return ELD_EINVAL;
     const bool n64 = a.Nout % 64 == 0;
     switch (mode) {
         case CONV_3X3: return n64 ? launch_t<CONV_3X3, 64, 2>(a, st) : launch_t<CONV_3X3, 32, 2>(a, st);
