@@ -225,30 +225,39 @@ int launch_wgrad(const WgradArgs& a, int mode, hipStream_t st) {
     return ELD_EINVAL;
 }
 
-// out[(i*CBr + j)*T + tap] = sum_s part[s][tap][i][j].  Each output element is summed by SL lanes (slice k takes
-// partials k, k+SL, ...; slices are combined by a fixed xor-shuffle tree), so the order is fixed -> run-to-run
-// bit-stable, and small planes with many partials (the 32-channel layers) still fill the chip.
-template <int SL>
+// out[(i*CBr + j)*T + tap] = sum_s part[s][tap][i][j].  One lane group (SL lanes) per (i, j) pair: slice k of the group
+// sums partials k, k+SL, ... for all T taps, slices are combined by a fixed xor-shuffle tree (fixed order -> run-to-run
+// bit-stable), and lane 0 of the group writes the pair's T consecutive outputs (reads coalesced along j, writes
+// contiguous per pair instead of a 4-byte scatter at stride T).
+template <int SL, int T>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart, float* __restrict__ wgrad,
-                                                           float* __restrict__ bgrad, int psplit, int T, int CA, int CBp, int CBr) {
-    constexpr int EPW = 64 / SL;                 // elements per wave
-    const size_t plane = (size_t)T * CA * CBp;
+                                                           float* __restrict__ bgrad, int psplit, int CA, int CBp, int CBr) {
+    constexpr int PPW = 64 / SL;                 // (i,j) pairs per wave
+    const size_t pairs = (size_t)CA * CBp, plane = pairs * T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int e_in_wave = lane % EPW, slice = lane / EPW;
-    const size_t idx = ((size_t)blockIdx.x * 4 + wave) * EPW + e_in_wave;
-    float s = 0.f;
-    if (idx < plane) {
-        const float* p = part + idx;
-#pragma unroll 4
-        for (int k = slice; k < psplit; k += SL) s += p[(size_t)k * plane];
+    const int p_in_wave = lane % PPW, slice = lane / PPW;
+    const size_t pr = ((size_t)blockIdx.x * 4 + wave) * PPW + p_in_wave;
+    float s[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) s[t] = 0.f;
+    if (pr < pairs) {
+        for (int k = slice; k < psplit; k += SL) {
+            const float* p = part + (size_t)k * plane + pr;
+#pragma unroll
+            for (int t = 0; t < T; ++t) s[t] += p[(size_t)t * pairs];
+        }
     }
 #pragma unroll
-    for (int off = EPW; off < 64; off <<= 1) s += __shfl_xor(s, off, 64);
-    if (slice == 0 && idx < plane) {
-        const int j = (int)(idx % CBp);
-        const int i = (int)((idx / CBp) % CA);
-        const int t = (int)(idx / ((size_t)CBp * CA));
-        if (j < CBr) wgrad[((size_t)i * CBr + j) * T + t] = s;
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int off = PPW; off < 64; off <<= 1) s[t] += __shfl_xor(s[t], off, 64);
+    if (slice == 0 && pr < pairs) {
+        const int j = (int)(pr % CBp), i = (int)(pr / CBp);
+        if (j < CBr) {
+            float* o = wgrad + ((size_t)i * CBr + j) * T;
+#pragma unroll
+            for (int t = 0; t < T; ++t) o[t] = s[t];
+        }
     }
     if (bgrad && blockIdx.x == 0) {
         for (int c = threadIdx.x; c < CA; c += 256) {
@@ -259,16 +268,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+template <int SL>
+static void launch_red(const float* part, const float* bpart, float* wgrad, float* bgrad, int psplit, int T, int CA, int CBp, int CBr, hipStream_t st) {
+    const size_t pairs = (size_t)CA * CBp;
+    const unsigned blocks = (unsigned)((pairs + 4 * (64 / SL) - 1) / (4 * (64 / SL)));
+    if (T == 9) hipLaunchKernelGGL((wgrad_reduce_kernel<SL, 9>), dim3(blocks), dim3(256), 0, st, part, bpart, wgrad, bgrad, psplit, CA, CBp, CBr);
+    else hipLaunchKernelGGL((wgrad_reduce_kernel<SL, 4>), dim3(blocks), dim3(256), 0, st, part, bpart, wgrad, bgrad, psplit, CA, CBp, CBr);
+}
+
 int launch_wgrad_reduce(const float* part, const float* bpart, float* wgrad, float* bgrad, int psplit, int T, int CA,
                         int CBp, int CBr, hipStream_t st) {
-    const size_t plane = (size_t)T * CA * CBp;
-    if (psplit >= 32) {
-        const unsigned blocks = (unsigned)((plane + 4 * 4 - 1) / (4 * 4));          // 16 slices -> 4 elements per wave
-        hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(blocks), dim3(256), 0, st, part, bpart, wgrad, bgrad, psplit, T, CA, CBp, CBr);
-    } else {
-        const unsigned blocks = (unsigned)((plane + 4 * 16 - 1) / (4 * 16));        // 4 slices -> 16 elements per wave
-        hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3(blocks), dim3(256), 0, st, part, bpart, wgrad, bgrad, psplit, T, CA, CBp, CBr);
-    }
+    if (T != 9 && T != 4) return ELD_EINVAL;
+    if (psplit >= 64) launch_red<16>(part, bpart, wgrad, bgrad, psplit, T, CA, CBp, CBr, st);
+    else if (psplit >= 8) launch_red<4>(part, bpart, wgrad, bgrad, psplit, T, CA, CBp, CBr, st);
+    else launch_red<1>(part, bpart, wgrad, bgrad, psplit, T, CA, CBp, CBr, st);
     ELD_LAUNCH_CHECK();
     return 0;
 }

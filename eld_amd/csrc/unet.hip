@@ -182,6 +182,7 @@ int make_plan(Plan& P, int N, int H, int W, int in_ch, int out_ch) {
     P.gA = take(act(0, 32));
     P.gB = take(act(0, 32));
     size_t pmax = head_bwd_ws_floats();
+    pmax = pmax > conv_first_wgrad_ws_floats() ? pmax : conv_first_wgrad_ws_floats();
     pmax = pmax > colsum_ws_floats(256) ? pmax : colsum_ws_floats(256);
     for (int i = 0; i < NLAYERS; ++i) {
         const LayerDef& d = P.L[i];
@@ -198,20 +199,27 @@ int make_plan(Plan& P, int N, int H, int W, int in_ch, int out_ch) {
 }
 
 int pack_weights(const Plan& P, const float* params, float* ws, bool for_backward, hipStream_t st) {
+    PackJobs jobs;
+    jobs.n = 0;
     for (int i = 0; i < NLAYERS; ++i) {
         const LayerDef& d = P.L[i];
-        int rc = 0;
+        PackJob J = {};
+        J.src_off = d.w_off; J.Cout = d.cout; J.Cin = d.cin; J.Cinp = d.cin;
         if (d.kind == 0) {
-            const int cinp = (d.cin + 15) / 16 * 16;
-            if (!for_backward) rc = launch_pack(params + d.w_off, ws + P.wp_fwd[i], PACK_CONV_FWD, d.cout, d.cin, cinp, 9, st);
-            else if (i != L_E0A) rc = launch_pack(params + d.w_off, ws + P.wp_bwd[i], PACK_CONV_BWD, d.cout, d.cin, d.cin, 9, st);
+            J.T = 9;
+            if (!for_backward) { J.kind = PACK_CONV_FWD; J.Cinp = (d.cin + 15) / 16 * 16; J.dst_off = P.wp_fwd[i]; }
+            else if (i != L_E0A) { J.kind = PACK_CONV_BWD; J.dst_off = P.wp_bwd[i]; }
+            else continue;
         } else if (d.kind == 1) {
-            if (!for_backward) rc = launch_pack(params + d.w_off, ws + P.wp_fwd[i], PACK_CONVT_FWD, d.cout, d.cin, d.cin, 4, st);
-            else rc = launch_pack(params + d.w_off, ws + P.wp_bwd[i], PACK_CONVT_BWD, d.cout, d.cin, d.cin, 4, st);
+            J.T = 4;
+            J.kind = for_backward ? PACK_CONVT_BWD : PACK_CONVT_FWD;
+            J.dst_off = for_backward ? P.wp_bwd[i] : P.wp_fwd[i];
+        } else {
+            continue;
         }
-        if (rc) return rc;
+        jobs.job[jobs.n++] = J;
     }
-    return 0;
+    return launch_pack_all(jobs, params, ws, st);
 }
 
 #define RC(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
@@ -219,11 +227,21 @@ int pack_weights(const Plan& P, const float* params, float* ws, bool for_backwar
 int unet_forward(const Plan& P, const float* x, const float* prm, float* out, float* ws, hipStream_t st) {
     const int N = P.N;
     RC(pack_weights(P, prm, ws, false, st));
-    RC(launch_nchw_to_nhwc16(x, ws + P.x16, N, P.in_ch, P.H, P.W, st));
+    const bool first_direct = P.in_ch <= 4;        // conv1_1 straight from the NCHW planes (conv_first.hip)
+    if (first_direct) {
+        // keep the input for the backward's weight gradient (the backward entry point does not receive x)
+        hipError_t e = hipMemcpyAsync(ws + P.x16, x, (size_t)N * P.in_ch * P.H * P.W * sizeof(float), hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return (int)e;
+    } else {
+        RC(launch_nchw_to_nhwc16(x, ws + P.x16, N, P.in_ch, P.H, P.W, st));
+    }
     for (int l = 0; l < NLEV; ++l) {
         const LayerDef& A = P.L[2 * l]; const LayerDef& B = P.L[2 * l + 1];
         const float* src = l == 0 ? ws + P.x16 : ws + P.pool[l - 1];
         const int cin = l == 0 ? 16 : chan(l - 1);
+        if (l == 0 && first_direct)
+            RC(launch_conv_first_fwd(x, prm + A.w_off, prm + A.b_off, ws + P.ea[0], N, P.in_ch, P.H, P.W, 1, st));
+        else
         RC(conv_fwd(src, cin, nullptr, 0, ws + P.wp_fwd[2 * l], prm + A.b_off, ws + P.ea[l], N, P.Hl[l], P.Wl[l], chan(l), 1, st));
         RC(conv_fwd(ws + P.ea[l], chan(l), nullptr, 0, ws + P.wp_fwd[2 * l + 1], prm + B.b_off, ws + P.eb[l], N, P.Hl[l], P.Wl[l], chan(l), 1, st));
         if (l < NLEV - 1) RC(launch_maxpool_fwd(ws + P.eb[l], ws + P.pool[l], N, P.Hl[l + 1], P.Wl[l + 1], chan(l), st));
@@ -273,7 +291,10 @@ int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd
         RC(conv_bwd_data(cur, ws + P.wp_bwd[ib], oth, nullptr, C, ws + P.ea[l], nullptr, N, H, W, C, C, st));
         { float* t = cur; cur = oth; oth = t; }
         if (l == 0) {
-            RC(conv_wgrad(cur, C, ws + P.x16, 16, nullptr, 0, P.in_ch, grd + P.L[ia].w_off, grd + P.L[ia].b_off, part, N, H, W, st));
+            if (P.in_ch <= 4)
+                RC(launch_conv_first_wgrad(cur, ws + P.x16, grd + P.L[ia].w_off, grd + P.L[ia].b_off, part, N, P.in_ch, H, W, st));
+            else
+                RC(conv_wgrad(cur, C, ws + P.x16, 16, nullptr, 0, P.in_ch, grd + P.L[ia].w_off, grd + P.L[ia].b_off, part, N, H, W, st));
             break;
         }
         const int Cp = chan(l - 1);

@@ -14,7 +14,15 @@ int launch_head_bwd(const float* dout, const float* act, const float* w, float* 
 size_t colsum_ws_floats(int C);
 int launch_colsum(const float* x, float* out, float* part, size_t P, int C, hipStream_t st);
 int launch_pack(const float* src, float* dst, int kind, int Cout, int Cin, int Cinp, int T, hipStream_t st);
+struct PackJob { size_t src_off, dst_off; int kind, Cout, Cin, Cinp, T, first_block; };
+struct PackJobs { int n; PackJob job[24]; };
+int launch_pack_all(PackJobs& jobs, const float* params, float* ws, hipStream_t st);
 size_t l1_ws_floats();
 int launch_l1(const float* out, const float* tgt, float* dout, float* loss, float* part, size_t n, float grad_scale, hipStream_t st);
 int launch_adam(float* p, const float* g, float* m, float* v, size_t n, double lr, double b1, double b2, double eps, double wd,
                 int step, double gscale, hipStream_t st);
+
+// first layer (conv_first.hip): NCHW input with Cin <= 4 -> NHWC 32 channels
+int launch_conv_first_fwd(const float* x, const float* w, const float* bias, float* out, int N, int Cin, int H, int W, int lrelu, hipStream_t st);
+size_t conv_first_wgrad_ws_floats();
+int launch_conv_first_wgrad(const float* g, const float* x, float* dw, float* db, float* part, int N, int Cin, int H, int W, hipStream_t st);

@@ -325,6 +325,46 @@ int launch_pack(const float* src, float* dst, int kind, int Cout, int Cin, int C
     return 0;
 }
 
+// all layers of the network in ONE launch: block b belongs to job j with first_block[j] <= b < first_block[j+1]
+__global__ void pack_all_kernel(const PackJobs jobs, const float* __restrict__ params, float* __restrict__ ws) {
+    int j = 0;
+    while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.job[j + 1].first_block) ++j;
+    const PackJob J = jobs.job[j];
+    const size_t total = (size_t)J.T * J.Cout * (J.kind == PACK_CONV_FWD ? J.Cinp : J.Cin);
+    const size_t i = (size_t)(blockIdx.x - J.first_block) * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float* src = params + J.src_off;
+    float* dst = ws + J.dst_off;
+    const int Cout = J.Cout, Cin = J.Cin, Cinp = J.Cinp, T = J.T;
+    if (J.kind == PACK_CONV_FWD) {
+        const int ci = (int)(i % Cinp); const int co = (int)((i / Cinp) % Cout); const int t = (int)(i / ((size_t)Cinp * Cout));
+        dst[i] = ci < Cin ? src[((size_t)co * Cin + ci) * T + t] : 0.f;
+    } else if (J.kind == PACK_CONV_BWD) {
+        const int co = (int)(i % Cout); const int ci = (int)((i / Cout) % Cin); const int t = (int)(i / ((size_t)Cout * Cin));
+        dst[i] = src[((size_t)co * Cin + ci) * T + (T - 1 - t)];
+    } else if (J.kind == PACK_CONVT_FWD) {
+        const int ci = (int)(i % Cin); const int co = (int)((i / Cin) % Cout); const int t = (int)(i / ((size_t)Cin * Cout));
+        dst[i] = src[((size_t)ci * Cout + co) * T + t];
+    } else {
+        const int co = (int)(i % Cout); const int ci = (int)((i / Cout) % Cin); const int t = (int)(i / ((size_t)Cout * Cin));
+        dst[i] = src[((size_t)ci * Cout + co) * T + t];
+    }
+}
+
+int launch_pack_all(PackJobs& jobs, const float* params, float* ws, hipStream_t st) {
+    int blocks = 0;
+    for (int j = 0; j < jobs.n; ++j) {
+        PackJob& J = jobs.job[j];
+        const size_t total = (size_t)J.T * J.Cout * (J.kind == PACK_CONV_FWD ? J.Cinp : J.Cin);
+        J.first_block = blocks;
+        blocks += (int)((total + 255) / 256);
+    }
+    if (!blocks) return 0;
+    hipLaunchKernelGGL(pack_all_kernel, dim3(blocks), dim3(256), 0, st, jobs, params, ws);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // L1 loss (mean |out - target|) forward + backward in one pass; two-pass deterministic reduction.
 //   dout = sign(out - target) * scale / numel     (torch: sign(0) = 0)
