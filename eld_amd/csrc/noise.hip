@@ -565,3 +565,36 @@ extern "C" int eld_pack_bayer(const float* mosaic, float* packed, int N, int h, 
 extern "C" int eld_unpack_bayer(const float* packed, float* mosaic, int N, int h, int w, void* stream) {
     return bayer_launch(false, packed, mosaic, N, h, w, stream);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Augmentation (sid_dataset.py:344-352): out = transpose?(flipW?(flipH?(x))) per image, optional clip (:354).
+//   no transpose: out[c][i][j] = x[c][fh(i)][fw(j)]      transpose: out[c][i][j] = x[c][fh(j)][fw(i)]
+// ---------------------------------------------------------------------------------------------
+__global__ void augment_kernel(const float* __restrict__ in, float* __restrict__ out, const int32_t* __restrict__ aug, int C, int H, int W, uint32_t flags) {
+    const int n = blockIdx.y;
+    const int bits = aug[n];
+    const bool fh = bits & 1, fw = bits & 2, tr = bits & 4;
+    const size_t chw = (size_t)C * H * W, hw = (size_t)H * W;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < chw; e += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e / hw);
+        const int r = (int)(e - (size_t)c * hw);
+        const int i = r / W, j = r - i * W;               // output coordinates (H == W when tr)
+        const int a = tr ? j : i, b = tr ? i : j;         // coordinates in the flipped image
+        const int sy = fh ? H - 1 - a : a, sx = fw ? W - 1 - b : b;
+        float v = in[(size_t)n * chw + (size_t)c * hw + (size_t)sy * W + sx];
+        if (flags & ELD_CLIP) v = fmaxf(fminf(v, 1.0f), 0.0f);
+        out[(size_t)n * chw + e] = v;
+    }
+}
+
+extern "C" int eld_augment(const float* in, float* out, const int32_t* aug, int N, int C, int H, int W, uint32_t flags, void* stream) {
+    if (N < 0 || C < 0 || H < 0 || W < 0) return ELD_EINVAL;
+    const size_t chw = (size_t)C * H * W;
+    if (N == 0 || chw == 0) return 0;
+    if (!in || !out || !aug || in == out) return ELD_EINVAL;
+    if (H != W) return ELD_ENOTSUP;                        // a batch with transposed members must stay rectangular-compatible
+    dim3 grid((unsigned)min((chw + 255) / 256, (size_t)4096), N);
+    hipLaunchKernelGGL(augment_kernel, grid, dim3(256), 0, as_stream(stream), in, out, aug, C, H, W, flags);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}

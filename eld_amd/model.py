@@ -141,6 +141,12 @@ class ELDModel:
             inp = self.synthesize(target, data.get('params'), data.get('sample_ids'))
         else:
             raise KeyError('input')
+        if data.get('aug') is not None and mode == 'train':
+            # ELDTrainDataset augmentation (sid_dataset.py:344-354) AFTER synthesis, as the reference does, so that
+            # row banding follows the sensor rows of the un-augmented frame: same flips/transpose on input and target.
+            from .noise import augment
+            inp = augment(inp, data['aug'], clip=True)
+            target = augment(target, data['aug'], clip=False)
         self.input, self.target = inp, target
         self.data_name = data.get('fn')
 

@@ -119,6 +119,18 @@ def sample_noise(y, params, flags, seed, sample_ids, in_u16=False, inject=None, 
     return out
 
 
+def augment(x, bits, clip=False):
+    """Device-side ELDTrainDataset augmentation (sid_dataset.py:344-354): x CUDA [N,C,H,W]; bits[n] = flipH | flipW<<1 |
+    transpose<<2 (the three np.random.randint(2) draws, in the reference's order)."""
+    import torch
+    x = x.contiguous().float()
+    N, C, H, W = x.shape
+    out = torch.empty_like(x)
+    b = torch.as_tensor(list(bits), dtype=torch.int32, device=x.device)
+    L.check(L.lib().eld_augment(L.dptr(x), L.dptr(out), L.dptr(b), N, C, H, W, L.CLIP if clip else 0, L.cur_stream()), 'eld_augment')
+    return out
+
+
 class RawPacker:
     """Bayer pack/unpack (noise.py:6-145) on the device.  X-Trans packing is outside the hot path
     (only the Bayer maps are in scope) and raises NotImplementedError like an

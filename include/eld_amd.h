@@ -98,6 +98,12 @@ int eld_pack_bayer(const float* mosaic, float* packed, int N, int h, int w, void
 int eld_unpack_bayer(const float* packed, float* mosaic, int N, int h, int w, void* stream);
 
 
+/* Training-pair augmentation of ELDTrainDataset.__getitem__ (dataset/sid_dataset.py:344-352), batched on device:
+ * per image n, bits of aug[n]: 1 = flip H (axis 1), 2 = flip W (axis 2), 4 = transpose (0,2,1), applied in that order;
+ * ELD_CLIP in `flags` fuses the clip to [0,1] of sid_dataset.py:354.  A transposed image needs H == W (batched tensor).
+ * in/out: float32 [N,C,H,W]; aug: device int32[N].  Pure index map: bit-exact. */
+int eld_augment(const float* in, float* out, const int32_t* aug, int N, int C, int H, int W, uint32_t flags, void* stream);
+
 /* ====================================================================================================
  * U-Net ("See-in-the-Dark", 5 scales) -- replaces UNetSeeInDark.forward (models/arch/Unet.py:48-91) and
  * the autograd backward that ELDModel.backward_G triggers (models/ELD_model.py:411-420).

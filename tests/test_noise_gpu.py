@@ -318,3 +318,23 @@ def test_plugin_call_surface(dev):
     assert not np.array_equal(burst[0], burst[1])
     zt = nm(torch.from_numpy(y).cuda()[None].repeat(2, 1, 1, 1))
     assert zt.is_cuda and zt.shape == (2, 4, 64, 64)
+
+
+def test_augment_matches_reference_golden(dev, golden_dir):
+    """Device augmentation == ELDTrainDataset.__getitem__ output (golden minted from dataset/sid_dataset.py:332-363)."""
+    from eld_amd.noise import augment
+    d = np.load(os.path.join(golden_dir, 'augment.npz'))
+    bits = [int(b[0]) | (int(b[1]) << 1) | (int(b[2]) << 2) for b in d['bits']]
+    assert len(set(bits)) > 3                                   # several flip/transpose combinations are exercised
+    oi = augment(torch.from_numpy(d['inp']).cuda(), bits, clip=True).cpu().numpy()
+    ot = augment(torch.from_numpy(d['tgt']).cuda(), bits, clip=False).cpu().numpy()
+    assert np.array_equal(oi, d['out_inp']) and np.array_equal(ot, d['out_tgt'])
+    x = torch.rand(3, 4, 512, 512, device=dev)
+    for b in range(8):                                          # involutions at the training patch size
+        y = augment(x, [b] * 3)
+        back = augment(y, [b] * 3) if not (b & 4) or b in (4, 7) else None
+        if back is not None:
+            assert torch.equal(back, x), b
+        assert torch.equal(y.sum(dtype=torch.float64), x.sum(dtype=torch.float64))
+    assert torch.equal(augment(x, [4, 4, 4]), x.transpose(2, 3).contiguous())
+    assert torch.equal(augment(x, [1, 2, 3]), torch.stack([x[0].flip(1), x[1].flip(2), x[2].flip(1).flip(2)]))
