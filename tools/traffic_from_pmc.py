@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; counter_collection.csv each) of `bench.py` into
+profiles/traffic.json, which bench.py reports as roofline.traffic.
+  bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024   -- FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE counts half of a
+  wide (16 B/lane) coalesced read stream (MI355X_MICROARCH.md, HBM section), every read in these kernels is 16 B/lane.
+Usage: traffic_from_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
+import collections
+import csv
+import json
+import sys
+
+
+def load(path, counter):
+    tot = collections.defaultdict(float)
+    calls = collections.Counter()
+    grid = collections.defaultdict(float)
+    seen = set()
+    for r in csv.DictReader(open(path)):
+        if r['Counter_Name'] != counter:
+            continue
+        k = r['Kernel_Name']
+        tot[k] += float(r['Counter_Value'])
+        if r['Dispatch_Id'] not in seen:
+            seen.add(r['Dispatch_Id'])
+            calls[k] += 1
+            grid[k] += float(r['Grid_Size'])
+    return tot, calls, grid
+
+
+def main():
+    f, fc, fg = load(sys.argv[1], 'FETCH_SIZE')
+    w, wc, wg = load(sys.argv[2], 'WRITE_SIZE')
+    out = {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --steps 1 --warmup 1 --no-cpu-baseline`; '
+                     'bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE x2 correction for 16 B/lane streams)', 'kernels': {}}
+    for k in f:
+        rd, wr = 2.0 * f[k] * 1024.0, w.get(k, 0.0) * 1024.0
+        out['kernels'][k[:80]] = {'calls': fc[k], 'read_bytes': rd, 'write_bytes': wr, 'bytes_per_launch': (rd + wr) / max(fc[k], 1)}
+    noise = [k for k in f if k.startswith('void noise_kernel')]
+    if noise:
+        px = sum(fg[k] / 256.0 * 4096.0 for k in noise)           # 256 threads per workgroup, 4096 pixels per workgroup
+        b = sum(2.0 * f[k] * 1024.0 + w.get(k, 0.0) * 1024.0 for k in noise)
+        out['sampler_bytes_per_pixel'] = b / px
+    passes = sum(fc[k] for k in f if k.startswith('head_fwd_kernel'))
+    conv = [k for k in f if any(s in k for s in ('conv_igemm_kernel', 'wgrad_kernel', 'conv_first', 'wgrad_reduce'))]
+    if passes and conv:
+        out['unet_passes'] = passes
+        out['unet_conv_bytes_per_pass'] = sum(2.0 * f[k] * 1024.0 + w.get(k, 0.0) * 1024.0 for k in conv) / passes
+    json.dump(out, open(sys.argv[3], 'w'), indent=1)
+    print(json.dumps({k: v for k, v in out.items() if k != 'kernels'}, indent=1))
+
+
+if __name__ == '__main__':
+    main()
