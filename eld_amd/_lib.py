@@ -36,6 +36,7 @@ SIGNATURES = {
     'eld_unet_param_offsets': (_i, [_i, _i, _vp]),
     'eld_unet_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'eld_unet_forward': (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
+    'eld_unet_forward_bf16': (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
     'eld_unet_backward': (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
     'eld_l1_workspace_bytes': (_sz, []),
     'eld_l1_loss': (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _f, _vp]),

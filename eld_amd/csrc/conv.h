@@ -13,23 +13,28 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 enum ConvMode { CONV_3X3 = 0, CONV_1X1 = 1, CONV_GATHER2X2 = 2 };
 enum ConvEpi { EPI_FWD = 0, EPI_CONVT_FWD = 1, EPI_GRAD = 2 };
 
+typedef unsigned short bf16_t;       // storage type of a bfloat16 element
+enum ConvDtype { DT_F32 = 0, DT_BF16 = 1 };
+
+// Element type T of activations / packed weights is float or bf16_t (dtype); accumulation, bias are always float.
 struct ConvArgs {
-    const float* in0;   // NHWC source 0 (C0 channels)
-    const float* in1;   // NHWC source 1 (C1 channels) -- virtual channel concat [in0, in1]; may be null
+    const void* in0;    // NHWC source 0 (C0 channels)
+    const void* in1;    // NHWC source 1 (C1 channels) -- virtual channel concat [in0, in1]; may be null
     int C0, C1;
-    const float* wp;    // packed weights [taps][Nout][C0+C1], c contiguous
+    const void* wp;     // packed weights [taps][Nout][C0+C1], c contiguous
     int N, H, W;        // tile domain: output pixels (3x3 / 1x1) or input-resolution pixels (gather: source is 2H x 2W)
     int Nout;           // GEMM N
     int epi;
     const float* bias;  // EPI_FWD: [Nout]; EPI_CONVT_FWD: [Cout_t]
     int lrelu;          // EPI_FWD: apply max(0.2v, v)
-    float* out0;        // EPI_FWD/CONVT: destination.  EPI_GRAD: channels [0, split)
-    float* out1;        // EPI_GRAD: channels [split, Nout)
+    void* out0;         // EPI_FWD/CONVT: destination.  EPI_GRAD: channels [0, split)
+    void* out1;         // EPI_GRAD: channels [split, Nout)
     int split;
-    const float* act0;  // EPI_GRAD: saved post-activation tensor (layout of out0) -> multiply by lrelu slope; may be null
-    const float* act1;
+    const void* act0;   // EPI_GRAD: saved post-activation tensor (layout of out0) -> multiply by lrelu slope; may be null
+    const void* act1;
     int Cout_t;         // EPI_CONVT_FWD: real Cout (Nout = 4*Cout_t, n = tap*Cout_t + co)
     int tiles_x, tiles_y;
+    int dtype;          // DT_F32 / DT_BF16
     int dbg;            // ablation switches for tools/ (env ELD_CONV_DBG): 1 skip epilogue, 2 skip MFMA, 4 skip staging loads
 };
 
@@ -37,6 +42,20 @@ struct ConvArgs {
 // ties (x == 0) split the gradient evenly between the two branches -> 0.6.  The saved tensor is the
 // post-activation value, whose sign equals the pre-activation's.
 __device__ __forceinline__ float lrelu_slope(float y) { return y > 0.f ? 1.0f : (y < 0.f ? 0.2f : 0.6f); }
+
+// bfloat16 <-> float (round to nearest even; NaN not special-cased: activations are finite)
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float((unsigned)v << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint2 pack_bf4(float4 v) {
+    return make_uint2((unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16), (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16));
+}
+__device__ __forceinline__ float4 unpack_bf4(uint2 p) {
+    return make_float4(__uint_as_float(p.x << 16), __uint_as_float(p.x & 0xFFFF0000u), __uint_as_float(p.y << 16), __uint_as_float(p.y & 0xFFFF0000u));
+}
 
 int launch_conv(const ConvArgs& a, int mode, hipStream_t st);
 

@@ -23,9 +23,9 @@ __device__ __forceinline__ void first_load_halo(float* halo, const float* __rest
     }
 }
 
-template <int CIN>
+template <int CIN, typename TO>
 __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                             float* __restrict__ out, int N, int H, int W, int lrelu) {
+                                                             TO* __restrict__ out, int N, int H, int W, int lrelu) {
     constexpr int K = 9 * CIN, KS = (K + 1) / 2;
     __shared__ float halo[CIN * FHP];
     __shared__ float wl[2 * KS * 32];            // [k][co], zero padded to 2*KS
@@ -74,32 +74,41 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
             for (int r = 0; r < 2; ++r) {
                 const int y = y0 + wave * 2 + r;
                 if (y >= H) continue;
-                float* dst = out + ((size_t)(img * H + y) * W + xx) * 32 + 4 * hi;
+                TO* dst = out + ((size_t)(img * H + y) * W + xx) * 32 + 4 * hi;
                 const float4 bs[4] = {b0, b1, b2, b3};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     float4 v = make_float4(acc[r][4 * q] + bs[q].x, acc[r][4 * q + 1] + bs[q].y, acc[r][4 * q + 2] + bs[q].z, acc[r][4 * q + 3] + bs[q].w);
                     if (lrelu) { v.x = fmaxf(0.2f * v.x, v.x); v.y = fmaxf(0.2f * v.y, v.y); v.z = fmaxf(0.2f * v.z, v.z); v.w = fmaxf(0.2f * v.w, v.w); }
-                    *reinterpret_cast<float4*>(dst + 8 * q) = v;
+                    if constexpr (sizeof(TO) == 4) *reinterpret_cast<float4*>(dst + 8 * q) = v;
+                    else *reinterpret_cast<uint2*>(dst + 8 * q) = pack_bf4(v);
                 }
             }
         }
     }
 }
 
-int launch_conv_first_fwd(const float* x, const float* w, const float* bias, float* out, int N, int Cin, int H, int W, int lrelu, hipStream_t st) {
+template <typename TO>
+static int launch_first_t(const float* x, const float* w, const float* bias, TO* out, int N, int Cin, int H, int W, int lrelu, hipStream_t st) {
     const int tiles = ((W + FTW - 1) / FTW) * ((H + FTH - 1) / FTH) * N;
     if (tiles <= 0) return 0;
     const int grid = tiles < 2048 ? tiles : 2048;
     switch (Cin) {
-        case 1: hipLaunchKernelGGL(conv_first_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, x, w, bias, out, N, H, W, lrelu); break;
-        case 2: hipLaunchKernelGGL(conv_first_fwd_kernel<2>, dim3(grid), dim3(256), 0, st, x, w, bias, out, N, H, W, lrelu); break;
-        case 3: hipLaunchKernelGGL(conv_first_fwd_kernel<3>, dim3(grid), dim3(256), 0, st, x, w, bias, out, N, H, W, lrelu); break;
-        case 4: hipLaunchKernelGGL(conv_first_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, x, w, bias, out, N, H, W, lrelu); break;
+        case 1: hipLaunchKernelGGL((conv_first_fwd_kernel<1, TO>), dim3(grid), dim3(256), 0, st, x, w, bias, out, N, H, W, lrelu); break;
+        case 2: hipLaunchKernelGGL((conv_first_fwd_kernel<2, TO>), dim3(grid), dim3(256), 0, st, x, w, bias, out, N, H, W, lrelu); break;
+        case 3: hipLaunchKernelGGL((conv_first_fwd_kernel<3, TO>), dim3(grid), dim3(256), 0, st, x, w, bias, out, N, H, W, lrelu); break;
+        case 4: hipLaunchKernelGGL((conv_first_fwd_kernel<4, TO>), dim3(grid), dim3(256), 0, st, x, w, bias, out, N, H, W, lrelu); break;
         default: return ELD_ENOTSUP;
     }
     ELD_LAUNCH_CHECK();
     return 0;
+}
+
+int launch_conv_first_fwd(const float* x, const float* w, const float* bias, float* out, int N, int Cin, int H, int W, int lrelu, hipStream_t st) {
+    return launch_first_t<float>(x, w, bias, out, N, Cin, H, W, lrelu, st);
+}
+int launch_conv_first_fwd_bf16(const float* x, const float* w, const float* bias, bf16_t* out, int N, int Cin, int H, int W, int lrelu, hipStream_t st) {
+    return launch_first_t<bf16_t>(x, w, bias, out, N, Cin, H, W, lrelu, st);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

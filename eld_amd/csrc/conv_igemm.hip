@@ -28,8 +28,8 @@
 #include <stdlib.h>
 #include "conv.h"
 
-#define CK 16
-#define PS 20           // LDS pixel stride in words (16 + 4 pad)
+#define PS 20           // LDS pixel stride in 4-byte words: one 64-byte K chunk (16 fp32 / 32 bf16 channels) + 16 bytes pad
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define TW 32
 
 template <int MODE, int RPW>
@@ -39,9 +39,11 @@ struct Geo {
     static constexpr int A_PIX = MODE == CONV_3X3 ? (TH + 2) * (TW + 2) : (MODE == CONV_1X1 ? TH * TW : 4 * TH * TW);
 };
 
-template <int MODE, int BN, int RPW>
+template <typename T, int MODE, int BN, int RPW>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     using G = Geo<MODE, RPW>;
+    constexpr int ES = sizeof(T);               // element size of activations / packed weights
+    constexpr int CK = 64 / ES;                 // channels per K chunk: 16 (fp32) or 32 (bf16) -- always 64 bytes per pixel
     constexpr int TH = G::TH, TAPS = G::TAPS, A_PIX = G::A_PIX, NT = BN / 32;
     constexpr int A_WORDS = A_PIX * PS, B_ROWS = TAPS * BN;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -73,13 +75,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     unsigned a_voff[A_IT];       // load side: byte offset of the staging unit inside the image, OOB = zero fill
     unsigned b_voff[B_IT];       // byte offset of the weight unit inside the n-block's slab (chunk offset is scalar)
     int l_nb = 0, l_img = 0;     // load side: tile being loaded (workgroup-uniform -> SGPRs)
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (int)((size_t)TAPS * a.Nout * Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (int)((size_t)TAPS * a.Nout * Cin * ES), 0x00020000);
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
         const int u = tid + it * 256;
         const int row = u >> 2, part = u & 3;
         const int tap = row / BN, n = row - tap * BN;
-        b_voff[it] = u < B_UNITS ? (unsigned)(((tap * a.Nout + n) * Cin + part * 4) * 4) : OOB;
+        b_voff[it] = u < B_UNITS ? (unsigned)((tap * a.Nout + n) * Cin * ES + part * 16) : OOB;
     }
 
     auto decode = [&](int t, int& nb, int& img, int& y0, int& x0) {
@@ -114,19 +116,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
                 ok = ok && (y0 + py) < a.H && (x0 + px) < a.W;
                 gy = 2 * (y0 + py) + (tap >> 1); gx = 2 * (x0 + px) + (tap & 1);
             }
-            a_voff[it] = ok ? ((unsigned)(gy * Ws + gx) * (unsigned)Cs0 + (unsigned)part * 4u) * 4u : OOB;     // final byte offset
+            a_voff[it] = ok ? (unsigned)(gy * Ws + gx) * (unsigned)(Cs0 * ES) + (unsigned)part * 16u : OOB;     // final byte offset
         }
     };
     auto load_chunk = [&](int c0) {
         // both concat sources have the same channel count (checked at launch), so one set of offsets serves both
-        const float* src = c0 < a.C0 ? a.in0 : a.in1;
+        const char* src = static_cast<const char*>(c0 < a.C0 ? a.in0 : a.in1);
         const int cs = c0 < a.C0 ? c0 : c0 - a.C0;
-        const size_t img_elems = (size_t)Hs * Ws * Cs0;
-        const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)l_img * img_elems), 0, (int)(img_elems * 4), 0x00020000);
+        const size_t img_bytes = (size_t)Hs * Ws * Cs0 * ES;
+        const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)l_img * img_bytes), 0, (int)img_bytes, 0x00020000);
 #pragma unroll
         for (int it = 0; it < A_IT; ++it)
-            ra[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)a_voff[it], cs * 4, 0));
-        const int wsoff = (l_nb * BN * Cin + c0) * 4;
+            ra[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)a_voff[it], cs * ES, 0));
+        const int wsoff = (l_nb * BN * Cin + c0) * ES;
 #pragma unroll
         for (int it = 0; it < B_IT; ++it)
             rb[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)b_voff[it], wsoff, 0));
@@ -148,13 +150,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     if (t >= total_tiles) return;
     setup_load(t);
     load_chunk(0);
-    // De-phase the co-resident workgroups: the grid is (#CUs x 2) persistent workgroups doing identical work per
-    // tile, so without an offset both workgroups of a CU sit in their epilogue (matrix pipe idle) at the same
-    // time.  The second wave of workgroups starts half a tile late; the offset persists because tile times are equal.
-    if ((a.dbg & 8) == 0 && (int)blockIdx.x >= (int)gridDim.x / 2) {
-        const int naps = (Cin / CK) * TAPS * RPW * NT * 8 * 64 / 2 / (64 * 64);      // half of the tile's MFMA cycles, in 4096-cycle naps
-        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(64);
-    }
     for (;;) {
         int nb, img, y0, x0;             // compute / epilogue side of the current tile
         decode(t, nb, img, y0, x0);
@@ -180,22 +175,25 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
                 }
             }
             if (a.dbg & 2) continue;
-            // ---- MFMA over taps x 8 k-steps; fragments of group g+1 are read from LDS while group g's
-            //      16 MFMAs occupy the matrix pipe (explicit register double-buffering) --------------------
+            // ---- MFMA over taps x the chunk's 64 bytes of K.  Group g = (tap, q): every lane reads 16 bytes per operand
+            //      row (fp32: 4 channels of its k-half -> 4 x v_mfma_f32_32x32x2_f32; bf16: 8 channels = one whole
+            //      v_mfma_f32_32x32x16_bf16 operand).  Fragments of group g+1 are read from LDS while group g's MFMAs
+            //      occupy the matrix pipe (explicit register double-buffering, order pinned with sched_barrier) -----------
             float4 fa[2][RPW], fb[2][NT];
             auto read_group = [&](int g, float4 (&A)[RPW], float4 (&B)[NT]) {
                 const int tap = g >> 1, q = g & 1;
+                const int ko = ES == 4 ? hi * 8 + q * 4 : hi * 4 + q * 8;      // word offset of this lane's 16 bytes inside the pixel row
 #pragma unroll
                 for (int r = 0; r < RPW; ++r) {
                     const int row = wave * RPW + r;
                     int off;
-                    if (MODE == CONV_3X3) off = ((row + tap / 3) * (TW + 2) + m + tap % 3) * PS + hi * 8;
-                    else if (MODE == CONV_1X1) off = (row * TW + m) * PS + hi * 8;
-                    else off = (tap * TH * TW + row * TW + m) * PS + hi * 8;
-                    A[r] = *reinterpret_cast<const float4*>(ldsA + off + q * 4);
+                    if (MODE == CONV_3X3) off = ((row + tap / 3) * (TW + 2) + m + tap % 3) * PS;
+                    else if (MODE == CONV_1X1) off = (row * TW + m) * PS;
+                    else off = (tap * TH * TW + row * TW + m) * PS;
+                    A[r] = *reinterpret_cast<const float4*>(ldsA + off + ko);
                 }
 #pragma unroll
-                for (int tt = 0; tt < NT; ++tt) B[tt] = *reinterpret_cast<const float4*>(ldsB + ((tap * BN + tt * 32 + m) * PS + hi * 8) + q * 4);
+                for (int tt = 0; tt < NT; ++tt) B[tt] = *reinterpret_cast<const float4*>(ldsB + (tap * BN + tt * 32 + m) * PS + ko);
             };
             read_group(0, fa[0], fb[0]);
 #pragma unroll
@@ -203,17 +201,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
                 const int cur = g & 1;
                 if (g + 1 < 2 * TAPS) read_group(g + 1, fa[cur ^ 1], fb[cur ^ 1]);
                 __builtin_amdgcn_sched_barrier(0);      // keep the prefetch reads ABOVE this group's MFMAs
+                if constexpr (ES == 4) {
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
+                    for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-                    for (int r = 0; r < RPW; ++r) {
-                        const float af = kk == 0 ? fa[cur][r].x : kk == 1 ? fa[cur][r].y : kk == 2 ? fa[cur][r].z : fa[cur][r].w;
+                        for (int r = 0; r < RPW; ++r) {
+                            const float af = kk == 0 ? fa[cur][r].x : kk == 1 ? fa[cur][r].y : kk == 2 ? fa[cur][r].z : fa[cur][r].w;
 #pragma unroll
-                        for (int tt = 0; tt < NT; ++tt) {
-                            const float bf = kk == 0 ? fb[cur][tt].x : kk == 1 ? fb[cur][tt].y : kk == 2 ? fb[cur][tt].z : fb[cur][tt].w;
-                            acc[r][tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf, af, acc[r][tt], 0, 0, 0);      // D[channel][pixel]
+                            for (int tt = 0; tt < NT; ++tt) {
+                                const float bf = kk == 0 ? fb[cur][tt].x : kk == 1 ? fb[cur][tt].y : kk == 2 ? fb[cur][tt].z : fb[cur][tt].w;
+                                acc[r][tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf, af, acc[r][tt], 0, 0, 0);      // D[channel][pixel]
+                            }
                         }
                     }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                        for (int tt = 0; tt < NT; ++tt)
+                            acc[r][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[cur][tt]), __builtin_bit_cast(bf16x8, fa[cur][r]),
+                                                                                 acc[r][tt], 0, 0, 0);      // D[channel][pixel]
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
                     float4 v[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = make_float4(acc[r][tt][4 * q], acc[r][tt][4 * q + 1], acc[r][tt][4 * q + 2], acc[r][tt][4 * q + 3]);
-                    float* dst[4];
+                    T* dst[4];
                     if (a.epi == EPI_FWD) {
                         float4 bs[4];
 #pragma unroll
@@ -249,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
                                 v[q].x = fmaxf(0.2f * v[q].x, v[q].x); v[q].y = fmaxf(0.2f * v[q].y, v[q].y);
                                 v[q].z = fmaxf(0.2f * v[q].z, v[q].z); v[q].w = fmaxf(0.2f * v[q].w, v[q].w);
                             }
-                            dst[q] = a.out0 + pix * a.Nout + nbase + 8 * q;
+                            dst[q] = static_cast<T*>(a.out0) + pix * a.Nout + nbase + 8 * q;
                         }
                     } else if (a.epi == EPI_CONVT_FWD) {
                         float4 bs[4];
@@ -258,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
                             const int n = nbase + 8 * q;
                             const int tap = n / a.Cout_t, co = n - tap * a.Cout_t;
                             bs[q] = *reinterpret_cast<const float4*>(a.bias + co);
-                            dst[q] = a.out0 + ((size_t)(img * 2 * a.H + 2 * y + (tap >> 1)) * (2 * a.W) + 2 * x + (tap & 1)) * a.Cout_t + co;
+                            dst[q] = static_cast<T*>(a.out0) + ((size_t)(img * 2 * a.H + 2 * y + (tap >> 1)) * (2 * a.W) + 2 * x + (tap & 1)) * a.Cout_t + co;
                         }
 #pragma unroll
                         for (int q = 0; q < 4; ++q) { v[q].x += bs[q].x; v[q].y += bs[q].y; v[q].z += bs[q].z; v[q].w += bs[q].w; }
@@ -271,11 +278,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
                             const bool lo = n < a.split;
                             const int C = lo ? a.split : a.Nout - a.split;
                             const size_t idx = pix * C + (lo ? n : n - a.split);
-                            dst[q] = (lo ? a.out0 : a.out1) + idx;
-                            const float* act = lo ? a.act0 : a.act1;
+                            dst[q] = static_cast<T*>(lo ? a.out0 : a.out1) + idx;
+                            const T* act = static_cast<const T*>(lo ? a.act0 : a.act1);
                             has[q] = act != nullptr;
                             s[q] = make_float4(1.f, 1.f, 1.f, 1.f);
-                            if (has[q]) s[q] = *reinterpret_cast<const float4*>(act + idx);
+                            if (has[q]) {
+                                if constexpr (ES == 4) s[q] = *reinterpret_cast<const float4*>(act + idx);
+                                else s[q] = unpack_bf4(*reinterpret_cast<const uint2*>(act + idx));
+                            }
                         }
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
@@ -289,7 +299,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
                         asm volatile("" : "+v"(v[q].x), "+v"(v[q].y), "+v"(v[q].z), "+v"(v[q].w));     // final values: no load result is consumed below
                     }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(dst[q]) = v[q];
+                    for (int q = 0; q < 4; ++q) {
+                        if constexpr (ES == 4) *reinterpret_cast<float4*>(dst[q]) = v[q];
+                        else *reinterpret_cast<uint2*>(dst[q]) = pack_bf4(v[q]);
+                    }
                 }
             }
         }
@@ -309,7 +322,7 @@ static int num_cus() {
     return n;
 }
 
-template <int MODE, int BN, int RPW>
+template <typename T, int MODE, int BN, int RPW>
 static int launch_t(ConvArgs a, hipStream_t st) {
     using G = Geo<MODE, RPW>;
     a.tiles_x = (a.W + TW - 1) / TW;
@@ -318,7 +331,7 @@ static int launch_t(ConvArgs a, hipStream_t st) {
     const long long tiles = (long long)a.tiles_x * a.tiles_y * a.N * (a.Nout / BN);
     if (tiles <= 0) return 0;
     if (tiles > 0x7fffffffLL) return ELD_ENOTSUP;
-    auto kern = conv_igemm_kernel<MODE, BN, RPW>;
+    auto kern = conv_igemm_kernel<T, MODE, BN, RPW>;
     static bool attr_set = false;     // per instantiation
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -336,21 +349,27 @@ static int launch_t(ConvArgs a, hipStream_t st) {
     return 0;
 }
 
+template <typename T>
+static int launch_dt(const ConvArgs& a, int mode, hipStream_t st) {
+    const bool n64 = a.Nout % 64 == 0;
+    switch (mode) {
+        case CONV_3X3: return n64 ? launch_t<T, CONV_3X3, 64, 2>(a, st) : launch_t<T, CONV_3X3, 32, 2>(a, st);
+        case CONV_1X1: return n64 ? launch_t<T, CONV_1X1, 64, 2>(a, st) : launch_t<T, CONV_1X1, 32, 2>(a, st);
+        case CONV_GATHER2X2: return n64 ? launch_t<T, CONV_GATHER2X2, 64, 1>(a, st) : launch_t<T, CONV_GATHER2X2, 32, 1>(a, st);
+    }
+    return ELD_EINVAL;
+}
+
 int launch_conv(const ConvArgs& a_in, int mode, hipStream_t st) {
     ConvArgs a = a_in;
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("ELD_CONV_DBG"); dbg = e ? atoi(e) : 0; }
     a.dbg = dbg;
     const int Cin = a.C0 + a.C1;
-    if (Cin % CK || a.C0 % CK || a.Nout % 32) return ELD_EINVAL;
+    const int ck = a.dtype == DT_BF16 ? 32 : 16;
+    if (Cin % ck || a.C0 % ck || a.Nout % 32) return ELD_EINVAL;
     if (a.C1 != 0 && a.C1 != a.C0) return ELD_ENOTSUP;          // virtual concat of two equally wide tensors (all the U-Net needs)
     if (a.epi == EPI_GRAD && (a.split % 32)) return ELD_EINVAL;
     if (a.epi == EPI_CONVT_FWD && (a.Cout_t % 4)) return ELD_EINVAL;
-    const bool n64 = a.Nout % 64 == 0;
-    switch (mode) {
-        case CONV_3X3: return n64 ? launch_t<CONV_3X3, 64, 2>(a, st) : launch_t<CONV_3X3, 32, 2>(a, st);
-        case CONV_1X1: return n64 ? launch_t<CONV_1X1, 64, 2>(a, st) : launch_t<CONV_1X1, 32, 2>(a, st);
-        case CONV_GATHER2X2: return n64 ? launch_t<CONV_GATHER2X2, 64, 1>(a, st) : launch_t<CONV_GATHER2X2, 32, 1>(a, st);
-    }
-    return ELD_EINVAL;
+    return a.dtype == DT_BF16 ? launch_dt<bf16_t>(a, mode, st) : launch_dt<float>(a, mode, st);
 }

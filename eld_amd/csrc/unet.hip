@@ -198,7 +198,7 @@ int make_plan(Plan& P, int N, int H, int W, int in_ch, int out_ch) {
     return 0;
 }
 
-int pack_weights(const Plan& P, const float* params, float* ws, bool for_backward, hipStream_t st) {
+int pack_weights(const Plan& P, const float* params, float* ws, bool for_backward, hipStream_t st, bool bf16 = false) {
     PackJobs jobs;
     jobs.n = 0;
     for (int i = 0; i < NLAYERS; ++i) {
@@ -207,7 +207,7 @@ int pack_weights(const Plan& P, const float* params, float* ws, bool for_backwar
         J.src_off = d.w_off; J.Cout = d.cout; J.Cin = d.cin; J.Cinp = d.cin;
         if (d.kind == 0) {
             J.T = 9;
-            if (!for_backward) { J.kind = PACK_CONV_FWD; J.Cinp = (d.cin + 15) / 16 * 16; J.dst_off = P.wp_fwd[i]; }
+            if (!for_backward) { J.kind = PACK_CONV_FWD; J.Cinp = (d.cin + 15) / 16 * 16; J.dst_off = P.wp_fwd[i]; if (bf16 && i == L_E0A) continue; }
             else if (i != L_E0A) { J.kind = PACK_CONV_BWD; J.dst_off = P.wp_bwd[i]; }
             else continue;
         } else if (d.kind == 1) {
@@ -217,6 +217,7 @@ int pack_weights(const Plan& P, const float* params, float* ws, bool for_backwar
         } else {
             continue;
         }
+        J.bf16 = bf16 ? 1 : 0;
         jobs.job[jobs.n++] = J;
     }
     return launch_pack_all(jobs, params, ws, st);
@@ -255,6 +256,45 @@ int unet_forward(const Plan& P, const float* x, const float* prm, float* out, fl
     }
     const LayerDef& Hd = P.L[L_HEAD];
     RC(launch_head_fwd(ws + P.db[0], prm + Hd.w_off, prm + Hd.b_off, out, N, P.H, P.W, P.out_ch, st));
+    return 0;
+}
+
+// bf16 forward (inference): bf16 activations and packed weights, fp32 accumulation / bias; the first layer reads the
+// fp32 NCHW planes and the head writes fp32 NCHW.  Buffers of the fp32 plan are reused (half filled).
+int conv_fwd_bf16(const bf16_t* in0, int C0, const bf16_t* in1, int C1, const bf16_t* wp, const float* bias, bf16_t* out, int N, int H, int W,
+                  int Cout, int lrelu, hipStream_t st) {
+    ConvArgs a = {};
+    a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1; a.wp = wp; a.N = N; a.H = H; a.W = W; a.Nout = Cout;
+    a.epi = EPI_FWD; a.bias = bias; a.lrelu = lrelu; a.out0 = out; a.dtype = DT_BF16;
+    return launch_conv(a, CONV_3X3, st);
+}
+
+int unet_forward_bf16(const Plan& P, const float* x, const float* prm, float* out, float* ws, hipStream_t st) {
+    const int N = P.N;
+    if (P.in_ch > 4) return ELD_ENOTSUP;
+    RC(pack_weights(P, prm, ws, false, st, true));
+    auto B = [&](size_t off) { return reinterpret_cast<bf16_t*>(ws + off); };
+    for (int l = 0; l < NLEV; ++l) {
+        const LayerDef& A = P.L[2 * l]; const LayerDef& Bd = P.L[2 * l + 1];
+        if (l == 0)
+            RC(launch_conv_first_fwd_bf16(x, prm + A.w_off, prm + A.b_off, B(P.ea[0]), N, P.in_ch, P.H, P.W, 1, st));
+        else
+            RC(conv_fwd_bf16(B(P.pool[l - 1]), chan(l - 1), nullptr, 0, B(P.wp_fwd[2 * l]), prm + A.b_off, B(P.ea[l]), N, P.Hl[l], P.Wl[l], chan(l), 1, st));
+        RC(conv_fwd_bf16(B(P.ea[l]), chan(l), nullptr, 0, B(P.wp_fwd[2 * l + 1]), prm + Bd.b_off, B(P.eb[l]), N, P.Hl[l], P.Wl[l], chan(l), 1, st));
+        if (l < NLEV - 1) RC(launch_maxpool_fwd_bf16(B(P.eb[l]), B(P.pool[l]), N, P.Hl[l + 1], P.Wl[l + 1], chan(l), st));
+    }
+    for (int l = 3; l >= 0; --l) {
+        const int iu = L_UP3 + 3 * (3 - l);
+        const bf16_t* src = l == 3 ? B(P.eb[4]) : B(P.db[l + 1]);
+        ConvArgs a = {};
+        a.in0 = src; a.C0 = chan(l + 1); a.wp = B(P.wp_fwd[iu]); a.N = N; a.H = P.Hl[l + 1]; a.W = P.Wl[l + 1]; a.Nout = 4 * chan(l);
+        a.epi = EPI_CONVT_FWD; a.bias = prm + P.L[iu].b_off; a.out0 = B(P.up[l]); a.Cout_t = chan(l); a.dtype = DT_BF16;
+        RC(launch_conv(a, CONV_1X1, st));
+        RC(conv_fwd_bf16(B(P.up[l]), chan(l), B(P.eb[l]), chan(l), B(P.wp_fwd[iu + 1]), prm + P.L[iu + 1].b_off, B(P.da[l]), N, P.Hl[l], P.Wl[l], chan(l), 1, st));
+        RC(conv_fwd_bf16(B(P.da[l]), chan(l), nullptr, 0, B(P.wp_fwd[iu + 2]), prm + P.L[iu + 2].b_off, B(P.db[l]), N, P.Hl[l], P.Wl[l], chan(l), 1, st));
+    }
+    const LayerDef& Hd = P.L[L_HEAD];
+    RC(launch_head_fwd_bf16(B(P.db[0]), prm + Hd.w_off, prm + Hd.b_off, out, N, P.H, P.W, P.out_ch, st));
     return 0;
 }
 
@@ -335,6 +375,16 @@ extern "C" int eld_unet_forward(const float* x, const float* params, float* out,
     if (!x || !params || !out || !ws) return ELD_EINVAL;
     if (ws_bytes < P.total * sizeof(float)) return ELD_EWS;
     return unet_forward(P, x, params, out, (float*)ws, as_stream(stream));
+}
+
+extern "C" int eld_unet_forward_bf16(const float* x, const float* params, float* out, void* ws, size_t ws_bytes, int N, int H, int W,
+                                     int in_ch, int out_ch, void* stream) {
+    if (N == 0) return 0;
+    Plan P;
+    RC(make_plan(P, N, H, W, in_ch, out_ch));
+    if (!x || !params || !out || !ws) return ELD_EINVAL;
+    if (ws_bytes < P.total * sizeof(float)) return ELD_EWS;
+    return unet_forward_bf16(P, x, params, out, (float*)ws, as_stream(stream));
 }
 
 extern "C" int eld_unet_backward(const float* dout, const float* params, float* grads, void* ws, size_t ws_bytes, int N, int H, int W,

@@ -14,7 +14,7 @@ int launch_head_bwd(const float* dout, const float* act, const float* w, float* 
 size_t colsum_ws_floats(int C);
 int launch_colsum(const float* x, float* out, float* part, size_t P, int C, hipStream_t st);
 int launch_pack(const float* src, float* dst, int kind, int Cout, int Cin, int Cinp, int T, hipStream_t st);
-struct PackJob { size_t src_off, dst_off; int kind, Cout, Cin, Cinp, T, first_block; };
+struct PackJob { size_t src_off, dst_off; int kind, Cout, Cin, Cinp, T, first_block, bf16; };   // dst_off in floats; bf16: write bf16_t
 struct PackJobs { int n; PackJob job[24]; };
 int launch_pack_all(PackJobs& jobs, const float* params, float* ws, hipStream_t st);
 size_t l1_ws_floats();
@@ -26,3 +26,8 @@ int launch_adam(float* p, const float* g, float* m, float* v, size_t n, double l
 int launch_conv_first_fwd(const float* x, const float* w, const float* bias, float* out, int N, int Cin, int H, int W, int lrelu, hipStream_t st);
 size_t conv_first_wgrad_ws_floats();
 int launch_conv_first_wgrad(const float* g, const float* x, float* dw, float* db, float* part, int N, int Cin, int H, int W, hipStream_t st);
+
+// bf16 activations (forward / inference path)
+int launch_maxpool_fwd_bf16(const bf16_t* in, bf16_t* out, int N, int Ho, int Wo, int C, hipStream_t st);
+int launch_head_fwd_bf16(const bf16_t* in, const float* w, const float* b, float* out, int N, int H, int W, int OC, hipStream_t st);
+int launch_conv_first_fwd_bf16(const float* x, const float* w, const float* bias, bf16_t* out, int N, int Cin, int H, int W, int lrelu, hipStream_t st);

@@ -336,19 +336,22 @@ __global__ void pack_all_kernel(const PackJobs jobs, const float* __restrict__ p
     const float* src = params + J.src_off;
     float* dst = ws + J.dst_off;
     const int Cout = J.Cout, Cin = J.Cin, Cinp = J.Cinp, T = J.T;
+    float v;
     if (J.kind == PACK_CONV_FWD) {
         const int ci = (int)(i % Cinp); const int co = (int)((i / Cinp) % Cout); const int t = (int)(i / ((size_t)Cinp * Cout));
-        dst[i] = ci < Cin ? src[((size_t)co * Cin + ci) * T + t] : 0.f;
+        v = ci < Cin ? src[((size_t)co * Cin + ci) * T + t] : 0.f;
     } else if (J.kind == PACK_CONV_BWD) {
         const int co = (int)(i % Cout); const int ci = (int)((i / Cout) % Cin); const int t = (int)(i / ((size_t)Cout * Cin));
-        dst[i] = src[((size_t)co * Cin + ci) * T + (T - 1 - t)];
+        v = src[((size_t)co * Cin + ci) * T + (T - 1 - t)];
     } else if (J.kind == PACK_CONVT_FWD) {
         const int ci = (int)(i % Cin); const int co = (int)((i / Cin) % Cout); const int t = (int)(i / ((size_t)Cin * Cout));
-        dst[i] = src[((size_t)ci * Cout + co) * T + t];
+        v = src[((size_t)ci * Cout + co) * T + t];
     } else {
         const int co = (int)(i % Cout); const int ci = (int)((i / Cout) % Cin); const int t = (int)(i / ((size_t)Cout * Cin));
-        dst[i] = src[((size_t)ci * Cout + co) * T + t];
+        v = src[((size_t)ci * Cout + co) * T + t];
     }
+    if (J.bf16) reinterpret_cast<bf16_t*>(dst)[i] = f2bf(v);
+    else dst[i] = v;
 }
 
 int launch_pack_all(PackJobs& jobs, const float* params, float* ws, hipStream_t st) {
@@ -452,6 +455,76 @@ int launch_adam(float* p, const float* g, float* m, float* v, size_t n, double l
     const double bc2 = 1.0 - pow(b2, (double)step);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n, (float)(lr / bc1), (float)b1,
                        (float)b2, (float)eps, (float)wd, (float)sqrt(bc2), (float)gscale);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 activation variants of the streaming kernels (forward path): 4 channels = 8 bytes per lane access
+// ------------------------------------------------------------------------------------------------
+__global__ void maxpool_fwd_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int N, int Ho, int Wo, int C) {
+    const int C4 = C / 4;
+    const size_t total = (size_t)N * Ho * Wo * C4;
+    const int Wi = 2 * Wo;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        size_t p = i / C4;
+        const int xo = (int)(p % Wo); p /= Wo;
+        const int yo = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        const uint2* src = reinterpret_cast<const uint2*>(in + (((size_t)n * 2 * Ho + 2 * yo) * Wi + 2 * xo) * C) + c4;
+        const float4 a = unpack_bf4(src[0]), b = unpack_bf4(src[C4]), c = unpack_bf4(src[(size_t)Wi * C4]), d = unpack_bf4(src[(size_t)Wi * C4 + C4]);
+        float4 r;
+        r.x = fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x));
+        r.y = fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y));
+        r.z = fmaxf(fmaxf(a.z, b.z), fmaxf(c.z, d.z));
+        r.w = fmaxf(fmaxf(a.w, b.w), fmaxf(c.w, d.w));
+        reinterpret_cast<uint2*>(out)[i] = pack_bf4(r);
+    }
+}
+
+int launch_maxpool_fwd_bf16(const bf16_t* in, bf16_t* out, int N, int Ho, int Wo, int C, hipStream_t st) {
+    const size_t total = (size_t)N * Ho * Wo * (C / 4);
+    if (!total) return 0;
+    hipLaunchKernelGGL(maxpool_fwd_bf16_kernel, dim3((unsigned)min((total + 255) / 256, (size_t)32768)), dim3(256), 0, st, in, out, N, Ho, Wo, C);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const bf16_t* __restrict__ in, const float* __restrict__ w, const float* __restrict__ b,
+                                                            float* __restrict__ out, int N, size_t HW, int OC) {
+    __shared__ float sw[4 * 32 + 4];
+    for (int i = threadIdx.x; i < 4 * 32 + 4; i += 256) {
+        float v = 0.f;
+        if (i < 128) { if (i / 32 < OC) v = w[i]; } else if (i - 128 < OC) v = b[i - 128];
+        sw[i] = v;
+    }
+    __syncthreads();
+    const size_t total = (size_t)N * HW;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+        const uint4* src = reinterpret_cast<const uint4*>(in + p * 32);
+        float acc[4] = {sw[128], sw[129], sw[130], sw[131]};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint4 q = src[k];                                   // 8 channels
+            const float4 lo = unpack_bf4(make_uint2(q.x, q.y)), hi4 = unpack_bf4(make_uint2(q.z, q.w));
+            const float vv[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[o] = fmaf(vv[j], sw[o * 32 + 8 * k + j], acc[o]);
+        }
+        const size_t n = p / HW, qq = p - n * HW;
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+            if (o < OC) out[(n * OC + o) * HW + qq] = acc[o];
+    }
+}
+
+int launch_head_fwd_bf16(const bf16_t* in, const float* w, const float* b, float* out, int N, int H, int W, int OC, hipStream_t st) {
+    const size_t total = (size_t)N * H * W;
+    if (!total) return 0;
+    hipLaunchKernelGGL(head_fwd_bf16_kernel, dim3((unsigned)min((total + 255) / 256, (size_t)16384)), dim3(256), 0, st, in, w, b, out, N, (size_t)H * W, OC);
     ELD_LAUNCH_CHECK();
     return 0;
 }

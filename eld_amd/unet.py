@@ -115,7 +115,9 @@ class UNetSeeInDark(nn.Module):
         return r
 
     # ---- engine calls ----------------------------------------------------------------------------------
-    def _engine_forward(self, x, save):
+    inference_precision = 'fp32'          # 'bf16': no-grad forwards run eld_unet_forward_bf16 (BASELINE config 3 precision)
+
+    def _engine_forward(self, x, save, bf16=False):
         if not x.is_cuda:
             raise RuntimeError('eld_amd U-Net runs on the GPU only (no CPU fallback); got a CPU tensor')
         x = x.contiguous().float()
@@ -125,12 +127,13 @@ class UNetSeeInDark(nn.Module):
         if H % 16 or W % 16:
             raise RuntimeError('U-Net input H, W must be multiples of 16 (4 pooling levels), got %dx%d' % (H, W))
         nbytes = L.lib().eld_unet_workspace_bytes(N, H, W, self.in_channels, self.out_channels)
-        key = ('train' if save else 'eval', N, H, W)
+        key = ('train' if save else ('eval_bf16' if bf16 else 'eval'), N, H, W)
         ws = self._ws.get(key, nbytes, x.device)
         self._ws.gen[key] += 1
         out = torch.empty((N, self.out_channels, H, W), dtype=torch.float32, device=x.device)
-        L.check(L.lib().eld_unet_forward(L.dptr(x), L.dptr(self.flat_params), L.dptr(out), L.dptr(ws), ws.numel(),
-                                         N, H, W, self.in_channels, self.out_channels, L.cur_stream()), 'eld_unet_forward')
+        fn = L.lib().eld_unet_forward_bf16 if bf16 else L.lib().eld_unet_forward
+        L.check(fn(L.dptr(x), L.dptr(self.flat_params), L.dptr(out), L.dptr(ws), ws.numel(),
+                   N, H, W, self.in_channels, self.out_channels, L.cur_stream()), 'eld_unet_forward')
         return out, key, self._ws.gen[key]
 
     def _engine_backward(self, dout, key, shape, grads=None):
@@ -145,7 +148,7 @@ class UNetSeeInDark(nn.Module):
     def forward(self, x):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self._plist):
             return _UNetFunction.apply(self, x, *self._plist)
-        return self._engine_forward(x, save=False)[0]
+        return self._engine_forward(x, save=False, bf16=self.inference_precision == 'bf16')[0]
 
     def lrelu(self, x):                  # Unet.py:102-104 (kept for API parity; the engine fuses it)
         return torch.max(0.2 * x, x)

@@ -282,3 +282,32 @@ def test_unet_rejects_bad_input(lib):
         net(torch.rand(1, 4, 30, 32, device='cuda'))
     with pytest.raises(RuntimeError):
         net(torch.rand(1, 4, 32, 32))
+
+
+@pytest.mark.parametrize('shape', [(1, 4, 32, 48), (2, 4, 64, 144), (1, 4, 176, 272)])
+def test_unet_bf16_inference_vs_fp32(lib, shape):
+    """BASELINE config 3 precision: bf16 activations/weights with fp32 accumulation.  Judged as SURVEY.md App. E-4 says:
+    output PSNR >= 60 dB against the fp32 engine (255-scaled, like util/index.py:79), and against the fp64 oracle."""
+    from eld_amd.unet import UNetSeeInDark
+    torch.manual_seed(11)
+    net = UNetSeeInDark(4, 4).cuda()
+    sd = {k: v.detach().cpu().double() for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(*shape, generator=g)
+    with torch.no_grad():
+        ref32 = net(x.cuda())
+        net.inference_precision = 'bf16'
+        out = net(x.cuda())
+        out2 = net(x.cuda())
+        net.inference_precision = 'fp32'
+        again32 = net(x.cuda())
+    assert torch.equal(out, out2) and torch.equal(ref32, again32)          # deterministic; switching precision leaves fp32 untouched
+    assert not torch.equal(out, ref32)
+    def psnr(a, b):
+        mse = torch.mean((a.double() * 255 - b.double() * 255) ** 2)
+        return float(10 * torch.log10(255.0 ** 2 / mse))
+    assert psnr(out, ref32) >= 60.0, psnr(out, ref32)
+    with torch.no_grad():
+        ref64 = U.unet_forward(sd, x.double())
+    assert psnr(out.cpu(), ref64) >= 60.0
+    assert float((out.cpu().double() - ref64).abs().max()) < 2e-2
