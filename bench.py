@@ -40,8 +40,8 @@ def synth_clean(n, h, w, device, seed):
     return (torch.floor(65535.0 * u ** 2.2) / 65535.0).contiguous()
 
 
-def make_opt(local_rank):
-    return types.SimpleNamespace(gpu_ids=[local_rank], isTrain=True, checkpoints_dir='/tmp/eld_amd_bench', name='bench', netG='unet',
+def make_opt(local_rank, precision='fp32'):
+    return types.SimpleNamespace(precision=precision, gpu_ids=[local_rank], isTrain=True, checkpoints_dir='/tmp/eld_amd_bench', name='bench', netG='unet',
                                  channels=4, stage_in='raw', stage_out='raw', lr=1e-4, beta1=0.9, wd=0.0, loss='l1', resume=False,
                                  no_log=True, chop=False, model='eld_model')
 
@@ -113,6 +113,7 @@ def main():
     ap.add_argument('--width', type=int, default=W_FULL)
     ap.add_argument('--noise', default='PGRU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'], help="U-Net precision; the contract's metric is quoted on fp32 (BASELINE configs[1]); bf16 = configs[2]")
     args = ap.parse_args()
 
     from eld_amd import dist as D
@@ -138,7 +139,7 @@ def main():
     with contextlib.redirect_stdout(io.StringIO()):
         nm = NoiseModel(model=args.noise, include=4)               # SonyA7S2
     model = ELDModel()
-    model.initialize(make_opt(local))
+    model.initialize(make_opt(local, args.precision))
     model.set_noise_model(nm)
     clean = synth_clean(B, Hh, Ww, dev, seed=1234 + rank)           # resident in HBM before the timed region
     total_steps = args.steps + args.warmup
@@ -172,9 +173,9 @@ def main():
         'metric': 'raw megapixels/sec (noise-synth + U-Net step)', 'value': round(pix_per_step * args.steps / dt / 1e6, 3),
         'unit': 'raw MPix/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'BASELINE.json configs[1]: full ELD noise model (%s, SonyA7S2 params) on 4x%dx%d packed raw + U-Net fp32 '
-                               'train step (fwd, L1, bwd, Adam), %d frames per GPU' % (args.noise, Hh, Ww, B),
+        'dtype': 'f32' if args.precision == 'fp32' else 'bf16', 'data': 'synthetic',
+        'config': {'workload': 'BASELINE.json configs[%d]: full ELD noise model (%s, SonyA7S2 params) on 4x%dx%d packed raw + U-Net %s '
+                               'train step (fwd, L1, bwd, Adam), %d frames per GPU' % (1 if args.precision == 'fp32' else 2, args.noise, Hh, Ww, args.precision, B),
                    'images_per_gpu': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world, 'final_loss': loss},
     }
 
@@ -186,7 +187,7 @@ def main():
         state = {}
 
         def fwd():
-            state['k'] = net._engine_forward(x, save=True)[1]
+            state['k'] = net._engine_forward(x, save=True, bf16=args.precision == 'bf16')[1]
 
         def bwd():
             net._engine_backward(dout, state['k'], tuple(x.shape), grads=model.optimizer_G.grads)
@@ -198,9 +199,9 @@ def main():
         flop_step = FLOP_STEP_PER_PIX * B * 4.0 * Hh * Ww
         ach = flop_step / ((t_f + t_b) * 1e-3) / 1e12
         res['roofline'] = {'bound': 'mfma', 'kernel': 'U-Net convolution launches of one step (conv_igemm_kernel fwd/bwd-data + wgrad_kernel), '
-                           'timed as eld_unet_forward + eld_unet_backward', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TF,
-                           'unit': 'TFLOP/s', 'frac': round(ach / PEAK_F32_MFMA_TF, 4),
-                           'traffic': (round(traffic['unet_conv_bytes_per_pass'] * B) if traffic and full_frame and 'unet_conv_bytes_per_pass' in traffic else None),
+                           'timed as eld_unet_forward + eld_unet_backward', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TF if args.precision == 'fp32' else 2500.0,
+                           'unit': 'TFLOP/s', 'frac': round(ach / (PEAK_F32_MFMA_TF if args.precision == 'fp32' else 2500.0), 4),
+                           'traffic': (round(traffic['unet_conv_bytes_per_pass'] * B) if traffic and full_frame and args.precision == 'fp32' and 'unet_conv_bytes_per_pass' in traffic else None),
                            'fwd_ms': round(t_f, 3), 'bwd_ms': round(t_b, 3),
                            'fwd_tflops': round(FLOP_FWD_PER_PIX * B * 4.0 * Hh * Ww / (t_f * 1e-3) / 1e12, 2)}
         # sampler alone (HBM-bound: 8 B per raw pixel), batch of 8 resident images

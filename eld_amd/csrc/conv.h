@@ -61,10 +61,10 @@ int launch_conv(const ConvArgs& a, int mode, hipStream_t st);
 
 // dW-type reduction:  P[tap][i][j] = sum_pixels G[pixel][i] * X[pixel (+) tap][j]
 struct WgradArgs {
-    const float* g;      // NHWC, CA channels, unshifted (the A operand)
+    const void* g;       // NHWC, CA channels, unshifted (the A operand); element type = dtype
     int CA;
-    const float* x0;     // NHWC sources of the shifted/gathered operand (virtual concat)
-    const float* x1;
+    const void* x0;      // NHWC sources of the shifted/gathered operand (virtual concat)
+    const void* x1;
     int C0, C1;          // C0 + C1 = CB (may be smaller than the padded j extent)
     int N, H, W;         // pixel domain of g
     float* part;         // partials [psplit][taps][CA][CBp]
@@ -72,6 +72,7 @@ struct WgradArgs {
     int CBp;             // padded CB (multiple of 32)
     int psplit;
     int tiles_x, tiles_y;
+    int dtype;           // DT_F32 / DT_BF16 inputs (partials and accumulation are always fp32)
 };
 
 int launch_wgrad(const WgradArgs& a, int mode, hipStream_t st);

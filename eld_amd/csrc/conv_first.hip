@@ -117,8 +117,8 @@ int launch_conv_first_fwd_bf16(const float* x, const float* w, const float* bias
 // walks tiles persistently, reduces its 4 waves through LDS and writes one partial [2][32][32] (+ 32 bias sums).
 // ------------------------------------------------------------------------------------------------------------------
 #define FW_BLOCKS 512
-template <int CIN>
-__global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x, float* __restrict__ part,
+template <int CIN, typename TG>
+__global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const TG* __restrict__ g, const float* __restrict__ x, float* __restrict__ part,
                                                                int N, int H, int W) {
     constexpr int K = 9 * CIN;
     __shared__ float halo[CIN * FHP];
@@ -149,7 +149,11 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const float* __re
             const int lp = u >> 3, part4 = u & 7;
             const int gy = y0 + lp / FTW, gx = x0 + lp % FTW;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy < H && gx < W) v = *reinterpret_cast<const float4*>(g + ((size_t)(img * H + gy) * W + gx) * 32 + part4 * 4);
+            if (gy < H && gx < W) {
+                const TG* gp = g + ((size_t)(img * H + gy) * W + gx) * 32 + part4 * 4;
+                if constexpr (sizeof(TG) == 4) v = *reinterpret_cast<const float4*>(gp);
+                else v = unpack_bf4(*reinterpret_cast<const uint2*>(gp));
+            }
             *reinterpret_cast<float4*>(gl + u * 4) = v;
         }
         __syncthreads();
@@ -214,19 +218,27 @@ __global__ void conv_first_wgrad_reduce_kernel(const float* __restrict__ part, f
 
 size_t conv_first_wgrad_ws_floats() { return (size_t)FW_BLOCKS * (2 * 32 * 32 + 32); }
 
-int launch_conv_first_wgrad(const float* g, const float* x, float* dw, float* db, float* part, int N, int Cin, int H, int W, hipStream_t st) {
+template <typename TG>
+static int launch_first_wgrad_t(const TG* g, const float* x, float* dw, float* db, float* part, int N, int Cin, int H, int W, hipStream_t st) {
     const int tiles = ((W + FTW - 1) / FTW) * ((H + FTH - 1) / FTH) * N;
     if (tiles <= 0) return 0;
     const int grid = tiles < FW_BLOCKS ? tiles : FW_BLOCKS;
     switch (Cin) {
-        case 1: hipLaunchKernelGGL(conv_first_wgrad_kernel<1>, dim3(grid), dim3(256), 0, st, g, x, part, N, H, W); break;
-        case 2: hipLaunchKernelGGL(conv_first_wgrad_kernel<2>, dim3(grid), dim3(256), 0, st, g, x, part, N, H, W); break;
-        case 3: hipLaunchKernelGGL(conv_first_wgrad_kernel<3>, dim3(grid), dim3(256), 0, st, g, x, part, N, H, W); break;
-        case 4: hipLaunchKernelGGL(conv_first_wgrad_kernel<4>, dim3(grid), dim3(256), 0, st, g, x, part, N, H, W); break;
+        case 1: hipLaunchKernelGGL((conv_first_wgrad_kernel<1, TG>), dim3(grid), dim3(256), 0, st, g, x, part, N, H, W); break;
+        case 2: hipLaunchKernelGGL((conv_first_wgrad_kernel<2, TG>), dim3(grid), dim3(256), 0, st, g, x, part, N, H, W); break;
+        case 3: hipLaunchKernelGGL((conv_first_wgrad_kernel<3, TG>), dim3(grid), dim3(256), 0, st, g, x, part, N, H, W); break;
+        case 4: hipLaunchKernelGGL((conv_first_wgrad_kernel<4, TG>), dim3(grid), dim3(256), 0, st, g, x, part, N, H, W); break;
         default: return ELD_ENOTSUP;
     }
     ELD_LAUNCH_CHECK();
     hipLaunchKernelGGL(conv_first_wgrad_reduce_kernel, dim3((2 * 32 * 32 + 32 + 255) / 256), dim3(256), 0, st, part, dw, db, grid, 9 * Cin);
     ELD_LAUNCH_CHECK();
     return 0;
+}
+
+int launch_conv_first_wgrad(const float* g, const float* x, float* dw, float* db, float* part, int N, int Cin, int H, int W, hipStream_t st) {
+    return launch_first_wgrad_t<float>(g, x, dw, db, part, N, Cin, H, W, st);
+}
+int launch_conv_first_wgrad_bf16(const bf16_t* g, const float* x, float* dw, float* db, float* part, int N, int Cin, int H, int W, hipStream_t st) {
+    return launch_first_wgrad_t<bf16_t>(g, x, dw, db, part, N, Cin, H, W, st);
 }

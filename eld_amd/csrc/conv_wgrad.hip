@@ -21,8 +21,10 @@
 #define TW 32
 #define JB 32     // j (shifted-operand channel) tile
 
-template <int MODE, int WCO, int TH>
+template <typename T, int MODE, int WCO, int TH>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
+    constexpr int ES = sizeof(T);            // element size of g / x in HBM (float or bf16); LDS and accumulation are fp32
+    constexpr int EPU = 16 / ES;             // elements per 16-byte staging unit
     constexpr int TAPS = MODE == CONV_3X3 ? 9 : 4;
     constexpr int WPIX = 4 / WCO;
     constexpr int COB = 32 * WCO;
@@ -47,8 +49,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     const int Hx = MODE == CONV_GATHER2X2 ? 2 * a.H : a.H;
     const int Wx = MODE == CONV_GATHER2X2 ? 2 * a.W : a.W;
     // source of the j tile (virtual concat); channels >= CB are zero padding
-    const float* xsrc; int Cs, cs;
-    if (j0 < a.C0) { xsrc = a.x0; Cs = a.C0; cs = j0; } else { xsrc = a.x1; Cs = a.C1; cs = j0 - a.C0; }
+    const char* xsrc; int Cs, cs;
+    if (j0 < a.C0) { xsrc = static_cast<const char*>(a.x0); Cs = a.C0; cs = j0; } else { xsrc = static_cast<const char*>(a.x1); Cs = a.C1; cs = j0 - a.C0; }
     const int jvalid = min(JB, CB - j0 > 0 ? (j0 < a.C0 ? a.C0 - j0 : CB - j0) : 0);   // channels of this tile that exist
 
     f32x16 acc[TAPS];
@@ -62,31 +64,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     const int ntiles = tiles_per_img * a.N;
     // Register-staged pipeline: tile t+1's global loads (buffer loads: 32-bit offsets, SGPR descriptor, hardware
     // zero-fill for the out-of-image marker) are in flight during tile t's MFMA phase and go to LDS after the barrier.
-    constexpr int G_UNITS = TPIX * (COB / 4), X_UNITS = X_PIX * (JB / 4);
+    constexpr int G_UNITS = TPIX * (COB / EPU), X_UNITS = X_PIX * (JB / EPU);
     constexpr int G_IT = (G_UNITS + 255) / 256, X_IT = (X_UNITS + 255) / 256;
     constexpr unsigned OOB = 0xFFFFFFF0u;
-    float4 rg[G_IT], rx[X_IT];
-    const size_t g_img = (size_t)a.H * a.W * a.CA, x_img = (size_t)Hx * Wx * Cs;
+    float4 rg[G_IT], rx[X_IT];               // raw 16-byte units (4 fp32 or 8 bf16)
+    const size_t g_img = (size_t)a.H * a.W * a.CA * ES, x_img = (size_t)Hx * Wx * Cs * ES;     // bytes
     auto load_tile = [&](int tile) {
         const int img = tile / tiles_per_img;
         const int trem = tile - img * tiles_per_img;
         const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
         const int y0 = ty * TH, x0 = tx * TW;
-        const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)(a.g + (size_t)img * g_img), 0, (int)(g_img * 4), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(xsrc + (size_t)img * x_img), 0, (int)(x_img * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)(static_cast<const char*>(a.g) + (size_t)img * g_img), 0, (int)g_img, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(xsrc + (size_t)img * x_img), 0, (int)x_img, 0x00020000);
         unsigned og[G_IT], ox[X_IT];
 #pragma unroll
         for (int it = 0; it < G_IT; ++it) {
             const int u = tid + it * 256;
-            const int lp = u / (COB / 4), part = u - lp * (COB / 4);
+            const int lp = u / (COB / EPU), part = u - lp * (COB / EPU);
             const int py = lp / TW, px = lp - py * TW;
             const int gy = y0 + py, gx = x0 + px;
-            og[it] = (u < G_UNITS && gy < a.H && gx < a.W) ? (unsigned)((gy * a.W + gx) * a.CA + part * 4) * 4u : OOB;
+            og[it] = (u < G_UNITS && gy < a.H && gx < a.W) ? (unsigned)((gy * a.W + gx) * a.CA * ES + part * 16) : OOB;
         }
 #pragma unroll
         for (int it = 0; it < X_IT; ++it) {
             const int u = tid + it * 256;
-            const int hp = u / (JB / 4), part = u - hp * (JB / 4);
+            const int hp = u / (JB / EPU), part = u - hp * (JB / EPU);
             int gy, gx; bool ok;
             if (MODE == CONV_3X3) {
                 const int hy = hp / (TW + 2), hx = hp - hy * (TW + 2);
@@ -98,23 +100,32 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
                 ok = (y0 + py) < a.H && (x0 + px) < a.W;
                 gy = 2 * (y0 + py) + (tap >> 1); gx = 2 * (x0 + px) + (tap & 1);
             }
-            ox[it] = (u < X_UNITS && ok && part * 4 < jvalid) ? (unsigned)((gy * Wx + gx) * Cs + part * 4) * 4u : OOB;
+            ox[it] = (u < X_UNITS && ok && part * EPU < jvalid) ? (unsigned)((gy * Wx + gx) * Cs * ES + part * 16) : OOB;
         }
 #pragma unroll
-        for (int it = 0; it < G_IT; ++it) rg[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, (int)og[it], i0 * 4, 0));
+        for (int it = 0; it < G_IT; ++it) rg[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, (int)og[it], i0 * ES, 0));
 #pragma unroll
-        for (int it = 0; it < X_IT; ++it) rx[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)ox[it], cs * 4, 0));
+        for (int it = 0; it < X_IT; ++it) rx[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)ox[it], cs * ES, 0));
+    };
+    auto put = [&](float* dst, int u, const float4& raw) {            // LDS rows are unit-linear: [lp][COB] and [hp][JB]
+        if constexpr (ES == 4) {
+            *reinterpret_cast<float4*>(dst + u * 4) = raw;
+        } else {                                                      // 8 bf16 -> 8 fp32
+            const uint4 q = __builtin_bit_cast(uint4, raw);
+            *reinterpret_cast<float4*>(dst + u * 8) = unpack_bf4(make_uint2(q.x, q.y));
+            *reinterpret_cast<float4*>(dst + u * 8 + 4) = unpack_bf4(make_uint2(q.z, q.w));
+        }
     };
     auto store_tile = [&]() {
 #pragma unroll
         for (int it = 0; it < G_IT; ++it) {
             const int u = tid + it * 256;
-            if (u < G_UNITS) *reinterpret_cast<float4*>(ldsG + u * 4) = rg[it];          // [lp][COB] is unit-linear
+            if (u < G_UNITS) put(ldsG, u, rg[it]);
         }
 #pragma unroll
         for (int it = 0; it < X_IT; ++it) {
             const int u = tid + it * 256;
-            if (u < X_UNITS) *reinterpret_cast<float4*>(ldsX + u * 4) = rx[it];          // [hp][JB] is unit-linear
+            if (u < X_UNITS) put(ldsX, u, rx[it]);
         }
     };
 
@@ -193,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     }
 }
 
-template <int MODE, int WCO, int TH>
+template <typename T, int MODE, int WCO, int TH>
 static int launch_w(WgradArgs a, hipStream_t st) {
     constexpr int COB = 32 * WCO;
     constexpr int X_PIX = MODE == CONV_3X3 ? (TH + 2) * (TW + 2) : 4 * TH * TW;
@@ -204,7 +215,7 @@ static int launch_w(WgradArgs a, hipStream_t st) {
     if (lds_bytes < red_bytes) lds_bytes = red_bytes;
     const long long blocks = (long long)(a.CA / COB) * (a.CBp / JB) * a.psplit;
     if (blocks <= 0) return 0;
-    auto kern = wgrad_kernel<MODE, WCO, TH>;
+    auto kern = wgrad_kernel<T, MODE, WCO, TH>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -220,8 +231,14 @@ int launch_wgrad(const WgradArgs& a, int mode, hipStream_t st) {
     if (a.CA % 32 || a.CBp % 32 || a.C0 % 4 || a.C1 % 4 || a.psplit < 1) return ELD_EINVAL;
     if (a.C1 > 0 && a.C0 % 32) return ELD_EINVAL;
     const bool c64 = a.CA % 64 == 0;
-    if (mode == CONV_3X3) return c64 ? launch_w<CONV_3X3, 2, 4>(a, st) : launch_w<CONV_3X3, 1, 4>(a, st);
-    if (mode == CONV_GATHER2X2) return c64 ? launch_w<CONV_GATHER2X2, 2, 2>(a, st) : launch_w<CONV_GATHER2X2, 1, 2>(a, st);
+    if (a.dtype == DT_BF16) {
+        if (a.C0 % 8 || a.C1 % 8) return ELD_EINVAL;
+        if (mode == CONV_3X3) return c64 ? launch_w<bf16_t, CONV_3X3, 2, 4>(a, st) : launch_w<bf16_t, CONV_3X3, 1, 4>(a, st);
+        if (mode == CONV_GATHER2X2) return c64 ? launch_w<bf16_t, CONV_GATHER2X2, 2, 2>(a, st) : launch_w<bf16_t, CONV_GATHER2X2, 1, 2>(a, st);
+        return ELD_EINVAL;
+    }
+    if (mode == CONV_3X3) return c64 ? launch_w<float, CONV_3X3, 2, 4>(a, st) : launch_w<float, CONV_3X3, 1, 4>(a, st);
+    if (mode == CONV_GATHER2X2) return c64 ? launch_w<float, CONV_GATHER2X2, 2, 2>(a, st) : launch_w<float, CONV_GATHER2X2, 1, 2>(a, st);
     return ELD_EINVAL;
 }
 

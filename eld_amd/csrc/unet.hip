@@ -273,6 +273,10 @@ int unet_forward_bf16(const Plan& P, const float* x, const float* prm, float* ou
     const int N = P.N;
     if (P.in_ch > 4) return ELD_ENOTSUP;
     RC(pack_weights(P, prm, ws, false, st, true));
+    {   // keep the fp32 input for the first layer's weight gradient
+        hipError_t e = hipMemcpyAsync(ws + P.x16, x, (size_t)N * P.in_ch * P.H * P.W * sizeof(float), hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return (int)e;
+    }
     auto B = [&](size_t off) { return reinterpret_cast<bf16_t*>(ws + off); };
     for (int l = 0; l < NLEV; ++l) {
         const LayerDef& A = P.L[2 * l]; const LayerDef& Bd = P.L[2 * l + 1];
@@ -347,6 +351,81 @@ int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd
     return 0;
 }
 
+// bf16 backward: activation gradients bf16 (igemm on v_mfma_f32_32x32x16_bf16), weight gradients accumulated and written
+// in fp32 (the wgrad kernels convert the bf16 operands while staging; fp32 MFMA).  Mirrors unet_backward step for step.
+int conv_bwd_data_bf16(const bf16_t* g, const bf16_t* wb, bf16_t* out0, bf16_t* out1, int split, const bf16_t* act0, const bf16_t* act1, int N, int H,
+                       int W, int Cin, int Cout, hipStream_t st) {
+    ConvArgs a = {};
+    a.in0 = g; a.C0 = Cout; a.wp = wb; a.N = N; a.H = H; a.W = W; a.Nout = Cin;
+    a.epi = EPI_GRAD; a.out0 = out0; a.out1 = out1; a.split = split; a.act0 = act0; a.act1 = act1; a.dtype = DT_BF16;
+    return launch_conv(a, CONV_3X3, st);
+}
+
+int conv_wgrad_bf16(const bf16_t* g, int Cout, const bf16_t* x0, int C0, const bf16_t* x1, int C1, float* dw, float* db, float* part,
+                    int N, int H, int W, hipStream_t st) {
+    const WgradGeom q = wgrad_geom(CONV_3X3, Cout, C0 + C1, N, H, W);
+    WgradArgs a = {};
+    a.g = g; a.CA = Cout; a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.N = N; a.H = H; a.W = W; a.dtype = DT_BF16;
+    a.part = part; a.bpart = db ? part + (size_t)q.psplit * q.T * q.CA * q.CBp : nullptr; a.CBp = q.CBp; a.psplit = q.psplit;
+    RC(launch_wgrad(a, CONV_3X3, st));
+    return launch_wgrad_reduce(part, a.bpart, dw, db, q.psplit, q.T, q.CA, q.CBp, C0 + C1, st);
+}
+
+int unet_backward_bf16(const Plan& P, const float* dout, const float* prm, float* grd, float* ws, hipStream_t st) {
+    const int N = P.N;
+    if (P.in_ch > 4) return ELD_ENOTSUP;
+    RC(pack_weights(P, prm, ws, true, st, true));
+    auto B = [&](size_t off) { return reinterpret_cast<bf16_t*>(ws + off); };
+    bf16_t* cur = B(P.gA); bf16_t* oth = B(P.gB); float* part = ws + P.part;
+    const LayerDef& Hd = P.L[L_HEAD];
+    RC(launch_head_bwd_bf16(dout, B(P.db[0]), prm + Hd.w_off, cur, grd + Hd.w_off, grd + Hd.b_off, part, N, P.H, P.W, P.out_ch, st));
+    auto swap = [&]() { bf16_t* t = cur; cur = oth; oth = t; };
+    for (int l = 0; l <= 3; ++l) {
+        const int iu = L_UP3 + 3 * (3 - l);
+        const int H = P.Hl[l], W = P.Wl[l], C = chan(l);
+        RC(conv_wgrad_bf16(cur, C, B(P.da[l]), C, nullptr, 0, grd + P.L[iu + 2].w_off, grd + P.L[iu + 2].b_off, part, N, H, W, st));
+        RC(conv_bwd_data_bf16(cur, B(P.wp_bwd[iu + 2]), oth, nullptr, C, B(P.da[l]), nullptr, N, H, W, C, C, st));
+        swap();
+        RC(conv_wgrad_bf16(cur, C, B(P.up[l]), C, B(P.eb[l]), C, grd + P.L[iu + 1].w_off, grd + P.L[iu + 1].b_off, part, N, H, W, st));
+        RC(conv_bwd_data_bf16(cur, B(P.wp_bwd[iu + 1]), oth, B(P.skip[l]), C, nullptr, nullptr, N, H, W, 2 * C, C, st));
+        swap();
+        const bf16_t* src = l == 3 ? B(P.eb[4]) : B(P.db[l + 1]);
+        {   // transposed conv: weight gradient (gather mode), bias gradient (column sums of d_up), backward data
+            const int Hi = P.Hl[l + 1], Wi = P.Wl[l + 1];
+            const WgradGeom q = wgrad_geom(CONV_GATHER2X2, 2 * C, C, N, Hi, Wi);
+            WgradArgs a = {};
+            a.g = src; a.CA = 2 * C; a.x0 = cur; a.C0 = C; a.N = N; a.H = Hi; a.W = Wi; a.dtype = DT_BF16;
+            a.part = part; a.bpart = nullptr; a.CBp = q.CBp; a.psplit = q.psplit;
+            RC(launch_wgrad(a, CONV_GATHER2X2, st));
+            RC(launch_wgrad_reduce(part, nullptr, grd + P.L[iu].w_off, nullptr, q.psplit, q.T, q.CA, q.CBp, C, st));
+            RC(launch_colsum_bf16(cur, grd + P.L[iu].b_off, part, (size_t)N * 4 * Hi * Wi, C, st));
+            ConvArgs c = {};
+            c.in0 = cur; c.C0 = C; c.wp = B(P.wp_bwd[iu]); c.N = N; c.H = Hi; c.W = Wi; c.Nout = 2 * C;
+            c.epi = EPI_GRAD; c.out0 = oth; c.split = 2 * C; c.act0 = src; c.dtype = DT_BF16;
+            RC(launch_conv(c, CONV_GATHER2X2, st));
+        }
+        swap();
+    }
+    for (int l = 4; l >= 0; --l) {
+        const int H = P.Hl[l], W = P.Wl[l], C = chan(l);
+        const int ia = 2 * l, ib = 2 * l + 1;
+        RC(conv_wgrad_bf16(cur, C, B(P.ea[l]), C, nullptr, 0, grd + P.L[ib].w_off, grd + P.L[ib].b_off, part, N, H, W, st));
+        RC(conv_bwd_data_bf16(cur, B(P.wp_bwd[ib]), oth, nullptr, C, B(P.ea[l]), nullptr, N, H, W, C, C, st));
+        swap();
+        if (l == 0) {
+            RC(launch_conv_first_wgrad_bf16(cur, ws + P.x16, grd + P.L[ia].w_off, grd + P.L[ia].b_off, part, N, P.in_ch, H, W, st));
+            break;
+        }
+        const int Cp = chan(l - 1);
+        RC(conv_wgrad_bf16(cur, C, B(P.pool[l - 1]), Cp, nullptr, 0, grd + P.L[ia].w_off, grd + P.L[ia].b_off, part, N, H, W, st));
+        RC(conv_bwd_data_bf16(cur, B(P.wp_bwd[ia]), oth, nullptr, Cp, nullptr, nullptr, N, H, W, Cp, C, st));
+        swap();
+        RC(launch_maxpool_bwd_bf16(B(P.eb[l - 1]), cur, B(P.skip[l - 1]), oth, N, H, W, Cp, st));
+        swap();
+    }
+    return 0;
+}
+
 }  // namespace
 
 // ====================================================================================================
@@ -395,6 +474,16 @@ extern "C" int eld_unet_backward(const float* dout, const float* params, float* 
     if (!dout || !params || !grads || !ws) return ELD_EINVAL;
     if (ws_bytes < P.total * sizeof(float)) return ELD_EWS;
     return unet_backward(P, dout, params, grads, (float*)ws, as_stream(stream));
+}
+
+extern "C" int eld_unet_backward_bf16(const float* dout, const float* params, float* grads, void* ws, size_t ws_bytes, int N, int H, int W,
+                                      int in_ch, int out_ch, void* stream) {
+    if (N == 0) return 0;
+    Plan P;
+    RC(make_plan(P, N, H, W, in_ch, out_ch));
+    if (!dout || !params || !grads || !ws) return ELD_EINVAL;
+    if (ws_bytes < P.total * sizeof(float)) return ELD_EWS;
+    return unet_backward_bf16(P, dout, params, grads, (float*)ws, as_stream(stream));
 }
 
 extern "C" size_t eld_l1_workspace_bytes(void) { return l1_ws_floats() * sizeof(float); }

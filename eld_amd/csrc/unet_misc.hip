@@ -528,3 +528,139 @@ int launch_head_fwd_bf16(const bf16_t* in, const float* w, const float* b, float
     ELD_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- backward pieces with bf16 activations / gradients (fp32 math, fp32 weight-gradient outputs) -----------------------
+__global__ void maxpool_bwd_bf16_kernel(const bf16_t* __restrict__ act, const bf16_t* __restrict__ dp, const bf16_t* __restrict__ skip,
+                                        bf16_t* __restrict__ g, int N, int Ho, int Wo, int C) {
+    const int C4 = C / 4;
+    const size_t total = (size_t)N * Ho * Wo * C4;
+    const int Wi = 2 * Wo;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        size_t p = i / C4;
+        const int xo = (int)(p % Wo); p /= Wo;
+        const int yo = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        const size_t base = ((((size_t)n * 2 * Ho + 2 * yo) * Wi + 2 * xo) * C) / 4 + c4;
+        const size_t o1 = C4, o2 = (size_t)Wi * C4, o3 = o2 + C4;
+        const uint2* A = reinterpret_cast<const uint2*>(act);
+        const float4 a = unpack_bf4(A[base]), b = unpack_bf4(A[base + o1]), c = unpack_bf4(A[base + o2]), d = unpack_bf4(A[base + o3]);
+        const float4 gp = unpack_bf4(reinterpret_cast<const uint2*>(dp)[i]);
+        float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa, sc = sa, sd = sa;
+        if (skip) {
+            const uint2* S = reinterpret_cast<const uint2*>(skip);
+            sa = unpack_bf4(S[base]); sb = unpack_bf4(S[base + o1]); sc = unpack_bf4(S[base + o2]); sd = unpack_bf4(S[base + o3]);
+        }
+        float4 ga, gb, gc, gd;
+        POOL_BWD_1(x) POOL_BWD_1(y) POOL_BWD_1(z) POOL_BWD_1(w)
+        uint2* G = reinterpret_cast<uint2*>(g);
+        G[base] = pack_bf4(ga); G[base + o1] = pack_bf4(gb); G[base + o2] = pack_bf4(gc); G[base + o3] = pack_bf4(gd);
+    }
+}
+
+int launch_maxpool_bwd_bf16(const bf16_t* act, const bf16_t* dp, const bf16_t* skip, bf16_t* g, int N, int Ho, int Wo, int C, hipStream_t st) {
+    const size_t total = (size_t)N * Ho * Wo * (C / 4);
+    if (!total) return 0;
+    hipLaunchKernelGGL(maxpool_bwd_bf16_kernel, dim3((unsigned)min((total + 255) / 256, (size_t)32768)), dim3(256), 0, st, act, dp, skip, g, N, Ho, Wo, C);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void head_bwd_bf16_kernel(const float* __restrict__ dout, const bf16_t* __restrict__ act, const float* __restrict__ w,
+                                                            bf16_t* __restrict__ g, float* __restrict__ part, int N, size_t HW, int OC) {
+    __shared__ float sw[128];
+    __shared__ float red[4][132];
+    for (int i = threadIdx.x; i < 128; i += 256) sw[i] = (i / 32 < OC) ? w[i] : 0.f;
+    __syncthreads();
+    float dw[4][32];
+    float db[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int c = 0; c < 32; ++c) dw[o][c] = 0.f;
+    const size_t total = (size_t)N * HW;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = p / HW, q = p - n * HW;
+        float d[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) { d[o] = o < OC ? dout[(n * OC + o) * HW + q] : 0.f; db[o] += d[o]; }
+        const uint2* A = reinterpret_cast<const uint2*>(act + p * 32);
+        uint2* G = reinterpret_cast<uint2*>(g + p * 32);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float4 a = unpack_bf4(A[k]);
+            const float av[4] = {a.x, a.y, a.z, a.w};
+            float gv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = 4 * k + j;
+                float s = 0.f;
+#pragma unroll
+                for (int o = 0; o < 4; ++o) { s = fmaf(sw[o * 32 + c], d[o], s); dw[o][c] = fmaf(d[o], av[j], dw[o][c]); }
+                gv[j] = s * lrelu_slope(av[j]);
+            }
+            G[k] = pack_bf4(make_float4(gv[0], gv[1], gv[2], gv[3]));
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            float v = dw[o][c];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0) red[wave][o * 32 + c] = v;
+        }
+        float v = db[o];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[wave][128 + o] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 132)
+        part[(size_t)blockIdx.x * 132 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+int launch_head_bwd_bf16(const float* dout, const bf16_t* act, const float* w, bf16_t* g, float* dw, float* db, float* part,
+                         int N, int H, int W, int OC, hipStream_t st) {
+    const size_t total = (size_t)N * H * W;
+    if (!total) return 0;
+    const int nb = (int)min((total + 255) / 256, (size_t)HEAD_BLOCKS);
+    hipLaunchKernelGGL(head_bwd_bf16_kernel, dim3(nb), dim3(256), 0, st, dout, act, w, g, part, N, (size_t)H * W, OC);
+    ELD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3((132 + 15) / 16), dim3(256), 0, st, part, dw, db, nb, OC);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ x, float* __restrict__ part, size_t P, int C) {
+    const int C4 = C / 4;
+    const int ppb = 256 / C4;
+    const int c4 = threadIdx.x % C4, pl = threadIdx.x / C4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pl < ppb) {
+        for (size_t p = (size_t)blockIdx.x * ppb + pl; p < P; p += (size_t)gridDim.x * ppb) {
+            const float4 v = unpack_bf4(reinterpret_cast<const uint2*>(x + p * C)[c4]);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    __shared__ float4 sh[256];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < C4) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < ppb; ++k) { const float4 v = sh[k * C4 + threadIdx.x]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        reinterpret_cast<float4*>(part + (size_t)blockIdx.x * C)[threadIdx.x] = t;
+    }
+}
+
+int launch_colsum_bf16(const bf16_t* x, float* out, float* part, size_t P, int C, hipStream_t st) {
+    if (C % 4 || C > 512) return ELD_EINVAL;
+    const int ppb = 256 / (C / 4);
+    const int nb = (int)min((P + ppb - 1) / ppb, (size_t)COLSUM_BLOCKS);
+    if (nb == 0) return 0;
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(nb), dim3(256), 0, st, x, part, P, C);
+    ELD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, out, nb, C);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}

@@ -101,6 +101,8 @@ class ELDModel:
             raise NotImplementedError('sRGB stages are outside the MI355X hot path (raw->raw only)')
         ch = getattr(opt, 'channels', 4)
         self.netG = ARCH[getattr(opt, 'netG', 'unet')](ch, ch).to(self.device)
+        prec = getattr(opt, 'precision', os.environ.get('ELD_AMD_PRECISION', 'fp32'))      # 'bf16' = BASELINE config 3
+        self.netG.train_precision = self.netG.inference_precision = prec
         self.world, self.rank = D.world_size(), D.rank()
         if self.world > 1:
             D.broadcast_(self.netG.flat_params, 0)          # identical replicas
@@ -196,7 +198,7 @@ class ELDModel:
     def optimize_parameters(self, **kwargs):
         net, opt = self.netG, self.optimizer_G
         x = self.input.contiguous().float()
-        out, key, _ = net._engine_forward(x, save=True)                       # forward()
+        out, key, _ = net._engine_forward(x, save=True, bf16=net.train_precision == 'bf16')      # forward()
         self.output = out
         dout = torch.empty_like(out)
         L.check(L.lib().eld_l1_loss(L.dptr(out), L.dptr(self.target.contiguous()), L.dptr(dout), L.dptr(self._loss_buf), L.dptr(self._l1_ws),
@@ -230,10 +232,10 @@ class ELDModel:
         out = self.forward()
         if correct:                                  # IlluminanceCorrect, ELD_model.py:138-169
             out = illuminance_correct(out, self.target)
-        a = torch.clamp(out[0] * 255.0, 0, 255)      # tensor2im, ELD_model.py:23-38
+        from .metrics import quality_assess
+        a = torch.clamp(out[0] * 255.0, 0, 255)      # tensor2im, ELD_model.py:23-38 (float, not rounded); only image 0 of the batch
         b = torch.clamp(self.target[0] * 255.0, 0, 255)
-        mse = torch.mean((a.double() - b.double()) ** 2)
-        return {'PSNR': float(10.0 * torch.log10(255.0 ** 2 / mse))}
+        return quality_assess(a, b)                  # util/index.py:76-81: {'PSNR', 'SSIM'}
 
     # ---- checkpoints (base_model.py:55-66, ELD_model.py:492-523) -----------------------------------------------
     def state_dict(self):

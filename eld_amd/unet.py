@@ -46,7 +46,7 @@ class _Workspace:
 class _UNetFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, x, *params):
-        out, key, gen = net._engine_forward(x, save=True)
+        out, key, gen = net._engine_forward(x, save=True, bf16=net.train_precision == 'bf16')
         ctx.net, ctx.key, ctx.gen, ctx.shape = net, key, gen, tuple(x.shape)
         return out
 
@@ -116,6 +116,7 @@ class UNetSeeInDark(nn.Module):
 
     # ---- engine calls ----------------------------------------------------------------------------------
     inference_precision = 'fp32'          # 'bf16': no-grad forwards run eld_unet_forward_bf16 (BASELINE config 3 precision)
+    train_precision = 'fp32'              # 'bf16': training forwards/backwards run the bf16 engine (fp32 master weights/grads)
 
     def _engine_forward(self, x, save, bf16=False):
         if not x.is_cuda:
@@ -127,7 +128,7 @@ class UNetSeeInDark(nn.Module):
         if H % 16 or W % 16:
             raise RuntimeError('U-Net input H, W must be multiples of 16 (4 pooling levels), got %dx%d' % (H, W))
         nbytes = L.lib().eld_unet_workspace_bytes(N, H, W, self.in_channels, self.out_channels)
-        key = ('train' if save else ('eval_bf16' if bf16 else 'eval'), N, H, W)
+        key = (('train_bf16' if bf16 else 'train') if save else ('eval_bf16' if bf16 else 'eval'), N, H, W)
         ws = self._ws.get(key, nbytes, x.device)
         self._ws.gen[key] += 1
         out = torch.empty((N, self.out_channels, H, W), dtype=torch.float32, device=x.device)
@@ -141,8 +142,9 @@ class UNetSeeInDark(nn.Module):
         ws = self._ws.bufs[key]
         if grads is None:
             grads = torch.empty(self._offsets[-1], dtype=torch.float32, device=dout.device)
-        L.check(L.lib().eld_unet_backward(L.dptr(dout), L.dptr(self.flat_params), L.dptr(grads), L.dptr(ws), ws.numel(),
-                                          N, H, W, self.in_channels, self.out_channels, L.cur_stream()), 'eld_unet_backward')
+        fn = L.lib().eld_unet_backward_bf16 if key[0] == 'train_bf16' else L.lib().eld_unet_backward
+        L.check(fn(L.dptr(dout), L.dptr(self.flat_params), L.dptr(grads), L.dptr(ws), ws.numel(),
+                   N, H, W, self.in_channels, self.out_channels, L.cur_stream()), 'eld_unet_backward')
         return grads
 
     def forward(self, x):

@@ -125,9 +125,13 @@ int eld_unet_forward(const float* x, const float* params, float* out, void* ws, 
                      int N, int H, int W, int in_ch, int out_ch, void* stream);
 /* Inference in bf16 (BASELINE config 3's precision): bf16 NHWC activations and packed weights on v_mfma_f32_32x32x16_bf16,
  * fp32 accumulation, bias, first-layer input and output.  Same arguments and workspace as eld_unet_forward; the saved
- * activations are bf16, so eld_unet_backward must not follow this call. */
+ * activations are bf16: follow it with eld_unet_backward_bf16, never with eld_unet_backward. */
 int eld_unet_forward_bf16(const float* x, const float* params, float* out, void* ws, size_t ws_bytes,
                           int N, int H, int W, int in_ch, int out_ch, void* stream);
+/* Backward of a bf16 forward: bf16 activation gradients on the bf16 MFMA; parameter gradients are accumulated and
+ * written in fp32 (fp32 master weights and Adam are unchanged).  Same contract as eld_unet_backward. */
+int eld_unet_backward_bf16(const float* dout, const float* params, float* grads, void* ws, size_t ws_bytes,
+                           int N, int H, int W, int in_ch, int out_ch, void* stream);
 /* Needs the workspace exactly as eld_unet_forward left it (saved activations).  Writes every element of grads. */
 int eld_unet_backward(const float* dout, const float* params, float* grads, void* ws, size_t ws_bytes,
                       int N, int H, int W, int in_ch, int out_ch, void* stream);

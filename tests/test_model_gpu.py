@@ -188,6 +188,22 @@ def test_forward_chop_and_eval_psnr(eld_lib, tmp_path):
     b = np.clip(t[0].numpy() * 255.0, 0, 255)
     psnr = 10 * np.log10(255.0 ** 2 / np.mean((a.astype(np.float64) - b) ** 2))
     assert abs(r['PSNR'] - psnr) < 1e-3
+    from oracle import metrics_ref as M
+    assert abs(r['SSIM'] - M.ssim(a, b)) < 1e-6 and abs(r['PSNR'] - M.psnr(b, a)) < 1e-3
+
+
+def test_metrics_on_device_vs_oracle(eld_lib):
+    """PSNR / SSIM as util/index.py:76-81 computes them (skimage defaults restated in oracle/metrics_ref.py)."""
+    from eld_amd.metrics import quality_assess, ssim
+    from oracle import metrics_ref as M
+    g = torch.Generator().manual_seed(0)
+    for shape, noise in (((4, 64, 80), 5.0), ((4, 37, 41), 30.0), ((3, 128, 128), 0.5)):
+        y = torch.rand(*shape, generator=g) * 255
+        x = torch.clamp(y + noise * torch.randn(*shape, generator=g), 0, 255)
+        r = quality_assess(x.cuda(), y.cuda())
+        assert abs(r['PSNR'] - M.psnr(y.numpy(), x.numpy())) < 1e-4
+        assert abs(r['SSIM'] - M.ssim(y.numpy(), x.numpy())) < 1e-7
+    assert abs(float(ssim(y.cuda(), y.cuda())) - 1.0) < 1e-12
 
 
 def test_engine_train_loop(eld_lib, tmp_path, capsys):
@@ -217,3 +233,22 @@ def test_model_requires_gpu_and_raw_stage(eld_lib, tmp_path):
         ELDModel().initialize(make_opt(tmp_path, gpu_ids=[]))
     with pytest.raises(NotImplementedError):
         ELDModel().initialize(make_opt(tmp_path, stage_in='srgb'))
+
+
+def test_bf16_training_tracks_fp32(eld_lib, tmp_path):
+    """BASELINE config 3 precision through the model plugin: same init, same batches -> the bf16 loss curve stays within
+    1 % of the fp32 one over 6 iterations and both decrease; master weights stay fp32."""
+    losses = {}
+    for prec in ('fp32', 'bf16'):
+        m = new_model(tmp_path, seed=3, precision=prec)
+        assert m.netG.train_precision == prec and m.netG.flat_params.dtype == torch.float32
+        ls = []
+        for it in range(6):
+            x, t = batch(shape=(2, 4, 64, 64), seed=it % 2)
+            m.set_input({'input': x, 'target': t}, 'train')
+            m.optimize_parameters()
+            ls.append(m.get_current_errors()['Pixel'])
+        losses[prec] = ls
+    a, b = np.array(losses['fp32']), np.array(losses['bf16'])
+    assert np.all(np.abs(a - b) / a < 0.01), (a, b)
+    assert a[-1] < a[0] and b[-1] < b[0]
