@@ -16,15 +16,23 @@
 // workgroup (persistent over tiles: the K reduction stays in registers), so the only HBM writes are
 // one partial per workgroup.  Partials are summed by a second kernel in a fixed order
 // (run-to-run bit-stable, no atomics).
+#include <stdlib.h>
 #include "conv.h"
 
 #define TW 32
 #define JB 32     // j (shifted-operand channel) tile
 
-template <typename T, int MODE, int WCO, int TH>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// BFM = true (bf16 inputs only): the tiles stay bf16 in LDS, untransposed [pixel][channel], and the contraction runs on
+// v_mfma_f32_32x32x16_bf16 with K = 16 consecutive pixels of a row: lane (channel = lane&31, kb = lane>>5) gathers its
+// 8 pixel values with 16-bit LDS reads (a half-wave reads 32 consecutive channels of one pixel: conflict-free).  The
+// G fragment of a k-step is shared by all taps, so a k-step costs 8 + 8*TAPS ds_read_u16 for TAPS MFMAs.
+template <typename T, int MODE, int WCO, int TH, bool BFM>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
-    constexpr int ES = sizeof(T);            // element size of g / x in HBM (float or bf16); LDS and accumulation are fp32
+    constexpr int ES = sizeof(T);            // element size of g / x in HBM (float or bf16); accumulation is fp32
     constexpr int EPU = 16 / ES;             // elements per 16-byte staging unit
+    constexpr int LES = BFM ? 2 : 4;         // element size in LDS
     constexpr int TAPS = MODE == CONV_3X3 ? 9 : 4;
     constexpr int WPIX = 4 / WCO;
     constexpr int COB = 32 * WCO;
@@ -33,8 +41,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     constexpr int KS = PW / 2;             // MFMA k-steps per wave per tile
     constexpr int X_PIX = MODE == CONV_3X3 ? (TH + 2) * (TW + 2) : 4 * TPIX;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* ldsG = lds;                     // [TPIX][COB]
-    float* ldsX = lds + TPIX * COB;        // [X_PIX][JB]
+    float* ldsG = lds;                                   // [TPIX][COB]   (LES-byte elements)
+    float* ldsX = lds + TPIX * COB * LES / 4;            // [X_PIX][JB]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 31, hi = lane >> 5;
@@ -108,8 +116,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
         for (int it = 0; it < X_IT; ++it) rx[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)ox[it], cs * ES, 0));
     };
     auto put = [&](float* dst, int u, const float4& raw) {            // LDS rows are unit-linear: [lp][COB] and [hp][JB]
-        if constexpr (ES == 4) {
-            *reinterpret_cast<float4*>(dst + u * 4) = raw;
+        if constexpr (ES == 4 || BFM) {
+            *reinterpret_cast<float4*>(dst + u * 4) = raw;            // 16 bytes as loaded
         } else {                                                      // 8 bf16 -> 8 fp32
             const uint4 q = __builtin_bit_cast(uint4, raw);
             *reinterpret_cast<float4*>(dst + u * 8) = unpack_bf4(make_uint2(q.x, q.y));
@@ -142,6 +150,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
         store_tile();
         __syncthreads();
         if (tile + a.psplit < ntiles) load_tile(tile + a.psplit);
+        if constexpr (!BFM) {
         // ---- K loop, fully unrolled; operands of step s+1 are read from LDS under step s's MFMAs -------------
         float fa[2], fb[2][TAPS];
         auto read_step = [&](int s_, float& A, float (&B)[TAPS]) {
@@ -162,6 +171,38 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur], fb[cur][t], acc[t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+        }
+        } else {
+        // ---- bf16 MFMA: k-steps of 16 consecutive pixels (PW is a multiple of 16 and a k-step never leaves its row) ----
+        constexpr int KSB = PW / 16;
+        const bf16_t* gq = reinterpret_cast<const bf16_t*>(ldsG) + (wpix * PW + 8 * hi) * COB + wco * 32 + m;
+        const int lq0 = wpix * PW + 8 * hi;                         // first pixel of this lane's k-half
+        const int pyq = lq0 / TW, pxq = lq0 - pyq * TW;
+        const bf16_t* xq = reinterpret_cast<const bf16_t*>(ldsX) + (MODE == CONV_3X3 ? (pyq * (TW + 2) + pxq) : lq0) * JB + m;
+        auto gather8 = [&](const bf16_t* p, int stride) {           // 8 pixel values of this lane's channel -> one MFMA operand
+            unsigned w0 = (unsigned)p[0] | ((unsigned)p[stride] << 16);
+            unsigned w1 = (unsigned)p[2 * stride] | ((unsigned)p[3 * stride] << 16);
+            unsigned w2 = (unsigned)p[4 * stride] | ((unsigned)p[5 * stride] << 16);
+            unsigned w3 = (unsigned)p[6 * stride] | ((unsigned)p[7 * stride] << 16);
+            return make_uint4(w0, w1, w2, w3);
+        };
+#pragma unroll
+        for (int ks = 0; ks < KSB; ++ks) {
+            // pixel offset of k-step ks inside the wave's slice: rows advance every TW/16 steps
+            const int lrel = ks * 16;
+            const int dy = lrel / TW, dxp = lrel - dy * TW;
+            const uint4 ga = gather8(gq + lrel * COB, COB);
+            if (a.bpart) {
+                bsum += __uint_as_float(ga.x << 16) + __uint_as_float(ga.x & 0xFFFF0000u) + __uint_as_float(ga.y << 16) + __uint_as_float(ga.y & 0xFFFF0000u)
+                      + __uint_as_float(ga.z << 16) + __uint_as_float(ga.z & 0xFFFF0000u) + __uint_as_float(ga.w << 16) + __uint_as_float(ga.w & 0xFFFF0000u);
+            }
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                const int xoff = MODE == CONV_3X3 ? ((dy + t / 3) * (TW + 2) + dxp + t % 3) : (t * TPIX + lrel);
+                const uint4 xb = gather8(xq + xoff * JB, JB);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ga), __builtin_bit_cast(bf16x8, xb), acc[t], 0, 0, 0);
+            }
+        }
         }
     }
 
@@ -204,18 +245,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     }
 }
 
-template <typename T, int MODE, int WCO, int TH>
+template <typename T, int MODE, int WCO, int TH, bool BFM = false>
 static int launch_w(WgradArgs a, hipStream_t st) {
     constexpr int COB = 32 * WCO;
     constexpr int X_PIX = MODE == CONV_3X3 ? (TH + 2) * (TW + 2) : 4 * TH * TW;
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + TH - 1) / TH;
-    size_t lds_bytes = (size_t)(TH * TW * COB + X_PIX * JB) * sizeof(float);
+    size_t lds_bytes = (size_t)(TH * TW * COB + X_PIX * JB) * (BFM ? 2 : 4);
     const size_t red_bytes = (size_t)4 * 16 * 64 * sizeof(float);
     if (lds_bytes < red_bytes) lds_bytes = red_bytes;
     const long long blocks = (long long)(a.CA / COB) * (a.CBp / JB) * a.psplit;
     if (blocks <= 0) return 0;
-    auto kern = wgrad_kernel<T, MODE, WCO, TH>;
+    auto kern = wgrad_kernel<T, MODE, WCO, TH, BFM>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -233,6 +274,13 @@ int launch_wgrad(const WgradArgs& a, int mode, hipStream_t st) {
     const bool c64 = a.CA % 64 == 0;
     if (a.dtype == DT_BF16) {
         if (a.C0 % 8 || a.C1 % 8) return ELD_EINVAL;
+        static int mma = -1;                  // ELD_WGRAD_BF16_MMA=0 falls back to fp32-MFMA accumulation of the widened operands
+        if (mma < 0) { const char* e = getenv("ELD_WGRAD_BF16_MMA"); mma = e ? atoi(e) : 1; }
+        if (mma) {
+            if (mode == CONV_3X3) return c64 ? launch_w<bf16_t, CONV_3X3, 2, 4, true>(a, st) : launch_w<bf16_t, CONV_3X3, 1, 4, true>(a, st);
+            if (mode == CONV_GATHER2X2) return c64 ? launch_w<bf16_t, CONV_GATHER2X2, 2, 2, true>(a, st) : launch_w<bf16_t, CONV_GATHER2X2, 1, 2, true>(a, st);
+            return ELD_EINVAL;
+        }
         if (mode == CONV_3X3) return c64 ? launch_w<bf16_t, CONV_3X3, 2, 4>(a, st) : launch_w<bf16_t, CONV_3X3, 1, 4>(a, st);
         if (mode == CONV_GATHER2X2) return c64 ? launch_w<bf16_t, CONV_GATHER2X2, 2, 2>(a, st) : launch_w<bf16_t, CONV_GATHER2X2, 1, 2>(a, st);
         return ELD_EINVAL;
