@@ -58,6 +58,10 @@ __device__ __forceinline__ float4 unpack_bf4(uint2 p) {
 }
 
 int launch_conv(const ConvArgs& a, int mode, hipStream_t st);
+// fp32 3x3 convolutions: 0 = exact-fp32 MFMA (conv_igemm.hip), 1 = three-piece bf16 split on the bf16 MFMA (conv_x3.hip).
+// set < 0 only queries.  Initial value from env ELD_FP32_CONV (mfma | x3).  Returns the value in force before the call.
+int conv_fp32_algo(int set);
+int launch_conv_x3(const ConvArgs& a, hipStream_t st);
 
 // dW-type reduction:  P[tap][i][j] = sum_pixels G[pixel][i] * X[pixel (+) tap][j]
 struct WgradArgs {

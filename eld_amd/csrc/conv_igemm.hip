@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include "conv.h"
 
+#define ELD_FP32_CONV_DEFAULT 1
 #define PS 20           // LDS pixel stride in 4-byte words: one 64-byte K chunk (16 fp32 / 32 bf16 channels) + 16 bytes pad
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define TW 32
@@ -360,6 +361,18 @@ static int launch_dt(const ConvArgs& a, int mode, hipStream_t st) {
     return ELD_EINVAL;
 }
 
+int conv_fp32_algo(int set) {
+    static int algo = -1;
+    if (algo < 0) {
+        const char* e = getenv("ELD_FP32_CONV");
+        algo = (e && (e[0] == 'm' || e[0] == '0')) ? 0 : ELD_FP32_CONV_DEFAULT;
+        if (e && (e[0] == 'x' || e[0] == '1')) algo = 1;
+    }
+    const int prev = algo;
+    if (set == 0 || set == 1) algo = set;
+    return prev;
+}
+
 int launch_conv(const ConvArgs& a_in, int mode, hipStream_t st) {
     ConvArgs a = a_in;
     static int dbg = -1;
@@ -371,5 +384,7 @@ int launch_conv(const ConvArgs& a_in, int mode, hipStream_t st) {
     if (a.C1 != 0 && a.C1 != a.C0) return ELD_ENOTSUP;          // virtual concat of two equally wide tensors (all the U-Net needs)
     if (a.epi == EPI_GRAD && (a.split % 32)) return ELD_EINVAL;
     if (a.epi == EPI_CONVT_FWD && (a.Cout_t % 4)) return ELD_EINVAL;
-    return a.dtype == DT_BF16 ? launch_dt<bf16_t>(a, mode, st) : launch_dt<float>(a, mode, st);
+    if (a.dtype == DT_BF16) return launch_dt<bf16_t>(a, mode, st);
+    if (mode == CONV_3X3 && a.epi != EPI_CONVT_FWD && conv_fp32_algo(-1) == 1) return launch_conv_x3(a, st);
+    return launch_dt<float>(a, mode, st);
 }

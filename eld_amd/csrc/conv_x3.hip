@@ -1,0 +1,318 @@
+// conv_x3.hip -- fp32 3x3 convolution (forward and backward-data) on the bf16 matrix pipe, gfx950.
+//
+// Same contract as conv_igemm_kernel<float, CONV_3X3, ...> (conv_igemm.hip): fp32 NHWC activations, fp32 packed
+// weights [tap][Nout][Cin], fp32 accumulation, fp32 results -- replaces nn.Conv2d(3x3, p=1) + max(0.2x, x) of
+// models/arch/Unet.py:11-46,102-104 and its autograd backward-data.  Only the way a product a*w is formed differs:
+//
+//   every fp32 operand is cut EXACTLY into three bf16 pieces while it is staged into LDS,
+//        a = a1 + a2 + a3,   a1 = top 16 bits of a,  a2 = top 16 bits of (a - a1),  a3 = a - a1 - a2
+//   (8 + 8 + 8 significant bits; both subtractions are exact in fp32), and
+//        a*w ~= a1 w1 + a1 w2 + a2 w1 + a1 w3 + a2 w2 + a3 w1
+//   is accumulated in fp32 by six v_mfma_f32_32x32x16_bf16 (each bf16 x bf16 product is exact in fp32).  The dropped
+//   terms a2 w3 + a3 w2 + a3 w3 are below 2^-23 |a w|: the error of one product is smaller than the rounding of
+//   the fp32 product itself, and the sum is accumulated in fp32 exactly as on the fp32 MFMA -- measured error against
+//   an fp64 convolution is the same as (slightly below) the v_mfma_f32_32x32x2_f32 kernel's (tests/test_unet_gpu.py).
+//
+// Why: six bf16 MFMAs cover 16 k-values in 6 x 32 = 192 matrix-pipe cycles, eight fp32 MFMAs need 8 x 64 = 512 for
+// the same 16 k-values -> 2.67x the fp32 peak (2.5 PFLOP/s / 6 = 417 TFLOP/s "fp32-equivalent" against 157 TFLOP/s),
+// and each staged fragment feeds 2-3 MFMAs instead of 1, so the LDS read rate per MFMA is half that of the plain
+// bf16 kernel.
+//
+// Tiling: 256 threads = 4 waves, output tile 4*RPW rows x 32 pixels x BN channels, D[channel][pixel] roles as in
+// conv_igemm.hip.  K chunk = 16 input channels.  LDS row = [3 pieces][16 bf16] = 96 B + 16 B pad (28-word stride:
+// 28/4 is odd, so 16 consecutive rows hit 16 distinct 4-bank groups -> conflict-free ds_read_b128).  The halo tile
+// ((TH+2) x 34 pixels) is staged once per chunk; the weight slab is staged per kernel ROW (3 taps x BN x 16), so a
+// workgroup needs 38 KB + 21 KB of LDS and two of them share a CU: one stages/synchronises while the other feeds the
+// matrix pipe.  Work items (tile, chunk, kernel row) stream through a register-staged pipeline like the fp32 kernel's.
+#include <stdlib.h>
+#include "conv.h"
+
+#define PX 28
+#define TW 32
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+__device__ __forceinline__ unsigned hi_pair(unsigned lo_src, unsigned hi_src) {        // (hi_src & 0xFFFF0000) | (lo_src >> 16)
+    return __builtin_amdgcn_perm(hi_src, lo_src, 0x07060302u);
+}
+
+// cut four fp32 values into their three bf16 pieces and write piece p at word offset 8p of the LDS row
+__device__ __forceinline__ void split_store(float* row, float4 v) {
+    const unsigned x0 = __float_as_uint(v.x), x1 = __float_as_uint(v.y), x2 = __float_as_uint(v.z), x3 = __float_as_uint(v.w);
+    const float r0 = v.x - __uint_as_float(x0 & 0xFFFF0000u), r1 = v.y - __uint_as_float(x1 & 0xFFFF0000u);
+    const float r2 = v.z - __uint_as_float(x2 & 0xFFFF0000u), r3 = v.w - __uint_as_float(x3 & 0xFFFF0000u);
+    const unsigned y0 = __float_as_uint(r0), y1 = __float_as_uint(r1), y2 = __float_as_uint(r2), y3 = __float_as_uint(r3);
+    const float s0 = r0 - __uint_as_float(y0 & 0xFFFF0000u), s1 = r1 - __uint_as_float(y1 & 0xFFFF0000u);
+    const float s2 = r2 - __uint_as_float(y2 & 0xFFFF0000u), s3 = r3 - __uint_as_float(y3 & 0xFFFF0000u);
+    *reinterpret_cast<uint2*>(row) = make_uint2(hi_pair(x0, x1), hi_pair(x2, x3));
+    *reinterpret_cast<uint2*>(row + 8) = make_uint2(hi_pair(y0, y1), hi_pair(y2, y3));
+    *reinterpret_cast<uint2*>(row + 16) = make_uint2(hi_pair(__float_as_uint(s0), __float_as_uint(s1)), hi_pair(__float_as_uint(s2), __float_as_uint(s3)));
+}
+
+template <int BN, int RPW>
+__global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
+    constexpr int CK = 16;
+    constexpr int TH = 4 * RPW, NT = BN / 32, A_PIX = (TH + 2) * (TW + 2);
+    constexpr int A_WORDS = A_PIX * PX, B_ROWS = 3 * BN;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* ldsA = lds;
+    float* ldsB = lds + A_WORDS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 31, hi = lane >> 5;
+    const int NB = a.Nout / BN;
+    const int Cin = a.C0 + a.C1;
+    const int total_tiles = a.tiles_x * a.tiles_y * a.N * NB;
+    const int Cs0 = a.C0;
+
+    constexpr int A_UNITS = A_PIX * 4, B_UNITS = B_ROWS * 4;
+    constexpr int A_IT = (A_UNITS + 255) / 256, B_IT = (B_UNITS + 255) / 256;
+    float4 ra[A_IT], rb[B_IT];
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    unsigned a_voff[A_IT], b_voff[B_IT];
+    int l_img = 0;
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (int)((size_t)9 * a.Nout * Cin * 4), 0x00020000);
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+        const int u = tid + it * 256;
+        const int row = u >> 2, part = u & 3;
+        const int kx = row / BN, n = row - kx * BN;
+        b_voff[it] = u < B_UNITS ? (unsigned)((kx * a.Nout + n) * Cin * 4 + part * 16) : OOB;
+    }
+
+    auto decode = [&](int t, int& nb, int& img, int& y0, int& x0) {
+        nb = t % NB;
+        int r = t / NB;
+        const int tx = r % a.tiles_x;
+        r /= a.tiles_x;
+        const int ty = r % a.tiles_y;
+        img = r / a.tiles_y;
+        y0 = ty * TH; x0 = tx * TW;
+    };
+    auto setup_load = [&](int t) {
+        int nb, y0, x0;
+        decode(t, nb, l_img, y0, x0);
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int u = tid + it * 256;
+            const int hp = u >> 2, part = u & 3;
+            const int hy = hp / (TW + 2), hx = hp - hy * (TW + 2);
+            const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+            const bool ok = u < A_UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            a_voff[it] = ok ? (unsigned)(gy * a.W + gx) * (unsigned)(Cs0 * 4) + (unsigned)part * 16u : OOB;
+        }
+    };
+    auto load_A = [&](int c0) {
+        const char* src = static_cast<const char*>(c0 < a.C0 ? a.in0 : a.in1);
+        const int cs = c0 < a.C0 ? c0 : c0 - a.C0;
+        const size_t img_bytes = (size_t)a.H * a.W * Cs0 * 4;
+        const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)l_img * img_bytes), 0, (int)img_bytes, 0x00020000);
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it)
+            ra[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)a_voff[it], cs * 4, 0));
+    };
+    auto load_B = [&](int nb, int c0, int ky) {
+        const int wsoff = ((ky * 3 * a.Nout + nb * BN) * Cin + c0) * 4;
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it)
+            rb[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)b_voff[it], wsoff, 0));
+    };
+    auto store_A = [&]() {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int u = tid + it * 256;
+            if (u < A_UNITS) split_store(ldsA + (u >> 2) * PX + (u & 3) * 2, ra[it]);
+        }
+    };
+    auto store_B = [&]() {
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int u = tid + it * 256;
+            if (u < B_UNITS) split_store(ldsB + (u >> 2) * PX + (u & 3) * 2, rb[it]);
+        }
+    };
+
+    int t = blockIdx.x;
+    if (t >= total_tiles) return;
+    setup_load(t);
+    load_A(0);
+    {
+        int nb0, i0, y00, x00;
+        decode(t, nb0, i0, y00, x00);
+        load_B(nb0, 0, 0);
+    }
+    for (;;) {
+        int nb, img, y0, x0;
+        decode(t, nb, img, y0, x0);
+        const int t_next = t + gridDim.x;
+        f32x16 acc[RPW][NT];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[r][tt][i] = 0.f;
+
+        for (int c0 = 0; c0 < Cin; c0 += CK) {
+            const bool last_chunk = c0 + CK >= Cin;
+#pragma unroll 1
+            for (int ky = 0; ky < 3; ++ky) {
+                __syncthreads();                 // every wave is done with the previous stage's operands
+                if (ky == 0) store_A();
+                store_B();
+                __syncthreads();
+                if (!(a.dbg & 4)) {
+                    if (ky == 0) {               // the halo tile of the next chunk / next tile has three stages to arrive
+                        if (!last_chunk) load_A(c0 + CK);
+                        else if (t_next < total_tiles) { setup_load(t_next); load_A(0); }
+                    }
+                    if (ky < 2) load_B(nb, c0, ky + 1);
+                    else if (!last_chunk) load_B(nb, c0 + CK, 0);
+                    else if (t_next < total_tiles) load_B(t_next % NB, 0, 0);
+                }
+                if (a.dbg & 2) continue;
+                uint4 fx[2][3][RPW], fw[2][3][NT];
+                auto read_tap = [&](int kx, uint4 (&X)[3][RPW], uint4 (&Wt)[3][NT]) {
+#pragma unroll
+                    for (int r = 0; r < RPW; ++r) {
+                        const float* p = ldsA + ((wave * RPW + r + ky) * (TW + 2) + m + kx) * PX + hi * 4;
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc) X[pc][r] = *reinterpret_cast<const uint4*>(p + pc * 8);
+                    }
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt) {
+                        const float* p = ldsB + (kx * BN + tt * 32 + m) * PX + hi * 4;
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc) Wt[pc][tt] = *reinterpret_cast<const uint4*>(p + pc * 8);
+                    }
+                };
+                read_tap(0, fx[0], fw[0]);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int cur = kx & 1;
+                    if (kx + 1 < 3) read_tap(kx + 1, fx[cur ^ 1], fw[cur ^ 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // six piece products, smallest first; the four accumulators of the wave rotate inside each product
+                    constexpr int WI[6] = {0, 1, 2, 0, 1, 0};
+                    constexpr int XI[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+                    for (int q = 0; q < 6; ++q)
+#pragma unroll
+                        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                            for (int tt = 0; tt < NT; ++tt)
+                                acc[r][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[cur][WI[q]][tt]),
+                                                                                     __builtin_bit_cast(bf16x8, fx[cur][XI[q]][r]), acc[r][tt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+
+        // ---- epilogue: identical to conv_igemm.hip's (lane (m, hi) owns pixel x0+m and channels 8q+4hi..+3 of each 32-block)
+        {
+            const int x = x0 + m;
+            const bool xok = x < a.W;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int y = y0 + wave * RPW + r;
+                if (y >= a.H || (a.dbg & 1) || !xok) continue;
+                const size_t pix = (size_t)(img * a.H + y) * a.W + x;
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) {
+                    const int nbase = nb * BN + tt * 32 + 4 * hi;
+                    float4 v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = make_float4(acc[r][tt][4 * q], acc[r][tt][4 * q + 1], acc[r][tt][4 * q + 2], acc[r][tt][4 * q + 3]);
+                    float* dst[4];
+                    if (a.epi == EPI_FWD) {
+                        float4 bs[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) bs[q] = *reinterpret_cast<const float4*>(a.bias + nbase + 8 * q);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            v[q].x += bs[q].x; v[q].y += bs[q].y; v[q].z += bs[q].z; v[q].w += bs[q].w;
+                            if (a.lrelu) {
+                                v[q].x = fmaxf(0.2f * v[q].x, v[q].x); v[q].y = fmaxf(0.2f * v[q].y, v[q].y);
+                                v[q].z = fmaxf(0.2f * v[q].z, v[q].z); v[q].w = fmaxf(0.2f * v[q].w, v[q].w);
+                            }
+                            dst[q] = static_cast<float*>(a.out0) + pix * a.Nout + nbase + 8 * q;
+                        }
+                    } else {
+                        float4 s[4];
+                        bool has[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int n = nbase + 8 * q;
+                            const bool lo = n < a.split;
+                            const int C = lo ? a.split : a.Nout - a.split;
+                            const size_t idx = pix * C + (lo ? n : n - a.split);
+                            dst[q] = static_cast<float*>(lo ? a.out0 : a.out1) + idx;
+                            const float* act = static_cast<const float*>(lo ? a.act0 : a.act1);
+                            has[q] = act != nullptr;
+                            s[q] = make_float4(1.f, 1.f, 1.f, 1.f);
+                            if (has[q]) s[q] = *reinterpret_cast<const float4*>(act + idx);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (has[q]) {
+                                v[q].x *= lrelu_slope(s[q].x); v[q].y *= lrelu_slope(s[q].y);
+                                v[q].z *= lrelu_slope(s[q].z); v[q].w *= lrelu_slope(s[q].w);
+                            }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(v[q].x), "+v"(v[q].y), "+v"(v[q].z), "+v"(v[q].w));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(dst[q]) = v[q];
+                }
+            }
+        }
+        if (t_next >= total_tiles) break;
+        t = t_next;
+    }
+}
+
+int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+template <int BN, int RPW>
+int launch_x3(ConvArgs a, hipStream_t st) {
+    constexpr int TH = 4 * RPW;
+    a.tiles_x = (a.W + TW - 1) / TW;
+    a.tiles_y = (a.H + TH - 1) / TH;
+    const size_t lds_bytes = (size_t)((TH + 2) * (TW + 2) + 3 * BN) * PX * sizeof(float);
+    const long long tiles = (long long)a.tiles_x * a.tiles_y * a.N * (a.Nout / BN);
+    if (tiles <= 0) return 0;
+    if (tiles > 0x7fffffffLL) return ELD_ENOTSUP;
+    auto kern = conv_x3_kernel<BN, RPW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    int per_cu = (int)((160 * 1024) / lds_bytes);
+    if (per_cu > 2) per_cu = 2;
+    if (per_cu < 1) per_cu = 1;
+    long long grid = (long long)num_cus() * per_cu;
+    if (grid > tiles) grid = tiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, st, a);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+// a: fp32 CONV_3X3 arguments already validated by launch_conv
+int launch_conv_x3(const ConvArgs& a, hipStream_t st) {
+    if ((size_t)a.H * a.W * a.C0 * 4 >= 0xFFFFFFF0ull) return ELD_ENOTSUP;
+    return a.Nout % 64 == 0 ? launch_x3<64, 2>(a, st) : launch_x3<32, 2>(a, st);
+}

@@ -486,6 +486,8 @@ extern "C" int eld_unet_backward_bf16(const float* dout, const float* params, fl
     return unet_backward_bf16(P, dout, params, grads, (float*)ws, as_stream(stream));
 }
 
+extern "C" int eld_conv_fp32_algo(int algo) { return conv_fp32_algo(algo); }
+
 extern "C" size_t eld_l1_workspace_bytes(void) { return l1_ws_floats() * sizeof(float); }
 
 extern "C" int eld_l1_loss(const float* out, const float* target, float* dout, float* loss, void* ws, size_t n, float grad_scale, void* stream) {

@@ -138,6 +138,13 @@ int eld_unet_backward(const float* dout, const float* params, float* grads, void
 
 /* mean |out-target| (nn.L1Loss, models/losses.py:32) and, if dout != NULL, its gradient times grad_scale.
  * ws: eld_l1_workspace_bytes() bytes.  loss: one device float. */
+/* How the fp32 3x3 convolutions of eld_unet_forward/backward and eld_conv3x3_* form their products:
+ *   0  v_mfma_f32_32x32x2_f32 (fp32 operands);
+ *   1  every fp32 operand cut exactly into three bf16 pieces, six v_mfma_f32_32x32x16_bf16 per k-block, fp32 accumulate
+ *      (same fp32-level accuracy, see csrc/conv_x3.hip).
+ * algo < 0 only queries.  Process-wide; returns the value in force before the call.  Initial value: env ELD_FP32_CONV. */
+int eld_conv_fp32_algo(int algo);
+
 size_t eld_l1_workspace_bytes(void);
 int eld_l1_loss(const float* out, const float* target, float* dout, float* loss, void* ws, size_t n, float grad_scale, void* stream);
 /* torch.optim.Adam step over a flat buffer (models/ELD_model.py:400-401,475); step counts from 1;

@@ -20,6 +20,14 @@ def lib(eld_lib):
     return eld_lib
 
 
+@pytest.fixture(params=[0, 1], ids=['fp32mfma', 'bf16x3'])
+def algo(request, lib):
+    """Run the test under both fp32 conv product schemes (include/eld_amd.h eld_conv_fp32_algo); same tolerance for both."""
+    prev = lib.eld_conv_fp32_algo(request.param)
+    yield request.param
+    lib.eld_conv_fp32_algo(prev)
+
+
 def nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 
@@ -51,7 +59,7 @@ CASES = [  # N, H, W, C0, C1, Cout
 
 @pytest.mark.parametrize('N,H,W,C0,C1,Cout', CASES)
 @pytest.mark.parametrize('act', [1, 0])
-def test_conv3x3_forward(lib, N, H, W, C0, C1, Cout, act):
+def test_conv3x3_forward(lib, N, H, W, C0, C1, Cout, act, algo):
     from eld_amd import _lib as L
     g = torch.Generator().manual_seed(H * W + C0 + Cout)
     x = torch.randn(N, C0 + C1, H, W, generator=g)
@@ -77,7 +85,7 @@ def test_conv3x3_forward(lib, N, H, W, C0, C1, Cout, act):
 
 @pytest.mark.parametrize('N,H,W,Cin,Cout,split', [(2, 20, 37, 32, 32, 32), (1, 16, 40, 64, 32, 32), (1, 9, 133, 128, 64, 64),
                                                      (1, 6, 18, 256, 512, 256), (1, 8, 32, 32, 64, 32)])
-def test_conv3x3_backward_data(lib, N, H, W, Cin, Cout, split):
+def test_conv3x3_backward_data(lib, N, H, W, Cin, Cout, split, algo):
     from eld_amd import _lib as L
     g = torch.Generator().manual_seed(7 + Cin)
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(9 * Cout)
@@ -217,7 +225,7 @@ def test_l1_and_adam(lib):
 
 
 # ------------------------------------------------------------------------------------------------ whole network
-def test_unet_forward_backward_vs_reference_golden(lib, golden_dir):
+def test_unet_forward_backward_vs_reference_golden(lib, golden_dir, algo):
     """Same seeded init as the reference module, same input: output within 1e-5, L1 gradients of all 46 tensors."""
     from eld_amd.unet import UNetSeeInDark
     d = np.load(os.path.join(golden_dir, 'unet.npz'))
@@ -247,7 +255,7 @@ def test_unet_forward_backward_vs_reference_golden(lib, golden_dir):
 
 
 @pytest.mark.parametrize('shape', [(1, 4, 16, 16), (3, 4, 48, 80), (1, 4, 64, 144)])
-def test_unet_all_gradients_vs_oracle(lib, shape):
+def test_unet_all_gradients_vs_oracle(lib, shape, algo):
     from eld_amd.unet import UNetSeeInDark
     torch.manual_seed(7)
     net = UNetSeeInDark(4, 4)
@@ -346,3 +354,33 @@ def test_unet_bf16_training_gradients(lib, shape):
     net.zero_grad()
     out32 = net(x.cuda())
     assert float((out32.detach().cpu().double() - out_ref).abs().max()) <= 1e-5
+
+
+def test_bf16x3_is_as_accurate_as_fp32_mfma(lib):
+    """Long contraction (K = 9*512), O(1) data: the error of the split-bf16 scheme against fp64 must not exceed the
+    fp32-MFMA kernel's by more than a rounding's worth (csrc/conv_x3.hip header)."""
+    from eld_amd import _lib as L
+    N, H, W, Cin, Cout = 1, 24, 64, 512, 64
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(9 * Cin)
+    b = torch.zeros(Cout)
+    ref = F.conv2d(x.double(), w.double(), None, padding=1)
+    xd, wd, bd = nhwc(x).cuda(), w.cuda(), b.cuda()
+    ws = ws_for(lib, N, H, W, Cin, Cout)
+    errs = []
+    prev = lib.eld_conv_fp32_algo(-1)
+    try:
+        for a in (0, 1):
+            lib.eld_conv_fp32_algo(a)
+            out = torch.empty(N, H, W, Cout, device='cuda')
+            L.check(lib.eld_conv3x3_forward(L.dptr(xd), Cin, None, 0, L.dptr(wd), L.dptr(bd), L.dptr(out), N, H, W, Cout, 0,
+                                            L.dptr(ws), ws.numel(), L.cur_stream()))
+            torch.cuda.synchronize()
+            e = (nchw(out).cpu().double() - ref).abs()
+            errs.append((float(e.max()), float((e ** 2).mean().sqrt())))
+    finally:
+        lib.eld_conv_fp32_algo(prev)
+    (m0, r0), (m1, r1) = errs
+    assert m1 < 3e-5 and r1 < 2e-6, errs          # O(1) outputs up to |4|, K = 4608
+    assert r1 <= 1.5 * r0 + 1e-8 and m1 <= 2.0 * m0 + 1e-8, errs
