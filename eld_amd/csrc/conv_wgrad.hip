@@ -28,11 +28,21 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // v_mfma_f32_32x32x16_bf16 with K = 16 consecutive pixels of a row: lane (channel = lane&31, kb = lane>>5) gathers its
 // 8 pixel values with 16-bit LDS reads (a half-wave reads 32 consecutive channels of one pixel: conflict-free).  The
 // G fragment of a k-step is shared by all taps, so a k-step costs 8 + 8*TAPS ds_read_u16 for TAPS MFMAs.
-template <typename T, int MODE, int WCO, int TH, bool BFM>
+//
+// ALG_X3 (fp32 inputs): as conv_x3.hip -- every fp32 value is cut exactly into three bf16 pieces while it is staged
+// (three [pixel][channel] bf16 planes per tile in LDS) and each 16-pixel k-step accumulates the six piece products
+// g1x1 + g1x2 + g2x1 + g1x3 + g2x2 + g3x1 on v_mfma_f32_32x32x16_bf16: fp32-level accuracy at 6 x 32 matrix-pipe
+// cycles per 16 k instead of 8 x 64.  The three horizontal taps of a kernel row share one 10-pixel window per piece
+// (10 ds_read_u16 + 4 v_alignbit instead of 24 reads).
+enum { ALG_F32 = 0, ALG_BFM = 1, ALG_X3 = 2 };
+
+template <typename T, int MODE, int WCO, int TH, int ALG>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
+    constexpr bool BFM = ALG == ALG_BFM, X3 = ALG == ALG_X3;
+    static_assert(!X3 || (sizeof(T) == 4 && MODE == CONV_3X3), "x3: fp32 3x3 only");
     constexpr int ES = sizeof(T);            // element size of g / x in HBM (float or bf16); accumulation is fp32
     constexpr int EPU = 16 / ES;             // elements per 16-byte staging unit
-    constexpr int LES = BFM ? 2 : 4;         // element size in LDS
+    constexpr int LES = X3 ? 6 : (BFM ? 2 : 4);   // bytes per element in LDS (x3: three bf16 planes)
     constexpr int TAPS = MODE == CONV_3X3 ? 9 : 4;
     constexpr int WPIX = 4 / WCO;
     constexpr int COB = 32 * WCO;
@@ -115,8 +125,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int it = 0; it < X_IT; ++it) rx[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)ox[it], cs * ES, 0));
     };
-    auto put = [&](float* dst, int u, const float4& raw) {            // LDS rows are unit-linear: [lp][COB] and [hp][JB]
-        if constexpr (ES == 4 || BFM) {
+    constexpr int GPL = TPIX * COB, XPL = X_PIX * JB;                 // x3: elements per piece plane
+    auto put = [&](float* dst, int u, const float4& raw, int plane_elems) {            // LDS rows are unit-linear: [lp][COB] and [hp][JB]
+        if constexpr (X3) {
+            bf16_t* d = reinterpret_cast<bf16_t*>(dst) + u * 4;
+            const unsigned x0 = __float_as_uint(raw.x), x1 = __float_as_uint(raw.y), x2 = __float_as_uint(raw.z), x3 = __float_as_uint(raw.w);
+            const float r0 = raw.x - __uint_as_float(x0 & 0xFFFF0000u), r1 = raw.y - __uint_as_float(x1 & 0xFFFF0000u);
+            const float r2 = raw.z - __uint_as_float(x2 & 0xFFFF0000u), r3 = raw.w - __uint_as_float(x3 & 0xFFFF0000u);
+            const unsigned y0 = __float_as_uint(r0), y1 = __float_as_uint(r1), y2 = __float_as_uint(r2), y3 = __float_as_uint(r3);
+            const unsigned z0 = __float_as_uint(r0 - __uint_as_float(y0 & 0xFFFF0000u)), z1 = __float_as_uint(r1 - __uint_as_float(y1 & 0xFFFF0000u));
+            const unsigned z2 = __float_as_uint(r2 - __uint_as_float(y2 & 0xFFFF0000u)), z3 = __float_as_uint(r3 - __uint_as_float(y3 & 0xFFFF0000u));
+            auto hp = [](unsigned lo, unsigned hi_) { return __builtin_amdgcn_perm(hi_, lo, 0x07060302u); };
+            *reinterpret_cast<uint2*>(d) = make_uint2(hp(x0, x1), hp(x2, x3));
+            *reinterpret_cast<uint2*>(d + plane_elems) = make_uint2(hp(y0, y1), hp(y2, y3));
+            *reinterpret_cast<uint2*>(d + 2 * plane_elems) = make_uint2(hp(z0, z1), hp(z2, z3));
+        } else if constexpr (ES == 4 || BFM) {
             *reinterpret_cast<float4*>(dst + u * 4) = raw;            // 16 bytes as loaded
         } else {                                                      // 8 bf16 -> 8 fp32
             const uint4 q = __builtin_bit_cast(uint4, raw);
@@ -128,12 +151,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int it = 0; it < G_IT; ++it) {
             const int u = tid + it * 256;
-            if (u < G_UNITS) put(ldsG, u, rg[it]);
+            if (u < G_UNITS) put(ldsG, u, rg[it], GPL);
         }
 #pragma unroll
         for (int it = 0; it < X_IT; ++it) {
             const int u = tid + it * 256;
-            if (u < X_UNITS) put(ldsX, u, rx[it]);
+            if (u < X_UNITS) put(ldsX, u, rx[it], XPL);
         }
     };
 
@@ -150,7 +173,50 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
         store_tile();
         __syncthreads();
         if (tile + a.psplit < ntiles) load_tile(tile + a.psplit);
-        if constexpr (!BFM) {
+        if constexpr (X3) {
+        constexpr int KSB = PW / 16;
+        const int lq0 = wpix * PW + 8 * hi;                         // first pixel of this lane's k-half
+        const int pyq = lq0 / TW, pxq = lq0 - pyq * TW;
+        const bf16_t* gq = reinterpret_cast<const bf16_t*>(ldsG) + lq0 * COB + wco * 32 + m;
+        const bf16_t* xq = reinterpret_cast<const bf16_t*>(ldsX) + (pyq * (TW + 2) + pxq) * JB + m;
+        auto pair = [](const bf16_t* p, int stride) { return (unsigned)p[0] | ((unsigned)p[stride] << 16); };
+#pragma unroll
+        for (int ks = 0; ks < KSB; ++ks) {
+            const int lrel = ks * 16;
+            const int dy0 = lrel / TW, dxp = lrel - dy0 * TW;
+            uint4 ga[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                const bf16_t* p = gq + pc * GPL + lrel * COB;
+                ga[pc] = make_uint4(pair(p, COB), pair(p + 2 * COB, COB), pair(p + 4 * COB, COB), pair(p + 6 * COB, COB));
+                if (a.bpart) {
+                    bsum += __uint_as_float(ga[pc].x << 16) + __uint_as_float(ga[pc].x & 0xFFFF0000u) + __uint_as_float(ga[pc].y << 16) + __uint_as_float(ga[pc].y & 0xFFFF0000u)
+                          + __uint_as_float(ga[pc].z << 16) + __uint_as_float(ga[pc].z & 0xFFFF0000u) + __uint_as_float(ga[pc].w << 16) + __uint_as_float(ga[pc].w & 0xFFFF0000u);
+                }
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                uint4 xb[3][3];                  // [kx][piece]
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
+                    const bf16_t* p = xq + pc * XPL + ((dy0 + ky) * (TW + 2) + dxp) * JB;
+                    const unsigned w0 = pair(p, JB), w1 = pair(p + 2 * JB, JB), w2 = pair(p + 4 * JB, JB), w3 = pair(p + 6 * JB, JB), w4 = pair(p + 8 * JB, JB);
+                    xb[0][pc] = make_uint4(w0, w1, w2, w3);
+                    xb[1][pc] = make_uint4(__builtin_amdgcn_alignbit(w1, w0, 16), __builtin_amdgcn_alignbit(w2, w1, 16),
+                                           __builtin_amdgcn_alignbit(w3, w2, 16), __builtin_amdgcn_alignbit(w4, w3, 16));
+                    xb[2][pc] = make_uint4(w1, w2, w3, w4);
+                }
+                constexpr int GI[6] = {0, 1, 2, 0, 1, 0};
+                constexpr int XI[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+                        acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ga[GI[q]]), __builtin_bit_cast(bf16x8, xb[kx][XI[q]]),
+                                                                                   acc[ky * 3 + kx], 0, 0, 0);
+            }
+        }
+        } else if constexpr (!BFM) {
         // ---- K loop, fully unrolled; operands of step s+1 are read from LDS under step s's MFMAs -------------
         float fa[2], fb[2][TAPS];
         auto read_step = [&](int s_, float& A, float (&B)[TAPS]) {
@@ -245,18 +311,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     }
 }
 
-template <typename T, int MODE, int WCO, int TH, bool BFM = false>
+template <typename T, int MODE, int WCO, int TH, int ALG = ALG_F32>
 static int launch_w(WgradArgs a, hipStream_t st) {
     constexpr int COB = 32 * WCO;
     constexpr int X_PIX = MODE == CONV_3X3 ? (TH + 2) * (TW + 2) : 4 * TH * TW;
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + TH - 1) / TH;
-    size_t lds_bytes = (size_t)(TH * TW * COB + X_PIX * JB) * (BFM ? 2 : 4);
+    size_t lds_bytes = (size_t)(TH * TW * COB + X_PIX * JB) * (ALG == ALG_X3 ? 6 : (ALG == ALG_BFM ? 2 : 4));
     const size_t red_bytes = (size_t)4 * 16 * 64 * sizeof(float);
     if (lds_bytes < red_bytes) lds_bytes = red_bytes;
     const long long blocks = (long long)(a.CA / COB) * (a.CBp / JB) * a.psplit;
     if (blocks <= 0) return 0;
-    auto kern = wgrad_kernel<T, MODE, WCO, TH, BFM>;
+    auto kern = wgrad_kernel<T, MODE, WCO, TH, ALG>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -277,14 +343,15 @@ int launch_wgrad(const WgradArgs& a, int mode, hipStream_t st) {
         static int mma = -1;                  // ELD_WGRAD_BF16_MMA=0 falls back to fp32-MFMA accumulation of the widened operands
         if (mma < 0) { const char* e = getenv("ELD_WGRAD_BF16_MMA"); mma = e ? atoi(e) : 1; }
         if (mma) {
-            if (mode == CONV_3X3) return c64 ? launch_w<bf16_t, CONV_3X3, 2, 4, true>(a, st) : launch_w<bf16_t, CONV_3X3, 1, 4, true>(a, st);
-            if (mode == CONV_GATHER2X2) return c64 ? launch_w<bf16_t, CONV_GATHER2X2, 2, 2, true>(a, st) : launch_w<bf16_t, CONV_GATHER2X2, 1, 2, true>(a, st);
+            if (mode == CONV_3X3) return c64 ? launch_w<bf16_t, CONV_3X3, 2, 4, ALG_BFM>(a, st) : launch_w<bf16_t, CONV_3X3, 1, 4, ALG_BFM>(a, st);
+            if (mode == CONV_GATHER2X2) return c64 ? launch_w<bf16_t, CONV_GATHER2X2, 2, 2, ALG_BFM>(a, st) : launch_w<bf16_t, CONV_GATHER2X2, 1, 2, ALG_BFM>(a, st);
             return ELD_EINVAL;
         }
         if (mode == CONV_3X3) return c64 ? launch_w<bf16_t, CONV_3X3, 2, 4>(a, st) : launch_w<bf16_t, CONV_3X3, 1, 4>(a, st);
         if (mode == CONV_GATHER2X2) return c64 ? launch_w<bf16_t, CONV_GATHER2X2, 2, 2>(a, st) : launch_w<bf16_t, CONV_GATHER2X2, 1, 2>(a, st);
         return ELD_EINVAL;
     }
+    if (mode == CONV_3X3 && conv_fp32_algo(-1) == 1) return c64 ? launch_w<float, CONV_3X3, 2, 2, ALG_X3>(a, st) : launch_w<float, CONV_3X3, 1, 2, ALG_X3>(a, st);
     if (mode == CONV_3X3) return c64 ? launch_w<float, CONV_3X3, 2, 4>(a, st) : launch_w<float, CONV_3X3, 1, 4>(a, st);
     if (mode == CONV_GATHER2X2) return c64 ? launch_w<float, CONV_GATHER2X2, 2, 2>(a, st) : launch_w<float, CONV_GATHER2X2, 1, 2>(a, st);
     return ELD_EINVAL;

@@ -108,7 +108,7 @@ def test_conv3x3_backward_data(lib, N, H, W, Cin, Cout, split, algo):
 
 
 @pytest.mark.parametrize('N,H,W,C0,C1,Cout', CASES + [(2, 64, 96, 32, 0, 32), (1, 21, 70, 16, 0, 32)])
-def test_conv3x3_backward_weight(lib, N, H, W, C0, C1, Cout):
+def test_conv3x3_backward_weight(lib, N, H, W, C0, C1, Cout, algo):
     from eld_amd import _lib as L
     g = torch.Generator().manual_seed(11 + H)
     x = torch.randn(N, C0 + C1, H, W, generator=g)
