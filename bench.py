@@ -29,6 +29,7 @@ import torch                # noqa: E402
 H_FULL, W_FULL = 1424, 2128
 FLOP_FWD_PER_PIX = 92288.0          # 2*MAC of the U-Net forward per raw pixel
 FLOP_STEP_PER_PIX = 276300.0        # forward + backward-data + backward-weight (no bwd-data for conv1_1)
+PEAK_BF16_MFMA_TF = 2500.0           # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16 dense peak
 PEAK_F32_MFMA_TF = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0
 
@@ -198,9 +199,15 @@ def main():
         full_frame = (Hh, Ww) == (H_FULL, W_FULL)
         flop_step = FLOP_STEP_PER_PIX * B * 4.0 * Hh * Ww
         ach = flop_step / ((t_f + t_b) * 1e-3) / 1e12
-        res['roofline'] = {'bound': 'mfma', 'kernel': 'U-Net convolution launches of one step (conv_igemm_kernel fwd/bwd-data + wgrad_kernel), '
-                           'timed as eld_unet_forward + eld_unet_backward', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TF if args.precision == 'fp32' else 2500.0,
-                           'unit': 'TFLOP/s', 'frac': round(ach / (PEAK_F32_MFMA_TF if args.precision == 'fp32' else 2500.0), 4),
+        # fp32 step: with eld_conv_fp32_algo = 1 every fp32 product is six bf16 MFMA products (csrc/conv_x3.hip), so the pipe
+        # that bounds the kernels is the bf16 MFMA and its fp32-equivalent peak is 2500 / 6; algo 0 runs on the fp32 MFMA.
+        x3 = args.precision == 'fp32' and eld_amd.load_library().eld_conv_fp32_algo(-1) == 1
+        peak = 2500.0 if args.precision == 'bf16' else (PEAK_BF16_MFMA_TF / 6.0 if x3 else PEAK_F32_MFMA_TF)
+        res['roofline'] = {'bound': 'mfma', 'kernel': 'U-Net convolution launches of one step (%s), timed as eld_unet_forward + eld_unet_backward' % (
+                               'conv_x3_kernel fwd/bwd-data + wgrad_kernel<ALG_X3>: fp32 operands as 3 bf16 pieces, 6 x v_mfma_f32_32x32x16_bf16 per k-block'
+                               if x3 else 'conv_igemm_kernel fwd/bwd-data + wgrad_kernel'),
+                           'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                           'peak_note': ('bf16 dense MFMA peak 2500 TFLOP/s / 6 piece products per fp32 product' if x3 else 'dense MFMA peak of the dtype'),
                            'traffic': (round(traffic['unet_conv_bytes_per_pass'] * B) if traffic and full_frame and args.precision == 'fp32' and 'unet_conv_bytes_per_pass' in traffic else None),
                            'fwd_ms': round(t_f, 3), 'bwd_ms': round(t_b, 3),
                            'fwd_tflops': round(FLOP_FWD_PER_PIX * B * 4.0 * Hh * Ww / (t_f * 1e-3) / 1e12, 2)}
