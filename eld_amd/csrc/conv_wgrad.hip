@@ -23,6 +23,7 @@
 #define JB 32     // j (shifted-operand channel) tile
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 // BFM = true (bf16 inputs only): the tiles stay bf16 in LDS, untransposed [pixel][channel], and the contraction runs on
 // v_mfma_f32_32x32x16_bf16 with K = 16 consecutive pixels of a row: lane (channel = lane&31, kb = lane>>5) gathers its
@@ -126,9 +127,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
         for (int it = 0; it < X_IT; ++it) rx[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)ox[it], cs * ES, 0));
     };
     constexpr int GPL = TPIX * COB, XPL = X_PIX * JB;                 // x3: elements per piece plane
-    auto put = [&](float* dst, int u, const float4& raw, int plane_elems) {            // LDS rows are unit-linear: [lp][COB] and [hp][JB]
+    auto put = [&](float* dst, int u, const float4& raw, int plane_elems, int e0) {      // e0: element index of the unit inside a bf16 plane            // LDS rows are unit-linear: [lp][COB] and [hp][JB]
         if constexpr (X3) {
-            bf16_t* d = reinterpret_cast<bf16_t*>(dst) + u * 4;
+            bf16_t* d = reinterpret_cast<bf16_t*>(dst) + e0;
             const unsigned x0 = __float_as_uint(raw.x), x1 = __float_as_uint(raw.y), x2 = __float_as_uint(raw.z), x3 = __float_as_uint(raw.w);
             const float r0 = raw.x - __uint_as_float(x0 & 0xFFFF0000u), r1 = raw.y - __uint_as_float(x1 & 0xFFFF0000u);
             const float r2 = raw.z - __uint_as_float(x2 & 0xFFFF0000u), r3 = raw.w - __uint_as_float(x3 & 0xFFFF0000u);
@@ -139,7 +140,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
             *reinterpret_cast<uint2*>(d) = make_uint2(hp(x0, x1), hp(x2, x3));
             *reinterpret_cast<uint2*>(d + plane_elems) = make_uint2(hp(y0, y1), hp(y2, y3));
             *reinterpret_cast<uint2*>(d + 2 * plane_elems) = make_uint2(hp(z0, z1), hp(z2, z3));
-        } else if constexpr (ES == 4 || BFM) {
+        } else if constexpr (BFM) {
+            *reinterpret_cast<float4*>(reinterpret_cast<bf16_t*>(dst) + e0) = raw;      // 8 bf16 as loaded
+        } else if constexpr (ES == 4) {
             *reinterpret_cast<float4*>(dst + u * 4) = raw;            // 16 bytes as loaded
         } else {                                                      // 8 bf16 -> 8 fp32
             const uint4 q = __builtin_bit_cast(uint4, raw);
@@ -151,12 +154,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int it = 0; it < G_IT; ++it) {
             const int u = tid + it * 256;
-            if (u < G_UNITS) put(ldsG, u, rg[it], GPL);
+            // bf16 planes of G are [32-channel block][pixel][32]: 64-byte rows, the layout ds_read_b64_tr_b16 reads conflict-free
+            const int lp = u / (COB / EPU), part = u - lp * (COB / EPU);
+            const int c = part * EPU;
+            if (u < G_UNITS) put(ldsG, u, rg[it], GPL, ((c >> 5) * TPIX + lp) * 32 + (c & 31));
         }
 #pragma unroll
         for (int it = 0; it < X_IT; ++it) {
             const int u = tid + it * 256;
-            if (u < X_UNITS) put(ldsX, u, rx[it], XPL);
+            if (u < X_UNITS) put(ldsX, u, rx[it], XPL, u * EPU);
         }
     };
 
@@ -173,47 +179,62 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
         store_tile();
         __syncthreads();
         if (tile + a.psplit < ntiles) load_tile(tile + a.psplit);
-        if constexpr (X3) {
+        if constexpr (X3 || BFM) {
+        // ---- bf16 MFMA, K = 16 consecutive pixels of a row per k-step.  Operands come straight out of the untransposed
+        //      [pixel][32 channels] bf16 planes with ds_read_b64_tr_b16: a 16-lane group reads a [4 pixels][16 channels]
+        //      block (lane i supplies the 8 bytes at pixel i/4, channels 4(i%4)..+3) and lane i receives the 4 pixel values
+        //      of channel i -- two reads make one 8-k MFMA operand, no 16-bit gathers, no packing.  Shifted taps are just
+        //      other immediate offsets (rows are 64 bytes, any pixel offset keeps the 8-byte alignment).
+        constexpr int NPC = X3 ? 3 : 1;
         constexpr int KSB = PW / 16;
-        const int lq0 = wpix * PW + 8 * hi;                         // first pixel of this lane's k-half
+        const int gi = lane & 15, gg = lane >> 4;                   // lane inside its 16-lane group, group: channels 16(gg&1).., k-half gg>>1 (= hi)
+        const int lq0 = wpix * PW + 8 * hi + (gi >> 2);             // pixel row this lane ADDRESSES in k-step 0 (first 4-pixel block)
         const int pyq = lq0 / TW, pxq = lq0 - pyq * TW;
-        const bf16_t* gq = reinterpret_cast<const bf16_t*>(ldsG) + lq0 * COB + wco * 32 + m;
-        const bf16_t* xq = reinterpret_cast<const bf16_t*>(ldsX) + (pyq * (TW + 2) + pxq) * JB + m;
-        auto pair = [](const bf16_t* p, int stride) { return (unsigned)p[0] | ((unsigned)p[stride] << 16); };
+        const bf16_t* gq = reinterpret_cast<const bf16_t*>(ldsG) + (wco * TPIX + lq0) * 32 + (gg & 1) * 16 + (gi & 3) * 4;
+        const bf16_t* xq = reinterpret_cast<const bf16_t*>(ldsX) + (MODE == CONV_3X3 ? (pyq * (TW + 2) + pxq) : lq0) * JB + (gg & 1) * 16 + (gi & 3) * 4;
+        auto tr8 = [](const bf16_t* p0) {                           // pixels [0,4) and [4,8) of the lane's k-half -> one operand
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+            const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 4 * 32));
+            return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+        };
 #pragma unroll
         for (int ks = 0; ks < KSB; ++ks) {
             const int lrel = ks * 16;
             const int dy0 = lrel / TW, dxp = lrel - dy0 * TW;
-            uint4 ga[3];
+            bf16x8 ga[NPC];
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) {
-                const bf16_t* p = gq + pc * GPL + lrel * COB;
-                ga[pc] = make_uint4(pair(p, COB), pair(p + 2 * COB, COB), pair(p + 4 * COB, COB), pair(p + 6 * COB, COB));
+            for (int pc = 0; pc < NPC; ++pc) {
+                ga[pc] = tr8(gq + pc * GPL + lrel * 32);
                 if (a.bpart) {
-                    bsum += __uint_as_float(ga[pc].x << 16) + __uint_as_float(ga[pc].x & 0xFFFF0000u) + __uint_as_float(ga[pc].y << 16) + __uint_as_float(ga[pc].y & 0xFFFF0000u)
-                          + __uint_as_float(ga[pc].z << 16) + __uint_as_float(ga[pc].z & 0xFFFF0000u) + __uint_as_float(ga[pc].w << 16) + __uint_as_float(ga[pc].w & 0xFFFF0000u);
+                    const uint4 q = __builtin_bit_cast(uint4, ga[pc]);
+                    bsum += __uint_as_float(q.x << 16) + __uint_as_float(q.x & 0xFFFF0000u) + __uint_as_float(q.y << 16) + __uint_as_float(q.y & 0xFFFF0000u)
+                          + __uint_as_float(q.z << 16) + __uint_as_float(q.z & 0xFFFF0000u) + __uint_as_float(q.w << 16) + __uint_as_float(q.w & 0xFFFF0000u);
                 }
             }
+            constexpr int TROW = MODE == CONV_3X3 ? 3 : TAPS;       // taps handled together (a kernel row / all four gather taps)
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                uint4 xb[3][3];                  // [kx][piece]
+            for (int t0 = 0; t0 < TAPS; t0 += TROW) {
+                bf16x8 xb[TROW][NPC];
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc) {
-                    const bf16_t* p = xq + pc * XPL + ((dy0 + ky) * (TW + 2) + dxp) * JB;
-                    const unsigned w0 = pair(p, JB), w1 = pair(p + 2 * JB, JB), w2 = pair(p + 4 * JB, JB), w3 = pair(p + 6 * JB, JB), w4 = pair(p + 8 * JB, JB);
-                    xb[0][pc] = make_uint4(w0, w1, w2, w3);
-                    xb[1][pc] = make_uint4(__builtin_amdgcn_alignbit(w1, w0, 16), __builtin_amdgcn_alignbit(w2, w1, 16),
-                                           __builtin_amdgcn_alignbit(w3, w2, 16), __builtin_amdgcn_alignbit(w4, w3, 16));
-                    xb[2][pc] = make_uint4(w1, w2, w3, w4);
+                for (int tt = 0; tt < TROW; ++tt) {
+                    const int t = t0 + tt;
+                    const int xoff = MODE == CONV_3X3 ? ((dy0 + t / 3) * (TW + 2) + dxp + t % 3) : (t * TPIX + lrel);
+#pragma unroll
+                    for (int pc = 0; pc < NPC; ++pc) xb[tt][pc] = tr8(xq + pc * XPL + xoff * JB);
                 }
-                constexpr int GI[6] = {0, 1, 2, 0, 1, 0};
-                constexpr int XI[6] = {2, 1, 0, 1, 0, 0};
+                if constexpr (X3) {
+                    constexpr int GI[6] = {0, 1, 2, 0, 1, 0};
+                    constexpr int XI[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
-                for (int q = 0; q < 6; ++q)
+                    for (int q = 0; q < 6; ++q)
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx)
-                        acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ga[GI[q]]), __builtin_bit_cast(bf16x8, xb[kx][XI[q]]),
-                                                                                   acc[ky * 3 + kx], 0, 0, 0);
+                        for (int tt = 0; tt < TROW; ++tt)
+                            acc[t0 + tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[GI[q]], xb[tt][XI[q]], acc[t0 + tt], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int tt = 0; tt < TROW; ++tt) acc[t0 + tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], xb[tt][0], acc[t0 + tt], 0, 0, 0);
+                }
+                if constexpr (X3 && WCO == 2) __builtin_amdgcn_sched_barrier(0);      // keep the next row's reads below: 256-VGPR budget
             }
         }
         } else if constexpr (!BFM) {
@@ -237,37 +258,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur], fb[cur][t], acc[t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-        }
-        } else {
-        // ---- bf16 MFMA: k-steps of 16 consecutive pixels (PW is a multiple of 16 and a k-step never leaves its row) ----
-        constexpr int KSB = PW / 16;
-        const bf16_t* gq = reinterpret_cast<const bf16_t*>(ldsG) + (wpix * PW + 8 * hi) * COB + wco * 32 + m;
-        const int lq0 = wpix * PW + 8 * hi;                         // first pixel of this lane's k-half
-        const int pyq = lq0 / TW, pxq = lq0 - pyq * TW;
-        const bf16_t* xq = reinterpret_cast<const bf16_t*>(ldsX) + (MODE == CONV_3X3 ? (pyq * (TW + 2) + pxq) : lq0) * JB + m;
-        auto gather8 = [&](const bf16_t* p, int stride) {           // 8 pixel values of this lane's channel -> one MFMA operand
-            unsigned w0 = (unsigned)p[0] | ((unsigned)p[stride] << 16);
-            unsigned w1 = (unsigned)p[2 * stride] | ((unsigned)p[3 * stride] << 16);
-            unsigned w2 = (unsigned)p[4 * stride] | ((unsigned)p[5 * stride] << 16);
-            unsigned w3 = (unsigned)p[6 * stride] | ((unsigned)p[7 * stride] << 16);
-            return make_uint4(w0, w1, w2, w3);
-        };
-#pragma unroll
-        for (int ks = 0; ks < KSB; ++ks) {
-            // pixel offset of k-step ks inside the wave's slice: rows advance every TW/16 steps
-            const int lrel = ks * 16;
-            const int dy = lrel / TW, dxp = lrel - dy * TW;
-            const uint4 ga = gather8(gq + lrel * COB, COB);
-            if (a.bpart) {
-                bsum += __uint_as_float(ga.x << 16) + __uint_as_float(ga.x & 0xFFFF0000u) + __uint_as_float(ga.y << 16) + __uint_as_float(ga.y & 0xFFFF0000u)
-                      + __uint_as_float(ga.z << 16) + __uint_as_float(ga.z & 0xFFFF0000u) + __uint_as_float(ga.w << 16) + __uint_as_float(ga.w & 0xFFFF0000u);
-            }
-#pragma unroll
-            for (int t = 0; t < TAPS; ++t) {
-                const int xoff = MODE == CONV_3X3 ? ((dy + t / 3) * (TW + 2) + dxp + t % 3) : (t * TPIX + lrel);
-                const uint4 xb = gather8(xq + xoff * JB, JB);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ga), __builtin_bit_cast(bf16x8, xb), acc[t], 0, 0, 0);
-            }
         }
         }
     }
