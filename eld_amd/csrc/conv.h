@@ -62,6 +62,7 @@ int launch_conv(const ConvArgs& a, int mode, hipStream_t st);
 // set < 0 only queries.  Initial value from env ELD_FP32_CONV (mfma | x3).  Returns the value in force before the call.
 int conv_fp32_algo(int set);
 int launch_conv_x3(const ConvArgs& a, hipStream_t st);
+int launch_conv_x3_gemm(const ConvArgs& a, int mode, hipStream_t st);      // transposed-conv directions; ELD_ENOTSUP if not covered
 
 // dW-type reduction:  P[tap][i][j] = sum_pixels G[pixel][i] * X[pixel (+) tap][j]
 struct WgradArgs {

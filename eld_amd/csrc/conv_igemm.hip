@@ -386,5 +386,9 @@ int launch_conv(const ConvArgs& a_in, int mode, hipStream_t st) {
     if (a.epi == EPI_CONVT_FWD && (a.Cout_t % 4)) return ELD_EINVAL;
     if (a.dtype == DT_BF16) return launch_dt<bf16_t>(a, mode, st);
     if (mode == CONV_3X3 && a.epi != EPI_CONVT_FWD && conv_fp32_algo(-1) == 1) return launch_conv_x3(a, st);
+    if (mode != CONV_3X3 && conv_fp32_algo(-1) == 1) {
+        const int rc = launch_conv_x3_gemm(a, mode, st);
+        if (rc != ELD_ENOTSUP) return rc;
+    }
     return launch_dt<float>(a, mode, st);
 }

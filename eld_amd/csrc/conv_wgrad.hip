@@ -40,7 +40,7 @@ enum { ALG_F32 = 0, ALG_BFM = 1, ALG_X3 = 2 };
 template <typename T, int MODE, int WCO, int TH, int ALG>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     constexpr bool BFM = ALG == ALG_BFM, X3 = ALG == ALG_X3;
-    static_assert(!X3 || (sizeof(T) == 4 && MODE == CONV_3X3), "x3: fp32 3x3 only");
+    static_assert(!X3 || sizeof(T) == 4, "x3: fp32 inputs");
     constexpr int ES = sizeof(T);            // element size of g / x in HBM (float or bf16); accumulation is fp32
     constexpr int EPU = 16 / ES;             // elements per 16-byte staging unit
     constexpr int LES = X3 ? 6 : (BFM ? 2 : 4);   // bytes per element in LDS (x3: three bf16 planes)
@@ -343,6 +343,7 @@ int launch_wgrad(const WgradArgs& a, int mode, hipStream_t st) {
     }
     if (mode == CONV_3X3 && conv_fp32_algo(-1) == 1) return c64 ? launch_w<float, CONV_3X3, 2, 2, ALG_X3>(a, st) : launch_w<float, CONV_3X3, 1, 2, ALG_X3>(a, st);
     if (mode == CONV_3X3) return c64 ? launch_w<float, CONV_3X3, 2, 4>(a, st) : launch_w<float, CONV_3X3, 1, 4>(a, st);
+    if (mode == CONV_GATHER2X2 && conv_fp32_algo(-1) == 1) return c64 ? launch_w<float, CONV_GATHER2X2, 2, 2, ALG_X3>(a, st) : launch_w<float, CONV_GATHER2X2, 1, 2, ALG_X3>(a, st);
     if (mode == CONV_GATHER2X2) return c64 ? launch_w<float, CONV_GATHER2X2, 2, 2>(a, st) : launch_w<float, CONV_GATHER2X2, 1, 2>(a, st);
     return ELD_EINVAL;
 }

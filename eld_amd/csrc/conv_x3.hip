@@ -50,7 +50,7 @@ __device__ __forceinline__ void split_store(float* row, float4 v) {
     *reinterpret_cast<uint2*>(row + 16) = make_uint2(hi_pair(__float_as_uint(s0), __float_as_uint(s1)), hi_pair(__float_as_uint(s2), __float_as_uint(s3)));
 }
 
-template <int BN, int RPW>
+template <int BN, int RPW, bool DB>
 __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
     constexpr int CK = 16;
     constexpr int TH = 4 * RPW, NT = BN / 32, A_PIX = (TH + 2) * (TW + 2);
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
                     else if (t_next < total_tiles) load_B(t_next % NB, 0, 0);
                 }
                 if (a.dbg & 2) continue;
-                uint4 fx[2][3][RPW], fw[2][3][NT];
+                uint4 fx[DB ? 2 : 1][3][RPW], fw[DB ? 2 : 1][3][NT];
                 auto read_tap = [&](int kx, uint4 (&X)[3][RPW], uint4 (&Wt)[3][NT]) {
 #pragma unroll
                     for (int r = 0; r < RPW; ++r) {
@@ -187,24 +187,39 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
                         for (int pc = 0; pc < 3; ++pc) Wt[pc][tt] = *reinterpret_cast<const uint4*>(p + pc * 8);
                     }
                 };
-                read_tap(0, fx[0], fw[0]);
+                constexpr int WI[6] = {0, 1, 2, 0, 1, 0};
+                constexpr int XI[6] = {2, 1, 0, 1, 0, 0};
+                if constexpr (DB) {
+                    read_tap(0, fx[0], fw[0]);
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int cur = kx & 1;
-                    if (kx + 1 < 3) read_tap(kx + 1, fx[cur ^ 1], fw[cur ^ 1]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    // six piece products, smallest first; the four accumulators of the wave rotate inside each product
-                    constexpr int WI[6] = {0, 1, 2, 0, 1, 0};
-                    constexpr int XI[6] = {2, 1, 0, 1, 0, 0};
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int cur = kx & 1;
+                        if (kx + 1 < 3) read_tap(kx + 1, fx[cur ^ 1], fw[cur ^ 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        // six piece products, smallest first; the accumulators of the wave rotate inside each product
 #pragma unroll
-                    for (int q = 0; q < 6; ++q)
+                        for (int q = 0; q < 6; ++q)
 #pragma unroll
-                        for (int r = 0; r < RPW; ++r)
+                            for (int r = 0; r < RPW; ++r)
 #pragma unroll
-                            for (int tt = 0; tt < NT; ++tt)
-                                acc[r][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[cur][WI[q]][tt]),
-                                                                                     __builtin_bit_cast(bf16x8, fx[cur][XI[q]][r]), acc[r][tt], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
+                                for (int tt = 0; tt < NT; ++tt)
+                                    acc[r][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[cur][WI[q]][tt]),
+                                                                                         __builtin_bit_cast(bf16x8, fx[cur][XI[q]][r]), acc[r][tt], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {                         // register budget: one fragment set, the compiler interleaves reads and MFMAs
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        read_tap(kx, fx[0], fw[0]);
+#pragma unroll
+                        for (int q = 0; q < 6; ++q)
+#pragma unroll
+                            for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                                for (int tt = 0; tt < NT; ++tt)
+                                    acc[r][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[0][WI[q]][tt]),
+                                                                                         __builtin_bit_cast(bf16x8, fx[0][XI[q]][r]), acc[r][tt], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -272,6 +287,192 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
     }
 }
 
+// ---- transposed conv 2x2/s2 as a pixel GEMM on the same split-operand scheme -----------------------------------------------
+// MODE CONV_1X1 (forward): out[(2y+dy, 2x+dx)][co] = sum_c in[(y,x)][c] * Wp[(dy,dx,co)][c]     (N = 4*Cout, K = Cin)
+// MODE CONV_GATHER2X2 (backward-data): din[(y,x)][ci] = sum_{tap,c} dout[(2y+dy, 2x+dx)][c] * Wp[tap][ci][c]   (K = 4*Cout)
+// Tile = 8 rows x 32 pixels x 64 channels, K stage = 32 k-values (two 16-k sub-chunks; a stage never straddles a tap),
+// LDS = [sub][256 pixels][28 words] + [sub][64][28 words] = 71.7 KB -> two workgroups per CU.
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void conv_x3_gemm_kernel(const ConvArgs a) {
+    constexpr int BN = 64, RPW = 2, TH = 8, NT = 2, NS = 2;
+    constexpr int TPIX = TH * TW;
+    constexpr int A_WORDS = NS * TPIX * PX;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* ldsA = lds;
+    float* ldsB = lds + A_WORDS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 31, hi = lane >> 5;
+    const int NB = a.Nout / BN;
+    const int C0 = a.C0;                                           // channels of the source tensor
+    const int Ktot = MODE == CONV_1X1 ? C0 : 4 * C0;
+    const int Ws = MODE == CONV_GATHER2X2 ? 2 * a.W : a.W, Hs = MODE == CONV_GATHER2X2 ? 2 * a.H : a.H;
+    const int total_tiles = a.tiles_x * a.tiles_y * a.N * NB;
+
+    constexpr int A_UNITS = NS * TPIX * 4, B_UNITS = NS * BN * 4;
+    constexpr int A_IT = A_UNITS / 256, B_IT = B_UNITS / 256;
+    float4 ra[A_IT], rb[B_IT];
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    unsigned a_voff[A_IT], b_voff[B_IT];
+    int l_img = 0;
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (int)((size_t)(MODE == CONV_1X1 ? 1 : 4) * a.Nout * C0 * 4), 0x00020000);
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+        const int u = tid + it * 256;                              // (sub, n, part)
+        const int part = u & 3, n = (u >> 2) % BN, sub = u / (4 * BN);
+        b_voff[it] = (unsigned)(n * C0 * 4 + sub * 64 + part * 16);
+    }
+    auto decode = [&](int t, int& nb, int& img, int& y0, int& x0) {
+        nb = t % NB;
+        int r = t / NB;
+        const int tx = r % a.tiles_x;
+        r /= a.tiles_x;
+        const int ty = r % a.tiles_y;
+        img = r / a.tiles_y;
+        y0 = ty * TH; x0 = tx * TW;
+    };
+    auto setup_load = [&](int t) {
+        int nb, y0, x0;
+        decode(t, nb, l_img, y0, x0);
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int u = tid + it * 256;                          // (sub, pixel, part)
+            const int part = u & 3, lp = (u >> 2) % TPIX, sub = u / (4 * TPIX);
+            const int gy = y0 + lp / TW, gx = x0 + lp % TW;
+            const bool ok = gy < a.H && gx < a.W;
+            const unsigned pix = MODE == CONV_GATHER2X2 ? (unsigned)(2 * gy * Ws + 2 * gx) : (unsigned)(gy * Ws + gx);
+            a_voff[it] = ok ? pix * (unsigned)(C0 * 4) + (unsigned)(sub * 64 + part * 16) : OOB;
+        }
+    };
+    auto load_stage = [&](int nb, int k0) {
+        const int tap = MODE == CONV_GATHER2X2 ? k0 / C0 : 0;
+        const int cs = k0 - tap * C0;
+        const size_t img_bytes = (size_t)Hs * Ws * C0 * 4;
+        const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(static_cast<const char*>(a.in0) + (size_t)l_img * img_bytes), 0, (int)img_bytes, 0x00020000);
+        const int asoff = (((tap >> 1) * Ws + (tap & 1)) * C0 + cs) * 4;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it)
+            ra[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)a_voff[it], asoff, 0));
+        const int wsoff = ((tap * a.Nout + nb * BN) * C0 + cs) * 4;
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it)
+            rb[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)b_voff[it], wsoff, 0));
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int u = tid + it * 256;
+            split_store(ldsA + (u >> 2) * PX + (u & 3) * 2, ra[it]);          // (u >> 2) = sub * TPIX + pixel
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int u = tid + it * 256;
+            split_store(ldsB + (u >> 2) * PX + (u & 3) * 2, rb[it]);
+        }
+    };
+
+    int t = blockIdx.x;
+    if (t >= total_tiles) return;
+    setup_load(t);
+    load_stage(t % NB, 0);
+    for (;;) {
+        int nb, img, y0, x0;
+        decode(t, nb, img, y0, x0);
+        const int t_next = t + gridDim.x;
+        f32x16 acc[RPW][NT];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[r][tt][i] = 0.f;
+        for (int k0 = 0; k0 < Ktot; k0 += 16 * NS) {
+            __syncthreads();
+            store_stage();
+            __syncthreads();
+            if (k0 + 16 * NS < Ktot) load_stage(nb, k0 + 16 * NS);
+            else if (t_next < total_tiles) { setup_load(t_next); load_stage(t_next % NB, 0); }
+            constexpr int WI[6] = {0, 1, 2, 0, 1, 0};
+            constexpr int XI[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+            for (int sub = 0; sub < NS; ++sub) {
+                uint4 fx[3][RPW], fw[3][NT];
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) {
+                    const float* p = ldsA + (sub * TPIX + (wave * RPW + r) * TW + m) * PX + hi * 4;
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) fx[pc][r] = *reinterpret_cast<const uint4*>(p + pc * 8);
+                }
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) {
+                    const float* p = ldsB + (sub * BN + tt * 32 + m) * PX + hi * 4;
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) fw[pc][tt] = *reinterpret_cast<const uint4*>(p + pc * 8);
+                }
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+#pragma unroll
+                    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                        for (int tt = 0; tt < NT; ++tt)
+                            acc[r][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[WI[q]][tt]), __builtin_bit_cast(bf16x8, fx[XI[q]][r]),
+                                                                                 acc[r][tt], 0, 0, 0);
+            }
+        }
+        {   // epilogue: lane (m, hi) owns pixel x0+m and channels 8q+4hi..+3 of each 32-block (see conv_igemm.hip)
+            const int x = x0 + m;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int y = y0 + wave * RPW + r;
+                if (y >= a.H || x >= a.W) continue;
+                const size_t pix = (size_t)(img * a.H + y) * a.W + x;
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) {
+                    const int nbase = nb * BN + tt * 32 + 4 * hi;
+                    float4 v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = make_float4(acc[r][tt][4 * q], acc[r][tt][4 * q + 1], acc[r][tt][4 * q + 2], acc[r][tt][4 * q + 3]);
+                    float* dst[4];
+                    if (MODE == CONV_1X1) {
+                        float4 bs[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int n = nbase + 8 * q;
+                            const int tap = n / a.Cout_t, co = n - tap * a.Cout_t;
+                            bs[q] = *reinterpret_cast<const float4*>(a.bias + co);
+                            dst[q] = static_cast<float*>(a.out0) + ((size_t)(img * 2 * a.H + 2 * y + (tap >> 1)) * (2 * a.W) + 2 * x + (tap & 1)) * a.Cout_t + co;
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { v[q].x += bs[q].x; v[q].y += bs[q].y; v[q].z += bs[q].z; v[q].w += bs[q].w; }
+                    } else {
+                        float4 sl[4];
+                        const float* act = static_cast<const float*>(a.act0);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const size_t idx = pix * a.Nout + nbase + 8 * q;
+                            dst[q] = static_cast<float*>(a.out0) + idx;
+                            sl[q] = make_float4(1.f, 1.f, 1.f, 1.f);
+                            if (act) sl[q] = *reinterpret_cast<const float4*>(act + idx);
+                        }
+                        if (act) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                v[q].x *= lrelu_slope(sl[q].x); v[q].y *= lrelu_slope(sl[q].y);
+                                v[q].z *= lrelu_slope(sl[q].z); v[q].w *= lrelu_slope(sl[q].w);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(v[q].x), "+v"(v[q].y), "+v"(v[q].z), "+v"(v[q].w));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(dst[q]) = v[q];
+                }
+            }
+        }
+        if (t_next >= total_tiles) break;
+        t = t_next;
+    }
+}
+
 int num_cus() {
     static int n = 0;
     if (!n) {
@@ -283,7 +484,7 @@ int num_cus() {
     return n;
 }
 
-template <int BN, int RPW>
+template <int BN, int RPW, bool DB>
 int launch_x3(ConvArgs a, hipStream_t st) {
     constexpr int TH = 4 * RPW;
     a.tiles_x = (a.W + TW - 1) / TW;
@@ -292,7 +493,7 @@ int launch_x3(ConvArgs a, hipStream_t st) {
     const long long tiles = (long long)a.tiles_x * a.tiles_y * a.N * (a.Nout / BN);
     if (tiles <= 0) return 0;
     if (tiles > 0x7fffffffLL) return ELD_ENOTSUP;
-    auto kern = conv_x3_kernel<BN, RPW>;
+    auto kern = conv_x3_kernel<BN, RPW, DB>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -309,10 +510,42 @@ int launch_x3(ConvArgs a, hipStream_t st) {
     return 0;
 }
 
+template <int MODE>
+int launch_x3_gemm(ConvArgs a, hipStream_t st) {
+    a.tiles_x = (a.W + TW - 1) / TW;
+    a.tiles_y = (a.H + 7) / 8;
+    const size_t lds_bytes = (size_t)(2 * 256 + 2 * 64) * PX * sizeof(float);
+    const long long tiles = (long long)a.tiles_x * a.tiles_y * a.N * (a.Nout / 64);
+    if (tiles <= 0) return 0;
+    if (tiles > 0x7fffffffLL) return ELD_ENOTSUP;
+    auto kern = conv_x3_gemm_kernel<MODE>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    long long grid = (long long)num_cus() * 2;
+    if (grid > tiles) grid = tiles;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, st, a);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace
 
 // a: fp32 CONV_3X3 arguments already validated by launch_conv
 int launch_conv_x3(const ConvArgs& a, hipStream_t st) {
     if ((size_t)a.H * a.W * a.C0 * 4 >= 0xFFFFFFF0ull) return ELD_ENOTSUP;
-    return a.Nout % 64 == 0 ? launch_x3<64, 2>(a, st) : launch_x3<32, 2>(a, st);
+    return a.Nout % 64 == 0 ? launch_x3<64, 2, true>(a, st) : launch_x3<32, 4, false>(a, st);
+}
+
+// transposed-conv directions (CONV_1X1 + EPI_CONVT_FWD, CONV_GATHER2X2 + EPI_GRAD); returns ELD_ENOTSUP for shapes the GEMM
+// tiling does not cover (the caller then uses the fp32-MFMA kernel)
+int launch_conv_x3_gemm(const ConvArgs& a, int mode, hipStream_t st) {
+    const size_t src_img = (size_t)a.H * a.W * a.C0 * 4 * (mode == CONV_GATHER2X2 ? 4 : 1);
+    if (a.Nout % 64 || a.C0 % 32 || a.C1 != 0 || src_img >= 0xFFFFFFF0ull) return ELD_ENOTSUP;
+    if (mode == CONV_1X1 && a.epi == EPI_CONVT_FWD) return launch_x3_gemm<CONV_1X1>(a, st);
+    if (mode == CONV_GATHER2X2 && a.epi == EPI_GRAD && a.split == a.Nout) return launch_x3_gemm<CONV_GATHER2X2>(a, st);
+    return ELD_ENOTSUP;
 }

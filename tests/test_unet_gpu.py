@@ -133,7 +133,7 @@ def test_conv3x3_backward_weight(lib, N, H, W, C0, C1, Cout, algo):
 
 
 @pytest.mark.parametrize('N,H,W,Cin,Cout', [(2, 10, 19, 64, 32), (1, 5, 33, 512, 256), (1, 8, 8, 128, 64)])
-def test_conv_transpose2x2(lib, N, H, W, Cin, Cout):
+def test_conv_transpose2x2(lib, N, H, W, Cin, Cout, algo):
     from eld_amd import _lib as L
     g = torch.Generator().manual_seed(3 + Cin)
     x = torch.randn(N, Cin, H, W, generator=g)
