@@ -208,7 +208,7 @@ def main():
                                if x3 else 'conv_igemm_kernel fwd/bwd-data + wgrad_kernel'),
                            'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                            'peak_note': ('bf16 dense MFMA peak 2500 TFLOP/s / 6 piece products per fp32 product' if x3 else 'dense MFMA peak of the dtype'),
-                           'traffic': (round(traffic['unet_conv_bytes_per_pass'] * B) if traffic and full_frame and args.precision == 'fp32' and 'unet_conv_bytes_per_pass' in traffic else None),
+                           'traffic': (round(traffic['unet_conv_bytes_per_pass'] * B / traffic.get('frames_per_pass', 1)) if traffic and full_frame and args.precision == 'fp32' and 'unet_conv_bytes_per_pass' in traffic else None),
                            'fwd_ms': round(t_f, 3), 'bwd_ms': round(t_b, 3),
                            'fwd_tflops': round(FLOP_FWD_PER_PIX * B * 4.0 * Hh * Ww / (t_f * 1e-3) / 1e12, 2)}
         # sampler alone (HBM-bound: 8 B per raw pixel), batch of 8 resident images

@@ -242,7 +242,7 @@ int launch_head_bwd(const float* dout, const float* act, const float* w, float* 
 // ------------------------------------------------------------------------------------------------
 // column sums of an NHWC matrix [P][C] -> [C]  (bias gradient of the transposed convs)
 // ------------------------------------------------------------------------------------------------
-#define COLSUM_BLOCKS 256
+#define COLSUM_BLOCKS 2048
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ part, size_t P, int C) {
     // thread t handles channel (t % C4)*4.. of pixels t / C4 + k*(256/C4 * gridDim)
     const int C4 = C / 4;
@@ -250,7 +250,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     const int c4 = threadIdx.x % C4, pl = threadIdx.x / C4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (pl < ppb) {
-        for (size_t p = (size_t)blockIdx.x * ppb + pl; p < P; p += (size_t)gridDim.x * ppb) {
+        const size_t step = (size_t)gridDim.x * ppb;
+        size_t p = (size_t)blockIdx.x * ppb + pl;
+        for (; p + 3 * step < P; p += 4 * step) {            // four independent 16-byte loads in flight per lane
+            const float4 v0 = reinterpret_cast<const float4*>(x + p * C)[c4], v1 = reinterpret_cast<const float4*>(x + (p + step) * C)[c4];
+            const float4 v2 = reinterpret_cast<const float4*>(x + (p + 2 * step) * C)[c4], v3 = reinterpret_cast<const float4*>(x + (p + 3 * step) * C)[c4];
+            s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
+            s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
+        }
+        for (; p < P; p += step) {
             const float4 v = reinterpret_cast<const float4*>(x + p * C)[c4];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
@@ -638,7 +646,16 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
     const int c4 = threadIdx.x % C4, pl = threadIdx.x / C4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (pl < ppb) {
-        for (size_t p = (size_t)blockIdx.x * ppb + pl; p < P; p += (size_t)gridDim.x * ppb) {
+        const size_t step = (size_t)gridDim.x * ppb;
+        size_t p = (size_t)blockIdx.x * ppb + pl;
+        for (; p + 3 * step < P; p += 4 * step) {
+            const uint2 q0 = reinterpret_cast<const uint2*>(x + p * C)[c4], q1 = reinterpret_cast<const uint2*>(x + (p + step) * C)[c4];
+            const uint2 q2 = reinterpret_cast<const uint2*>(x + (p + 2 * step) * C)[c4], q3 = reinterpret_cast<const uint2*>(x + (p + 3 * step) * C)[c4];
+            const float4 v0 = unpack_bf4(q0), v1 = unpack_bf4(q1), v2 = unpack_bf4(q2), v3 = unpack_bf4(q3);
+            s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
+            s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
+        }
+        for (; p < P; p += step) {
             const float4 v = unpack_bf4(reinterpret_cast<const uint2*>(x + p * C)[c4]);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }

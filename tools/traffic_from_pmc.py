@@ -3,7 +3,7 @@
 profiles/traffic.json, which bench.py reports as roofline.traffic.
   bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024   -- FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE counts half of a
   wide (16 B/lane) coalesced read stream (MI355X_MICROARCH.md, HBM section), every read in these kernels is 16 B/lane.
-Usage: traffic_from_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
+Usage: traffic_from_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [frames per pass = bench.py --batch, default 8]"""
 import collections
 import csv
 import json
@@ -41,9 +41,10 @@ def main():
         b = sum(2.0 * f[k] * 1024.0 + w.get(k, 0.0) * 1024.0 for k in noise)
         out['sampler_bytes_per_pixel'] = b / px
     passes = sum(fc[k] for k in f if k.startswith('head_fwd_kernel'))
-    conv = [k for k in f if any(s in k for s in ('conv_igemm_kernel', 'wgrad_kernel', 'conv_first', 'wgrad_reduce'))]
+    conv = [k for k in f if any(s in k for s in ('conv_igemm_kernel', 'conv_x3', 'wgrad_kernel', 'conv_first', 'wgrad_reduce'))]
     if passes and conv:
         out['unet_passes'] = passes
+        out['frames_per_pass'] = int(sys.argv[4]) if len(sys.argv) > 4 else 8
         out['unet_conv_bytes_per_pass'] = sum(2.0 * f[k] * 1024.0 + w.get(k, 0.0) * 1024.0 for k in conv) / passes
     json.dump(out, open(sys.argv[3], 'w'), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != 'kernels'}, indent=1))
