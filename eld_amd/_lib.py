@@ -39,6 +39,7 @@ SIGNATURES = {
     'eld_unet_forward_bf16': (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
     'eld_unet_backward': (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
     'eld_unet_backward_bf16': (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
+    'eld_unet_backward_buckets': (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     'eld_conv_fp32_algo': (_i, [_i]),
     'eld_l1_workspace_bytes': (_sz, []),
     'eld_l1_loss': (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _f, _vp]),

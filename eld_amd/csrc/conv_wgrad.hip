@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
                     for (int tt = 0; tt < TROW; ++tt) acc[t0 + tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], xb[tt][0], acc[t0 + tt], 0, 0, 0);
                 }
-                if constexpr (X3 && WCO == 2) __builtin_amdgcn_sched_barrier(0);      // keep the next row's reads below: 256-VGPR budget
+                if constexpr (X3 && MODE == CONV_3X3) __builtin_amdgcn_sched_barrier(0);      // keep the next row's reads below: 256-VGPR budget
             }
         }
         } else if constexpr (!BFM) {

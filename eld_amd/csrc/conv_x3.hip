@@ -135,6 +135,15 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
 
     int t = blockIdx.x;
     if (t >= total_tiles) return;
+    // The two workgroups of a CU run the same (stage skeleton -> MFMA phase) cycle; started together they stay in lockstep
+    // (both stage, then both contend for the matrix pipe).  The second wave of workgroups starts half a period late so that
+    // one stages while the other feeds the pipe.
+    const int stag_mode = (a.dbg >> 16) & 3;
+    const bool late = stag_mode == 0 ? blockIdx.x >= (gridDim.x >> 1) : (stag_mode == 1 ? ((blockIdx.x >> 3) & 1) : (stag_mode == 2 ? (blockIdx.x & 1) : ((blockIdx.x >> 8) & 1)));
+    if (late) {
+        const int n = (a.dbg >> 8) & 0xFF;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+    }
     setup_load(t);
     load_A(0);
     {
@@ -159,8 +168,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
 #pragma unroll 1
             for (int ky = 0; ky < 3; ++ky) {
                 __syncthreads();                 // every wave is done with the previous stage's operands
-                if (ky == 0) store_A();
-                store_B();
+                if (ky == 0 && !(a.dbg & 16)) store_A();
+                if (!(a.dbg & 8)) store_B();
                 __syncthreads();
                 if (!(a.dbg & 4)) {
                     if (ky == 0) {               // the halo tile of the next chunk / next tile has three stages to arrive

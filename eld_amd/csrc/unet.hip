@@ -225,6 +225,25 @@ int pack_weights(const Plan& P, const float* params, float* ws, bool for_backwar
 
 #define RC(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
 
+// Gradient buckets for the data-parallel exchange: the backward produces parameter gradients in DESCENDING flat-buffer order
+// (head, decoder level 0 .. 3, encoder level 4 .. 0 -- the reverse of named_parameters()), so once layer i's weight/bias
+// gradients are enqueued every gradient at offset >= L[i].w_off is final.  done(i) records the events of all buckets that
+// start at or above that offset; the caller's communication stream waits on them and all-reduces bucket by bucket while the
+// rest of the backward runs.
+struct BucketMarks {
+    const int64_t* start = nullptr;     // ascending parameter offsets (floats)
+    void* const* event = nullptr;       // hipEvent_t per bucket
+    int n = 0, next = 0;                // buckets [next .. n) counted from the TOP are not recorded yet
+    int done(const Plan& P, int layer, hipStream_t st) {
+        while (n - 1 - next >= 0 && start[n - 1 - next] >= (int64_t)P.L[layer].w_off) {
+            hipError_t e = hipEventRecord((hipEvent_t)event[n - 1 - next], st);
+            if (e != hipSuccess) return (int)e;
+            ++next;
+        }
+        return 0;
+    }
+};
+
 int unet_forward(const Plan& P, const float* x, const float* prm, float* out, float* ws, hipStream_t st) {
     const int N = P.N;
     RC(pack_weights(P, prm, ws, false, st));
@@ -302,28 +321,32 @@ int unet_forward_bf16(const Plan& P, const float* x, const float* prm, float* ou
     return 0;
 }
 
-int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd, float* ws, hipStream_t st) {
+int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd, float* ws, hipStream_t st, BucketMarks& marks) {
     const int N = P.N;
     RC(pack_weights(P, prm, ws, true, st));
     float* gA = ws + P.gA; float* gB = ws + P.gB; float* part = ws + P.part;
     const LayerDef& Hd = P.L[L_HEAD];
     // head: g (pre-activation grad of conv9_2) -> gA
     RC(launch_head_bwd(dout, ws + P.db[0], prm + Hd.w_off, gA, grd + Hd.w_off, grd + Hd.b_off, part, N, P.H, P.W, P.out_ch, st));
+    RC(marks.done(P, L_HEAD, st));
     float* cur = gA; float* oth = gB;
     for (int l = 0; l <= 3; ++l) {            // decoder levels 0 (conv9) .. 3 (conv6)
         const int iu = L_UP3 + 3 * (3 - l);
         const int H = P.Hl[l], W = P.Wl[l], C = chan(l);
         // conv_2 of the level: input da[l]
         RC(conv_wgrad(cur, C, ws + P.da[l], C, nullptr, 0, C, grd + P.L[iu + 2].w_off, grd + P.L[iu + 2].b_off, part, N, H, W, st));
+        RC(marks.done(P, iu + 2, st));
         RC(conv_bwd_data(cur, ws + P.wp_bwd[iu + 2], oth, nullptr, C, ws + P.da[l], nullptr, N, H, W, C, C, st));
         { float* t = cur; cur = oth; oth = t; }
         // conv_1: input cat[up[l], eb[l]] -> d_up (raw) in oth, skip grad (raw) in skip[l]
         RC(conv_wgrad(cur, C, ws + P.up[l], C, ws + P.eb[l], C, 2 * C, grd + P.L[iu + 1].w_off, grd + P.L[iu + 1].b_off, part, N, H, W, st));
+        RC(marks.done(P, iu + 1, st));
         RC(conv_bwd_data(cur, ws + P.wp_bwd[iu + 1], oth, ws + P.skip[l], C, nullptr, nullptr, N, H, W, 2 * C, C, st));
         { float* t = cur; cur = oth; oth = t; }
         // transposed conv: input src (level l+1, 2C channels), output grad = cur (d_up)
         const float* src = l == 3 ? ws + P.eb[4] : ws + P.db[l + 1];
         RC(convt_wgrad(src, cur, grd + P.L[iu].w_off, grd + P.L[iu].b_off, part, N, P.Hl[l + 1], P.Wl[l + 1], 2 * C, C, st));
+        RC(marks.done(P, iu, st));
         RC(convt_bwd_data(cur, ws + P.wp_bwd[iu], src, oth, N, P.Hl[l + 1], P.Wl[l + 1], 2 * C, C, st));
         { float* t = cur; cur = oth; oth = t; }
     }
@@ -332,6 +355,7 @@ int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd
         const int H = P.Hl[l], W = P.Wl[l], C = chan(l);
         const int ia = 2 * l, ib = 2 * l + 1;
         RC(conv_wgrad(cur, C, ws + P.ea[l], C, nullptr, 0, C, grd + P.L[ib].w_off, grd + P.L[ib].b_off, part, N, H, W, st));
+        RC(marks.done(P, ib, st));
         RC(conv_bwd_data(cur, ws + P.wp_bwd[ib], oth, nullptr, C, ws + P.ea[l], nullptr, N, H, W, C, C, st));
         { float* t = cur; cur = oth; oth = t; }
         if (l == 0) {
@@ -339,10 +363,12 @@ int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd
                 RC(launch_conv_first_wgrad(cur, ws + P.x16, grd + P.L[ia].w_off, grd + P.L[ia].b_off, part, N, P.in_ch, H, W, st));
             else
                 RC(conv_wgrad(cur, C, ws + P.x16, 16, nullptr, 0, P.in_ch, grd + P.L[ia].w_off, grd + P.L[ia].b_off, part, N, H, W, st));
+            RC(marks.done(P, ia, st));
             break;
         }
         const int Cp = chan(l - 1);
         RC(conv_wgrad(cur, C, ws + P.pool[l - 1], Cp, nullptr, 0, Cp, grd + P.L[ia].w_off, grd + P.L[ia].b_off, part, N, H, W, st));
+        RC(marks.done(P, ia, st));
         RC(conv_bwd_data(cur, ws + P.wp_bwd[ia], oth, nullptr, Cp, nullptr, nullptr, N, H, W, Cp, C, st));      // d_pool (raw)
         { float* t = cur; cur = oth; oth = t; }
         RC(launch_maxpool_bwd(ws + P.eb[l - 1], cur, ws + P.skip[l - 1], oth, N, H, W, Cp, st));
@@ -371,7 +397,7 @@ int conv_wgrad_bf16(const bf16_t* g, int Cout, const bf16_t* x0, int C0, const b
     return launch_wgrad_reduce(part, a.bpart, dw, db, q.psplit, q.T, q.CA, q.CBp, C0 + C1, st);
 }
 
-int unet_backward_bf16(const Plan& P, const float* dout, const float* prm, float* grd, float* ws, hipStream_t st) {
+int unet_backward_bf16(const Plan& P, const float* dout, const float* prm, float* grd, float* ws, hipStream_t st, BucketMarks& marks) {
     const int N = P.N;
     if (P.in_ch > 4) return ELD_ENOTSUP;
     RC(pack_weights(P, prm, ws, true, st, true));
@@ -379,14 +405,17 @@ int unet_backward_bf16(const Plan& P, const float* dout, const float* prm, float
     bf16_t* cur = B(P.gA); bf16_t* oth = B(P.gB); float* part = ws + P.part;
     const LayerDef& Hd = P.L[L_HEAD];
     RC(launch_head_bwd_bf16(dout, B(P.db[0]), prm + Hd.w_off, cur, grd + Hd.w_off, grd + Hd.b_off, part, N, P.H, P.W, P.out_ch, st));
+    RC(marks.done(P, L_HEAD, st));
     auto swap = [&]() { bf16_t* t = cur; cur = oth; oth = t; };
     for (int l = 0; l <= 3; ++l) {
         const int iu = L_UP3 + 3 * (3 - l);
         const int H = P.Hl[l], W = P.Wl[l], C = chan(l);
         RC(conv_wgrad_bf16(cur, C, B(P.da[l]), C, nullptr, 0, grd + P.L[iu + 2].w_off, grd + P.L[iu + 2].b_off, part, N, H, W, st));
+        RC(marks.done(P, iu + 2, st));
         RC(conv_bwd_data_bf16(cur, B(P.wp_bwd[iu + 2]), oth, nullptr, C, B(P.da[l]), nullptr, N, H, W, C, C, st));
         swap();
         RC(conv_wgrad_bf16(cur, C, B(P.up[l]), C, B(P.eb[l]), C, grd + P.L[iu + 1].w_off, grd + P.L[iu + 1].b_off, part, N, H, W, st));
+        RC(marks.done(P, iu + 1, st));
         RC(conv_bwd_data_bf16(cur, B(P.wp_bwd[iu + 1]), oth, B(P.skip[l]), C, nullptr, nullptr, N, H, W, 2 * C, C, st));
         swap();
         const bf16_t* src = l == 3 ? B(P.eb[4]) : B(P.db[l + 1]);
@@ -399,6 +428,7 @@ int unet_backward_bf16(const Plan& P, const float* dout, const float* prm, float
             RC(launch_wgrad(a, CONV_GATHER2X2, st));
             RC(launch_wgrad_reduce(part, nullptr, grd + P.L[iu].w_off, nullptr, q.psplit, q.T, q.CA, q.CBp, C, st));
             RC(launch_colsum_bf16(cur, grd + P.L[iu].b_off, part, (size_t)N * 4 * Hi * Wi, C, st));
+            RC(marks.done(P, iu, st));
             ConvArgs c = {};
             c.in0 = cur; c.C0 = C; c.wp = B(P.wp_bwd[iu]); c.N = N; c.H = Hi; c.W = Wi; c.Nout = 2 * C;
             c.epi = EPI_GRAD; c.out0 = oth; c.split = 2 * C; c.act0 = src; c.dtype = DT_BF16;
@@ -410,14 +440,17 @@ int unet_backward_bf16(const Plan& P, const float* dout, const float* prm, float
         const int H = P.Hl[l], W = P.Wl[l], C = chan(l);
         const int ia = 2 * l, ib = 2 * l + 1;
         RC(conv_wgrad_bf16(cur, C, B(P.ea[l]), C, nullptr, 0, grd + P.L[ib].w_off, grd + P.L[ib].b_off, part, N, H, W, st));
+        RC(marks.done(P, ib, st));
         RC(conv_bwd_data_bf16(cur, B(P.wp_bwd[ib]), oth, nullptr, C, B(P.ea[l]), nullptr, N, H, W, C, C, st));
         swap();
         if (l == 0) {
             RC(launch_conv_first_wgrad_bf16(cur, ws + P.x16, grd + P.L[ia].w_off, grd + P.L[ia].b_off, part, N, P.in_ch, H, W, st));
+            RC(marks.done(P, ia, st));
             break;
         }
         const int Cp = chan(l - 1);
         RC(conv_wgrad_bf16(cur, C, B(P.pool[l - 1]), Cp, nullptr, 0, grd + P.L[ia].w_off, grd + P.L[ia].b_off, part, N, H, W, st));
+        RC(marks.done(P, ia, st));
         RC(conv_bwd_data_bf16(cur, B(P.wp_bwd[ia]), oth, nullptr, Cp, nullptr, nullptr, N, H, W, Cp, C, st));
         swap();
         RC(launch_maxpool_bwd_bf16(B(P.eb[l - 1]), cur, B(P.skip[l - 1]), oth, N, H, W, Cp, st));
@@ -473,7 +506,8 @@ extern "C" int eld_unet_backward(const float* dout, const float* params, float* 
     RC(make_plan(P, N, H, W, in_ch, out_ch));
     if (!dout || !params || !grads || !ws) return ELD_EINVAL;
     if (ws_bytes < P.total * sizeof(float)) return ELD_EWS;
-    return unet_backward(P, dout, params, grads, (float*)ws, as_stream(stream));
+    BucketMarks none;
+    return unet_backward(P, dout, params, grads, (float*)ws, as_stream(stream), none);
 }
 
 extern "C" int eld_unet_backward_bf16(const float* dout, const float* params, float* grads, void* ws, size_t ws_bytes, int N, int H, int W,
@@ -483,7 +517,27 @@ extern "C" int eld_unet_backward_bf16(const float* dout, const float* params, fl
     RC(make_plan(P, N, H, W, in_ch, out_ch));
     if (!dout || !params || !grads || !ws) return ELD_EINVAL;
     if (ws_bytes < P.total * sizeof(float)) return ELD_EWS;
-    return unet_backward_bf16(P, dout, params, grads, (float*)ws, as_stream(stream));
+    BucketMarks none;
+    return unet_backward_bf16(P, dout, params, grads, (float*)ws, as_stream(stream), none);
+}
+
+extern "C" int eld_unet_backward_buckets(const float* dout, const float* params, float* grads, void* ws, size_t ws_bytes, int N, int H, int W,
+                                         int in_ch, int out_ch, int precision, const int64_t* bucket_start, void* const* bucket_event,
+                                         int n_buckets, void* stream) {
+    if (N == 0) return 0;
+    Plan P;
+    RC(make_plan(P, N, H, W, in_ch, out_ch));
+    if (!dout || !params || !grads || !ws || n_buckets < 0 || (n_buckets > 0 && (!bucket_start || !bucket_event))) return ELD_EINVAL;
+    if (precision != 0 && precision != 1) return ELD_EINVAL;
+    for (int k = 0; k < n_buckets; ++k)
+        if (!bucket_event[k] || bucket_start[k] < 0 || (k > 0 && bucket_start[k] <= bucket_start[k - 1]) || (size_t)bucket_start[k] >= P.nparams) return ELD_EINVAL;
+    if (ws_bytes < P.total * sizeof(float)) return ELD_EWS;
+    BucketMarks marks;
+    marks.start = bucket_start; marks.event = bucket_event; marks.n = n_buckets;
+    const int rc = precision == 1 ? unet_backward_bf16(P, dout, params, grads, (float*)ws, as_stream(stream), marks)
+                                  : unet_backward(P, dout, params, grads, (float*)ws, as_stream(stream), marks);
+    if (rc) return rc;
+    return marks.next == n_buckets ? 0 : ELD_EINVAL;
 }
 
 extern "C" int eld_conv_fp32_algo(int algo) { return conv_fp32_algo(algo); }

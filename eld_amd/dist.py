@@ -5,17 +5,19 @@ by image over ranks is new functionality.
 The only exchange step of the path is the gradient all-reduce: all 7,760,484 fp32 gradients live in ONE
 flat buffer (eld_amd.unet), so the reduction is a handful of large contiguous RCCL calls -- xGMI is
 point-to-point (7 links x ~153 GB/s per GPU) and a ring all-reduce is per-link bound, so few large
-buckets beat per-tensor calls.  The engine's backward is one stream-ordered call; the 31 MB reduction
-(~0.4 ms as a ring over one link) is small against the >= 20 ms fp32 step at the benchmark size, so it is
-issued right after the backward.  Gradient averaging (sum / world) is folded into the fused Adam's
-grad_scale, so no extra pass over the gradients is made.
+buckets beat per-tensor calls.  The engine's backward is one stream-ordered call that produces the flat
+gradient buffer from its END towards its start and records one event per bucket as soon as the bucket is
+final (include/eld_amd.h eld_unet_backward_buckets); GradBuckets all-reduces each bucket on a communication
+stream behind its event, so the 31 MB exchange runs under the rest of the backward.  Gradient averaging
+(sum / world) is folded into the fused Adam's grad_scale, so no extra pass over the gradients is made.
 """
+import ctypes
 import os
 
 import torch
 import torch.distributed as dist
 
-BUCKET_FLOATS = 4 * 1024 * 1024      # 16 MiB buckets
+BUCKET_FLOATS = 2 * 1024 * 1024      # 8 MiB buckets: 4 of them for the 7.76 M-parameter U-Net
 
 
 def env_world():
@@ -56,6 +58,42 @@ def allreduce_sum_(flat, bucket=BUCKET_FLOATS):
     for h in handles:
         h.wait()
     return w
+
+
+class GradBuckets:
+    """Bucket table of a flat CUDA gradient buffer for the overlapped exchange: ascending start offsets, one CUDA event per
+    bucket (recorded by the engine's backward on the compute stream) and a communication stream."""
+
+    def __init__(self, numel, device, bucket=BUCKET_FLOATS):
+        self.numel = int(numel)
+        self.starts = list(range(0, self.numel, int(bucket)))
+        self.events = [torch.cuda.Event() for _ in self.starts]
+        with torch.cuda.device(device):
+            for e in self.events:
+                e.record()                       # materialises the hipEvent_t behind the torch object
+            self.stream = torch.cuda.Stream(device)
+        n = len(self.starts)
+        self.starts_c = (ctypes.c_int64 * n)(*self.starts)
+        self.events_c = (ctypes.c_void_p * n)(*[e.cuda_event for e in self.events])
+        self.n = n
+
+    def allreduce_sum_(self, flat):
+        """Call after the bucketed backward has been enqueued on the current stream.  Buckets are reduced top-down (the order
+        in which they become final); the current stream then waits for all of them.  Returns the world size."""
+        w = world_size()
+        if w == 1:
+            return 1
+        handles = []
+        for k in range(self.n - 1, -1, -1):
+            lo = self.starts[k]
+            hi = self.starts[k + 1] if k + 1 < self.n else self.numel
+            self.stream.wait_event(self.events[k])
+            with torch.cuda.stream(self.stream):
+                handles.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        for h in handles:
+            h.wait()
+        torch.cuda.current_stream().wait_stream(self.stream)
+        return w
 
 
 def broadcast_(flat, src=0):

@@ -104,6 +104,7 @@ class ELDModel:
         prec = getattr(opt, 'precision', os.environ.get('ELD_AMD_PRECISION', 'fp32'))      # 'bf16' = BASELINE config 3
         self.netG.train_precision = self.netG.inference_precision = prec
         self.world, self.rank = D.world_size(), D.rank()
+        self._buckets = None
         if self.world > 1:
             D.broadcast_(self.netG.flat_params, 0)          # identical replicas
         self.loss_pixel = None
@@ -203,8 +204,14 @@ class ELDModel:
         dout = torch.empty_like(out)
         L.check(L.lib().eld_l1_loss(L.dptr(out), L.dptr(self.target.contiguous()), L.dptr(dout), L.dptr(self._loss_buf), L.dptr(self._l1_ws),
                                     out.numel(), 1.0, L.cur_stream()), 'eld_l1_loss')           # backward_G(): L1 + its gradient
-        net._engine_backward(dout, key, tuple(x.shape), grads=opt.grads)      # loss.backward()
-        w = D.allreduce_sum_(opt.grads)                                       # data-parallel exchange (new)
+        if self.world > 1 and opt.grads.is_cuda:                              # data-parallel exchange (new):
+            if self._buckets is None:                                         # buckets all-reduced under the rest of the backward
+                self._buckets = D.GradBuckets(opt.grads.numel(), opt.grads.device)
+            net._engine_backward(dout, key, tuple(x.shape), grads=opt.grads, buckets=self._buckets)      # loss.backward()
+            w = self._buckets.allreduce_sum_(opt.grads)
+        else:
+            net._engine_backward(dout, key, tuple(x.shape), grads=opt.grads)  # loss.backward()
+            w = D.allreduce_sum_(opt.grads)
         opt.step(grad_scale=1.0 / w)                                          # optimizer_G.step()
         self.loss_pixel = self._loss_buf
 

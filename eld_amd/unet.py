@@ -137,11 +137,17 @@ class UNetSeeInDark(nn.Module):
                    N, H, W, self.in_channels, self.out_channels, L.cur_stream()), 'eld_unet_forward')
         return out, key, self._ws.gen[key]
 
-    def _engine_backward(self, dout, key, shape, grads=None):
+    def _engine_backward(self, dout, key, shape, grads=None, buckets=None):
+        """buckets: eld_amd.dist.GradBuckets -- record one event per gradient bucket as soon as it is final (data-parallel overlap)."""
         N, _, H, W = shape
         ws = self._ws.bufs[key]
         if grads is None:
             grads = torch.empty(self._offsets[-1], dtype=torch.float32, device=dout.device)
+        if buckets is not None:
+            L.check(L.lib().eld_unet_backward_buckets(L.dptr(dout), L.dptr(self.flat_params), L.dptr(grads), L.dptr(ws), ws.numel(), N, H, W,
+                                                      self.in_channels, self.out_channels, 1 if key[0] == 'train_bf16' else 0,
+                                                      buckets.starts_c, buckets.events_c, buckets.n, L.cur_stream()), 'eld_unet_backward_buckets')
+            return grads
         fn = L.lib().eld_unet_backward_bf16 if key[0] == 'train_bf16' else L.lib().eld_unet_backward
         L.check(fn(L.dptr(dout), L.dptr(self.flat_params), L.dptr(grads), L.dptr(ws), ws.numel(),
                    N, H, W, self.in_channels, self.out_channels, L.cur_stream()), 'eld_unet_backward')

@@ -136,6 +136,17 @@ int eld_unet_backward_bf16(const float* dout, const float* params, float* grads,
 int eld_unet_backward(const float* dout, const float* params, float* grads, void* ws, size_t ws_bytes,
                       int N, int H, int W, int in_ch, int out_ch, void* stream);
 
+/* eld_unet_backward / eld_unet_backward_bf16 (precision 0 / 1) for data-parallel training (the reference is
+ * single-device, models/ELD_model.py:187-190): the flat gradient buffer is cut into n_buckets contiguous buckets starting at the
+ * ascending float offsets bucket_start[k] (bucket k = [bucket_start[k], bucket_start[k+1]) ; the last one runs to the end;
+ * bucket_start[0] is normally 0).  Gradients are produced from the END of the buffer towards its start, and
+ * hipEventRecord(bucket_event[k], stream) is enqueued as soon as the last kernel writing bucket k is enqueued, so a
+ * communication stream can wait on the events and all-reduce bucket by bucket while the rest of the backward runs.
+ * bucket_event[k]: hipEvent_t created by the caller. */
+int eld_unet_backward_buckets(const float* dout, const float* params, float* grads, void* ws, size_t ws_bytes,
+                              int N, int H, int W, int in_ch, int out_ch, int precision,
+                              const int64_t* bucket_start, void* const* bucket_event, int n_buckets, void* stream);
+
 /* mean |out-target| (nn.L1Loss, models/losses.py:32) and, if dout != NULL, its gradient times grad_scale.
  * ws: eld_l1_workspace_bytes() bytes.  loss: one device float. */
 /* How the fp32 3x3 convolutions of eld_unet_forward/backward and eld_conv3x3_* form their products:
