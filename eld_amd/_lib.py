@@ -41,6 +41,10 @@ SIGNATURES = {
     'eld_unet_backward_bf16': (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
     'eld_unet_backward_buckets': (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     'eld_conv_fp32_algo': (_i, [_i]),
+    'eld_quality_assess_workspace_bytes': (_sz, [_i, _i, _i, _i]),
+    'eld_quality_assess': (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _f, _vp]),
+    'eld_illuminance_correct_workspace_bytes': (_sz, [_i]),
+    'eld_illuminance_correct': (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _sz, _vp]),
     'eld_l1_workspace_bytes': (_sz, []),
     'eld_l1_loss': (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _f, _vp]),
     'eld_adam_step': (_i, [_vp, _vp, _vp, _vp, _sz, _d, _d, _d, _d, _d, _i, _d, _vp]),

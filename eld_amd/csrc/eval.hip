@@ -1,0 +1,197 @@
+// eval.hip -- evaluation-side kernels of the path, all HBM-bound single passes:
+//   * quality_assess: PSNR and multichannel SSIM of util/index.py:76-81 on the x255-clipped images of tensor2im
+//     (models/ELD_model.py:23-38), i.e. skimage.metrics.peak_signal_noise_ratio / structural_similarity(data_range=255,
+//     multichannel=True) with skimage's defaults (7x7 uniform window, K1 = 0.01, K2 = 0.03, sample covariance, windows
+//     fully inside the image, channels averaged) -- the frames never leave the device;
+//   * illuminance_correct: models/ELD_model.py:138-169, out = <p,s>/<p,p> * p over the elements with s != 1, p clamped
+//     to [0,1], one scale per image.
+// Sums are accumulated in double and reduced in a fixed order (run-to-run bit-stable, no atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int QA_TW = 32, QA_TH = 8, WIN = 7, HALO = WIN - 1;
+constexpr int RED_BLOCKS = 512;
+
+__device__ __forceinline__ float to_im(float v, float scale) { return fminf(fmaxf(v * scale, 0.f), scale); }     // np.clip(x * 255, 0, 255)
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {       // 256 threads, fixed tree
+    const int t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+#pragma unroll
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) sh[t] += sh[t + s];
+        __syncthreads();
+    }
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+// one workgroup = one 32x8 tile of window positions of one (image, channel) plane; writes the tile's sum of S
+__global__ __launch_bounds__(256) void ssim_kernel(const float* __restrict__ est, const float* __restrict__ ref, double* __restrict__ part,
+                                                   int H, int W, int tiles_x, int tiles_y, float scale) {
+    __shared__ float lx[QA_TH + HALO][QA_TW + HALO], ly[QA_TH + HALO][QA_TW + HALO];
+    __shared__ double hs[5][QA_TH + HALO][QA_TW];
+    __shared__ double red[256];
+    const int plane = blockIdx.y;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int y0 = ty * QA_TH, x0 = tx * QA_TW;
+    const int Ho = H - HALO, Wo = W - HALO;                       // window positions
+    const float* px = est + (size_t)plane * H * W;
+    const float* py = ref + (size_t)plane * H * W;
+    for (int i = threadIdx.x; i < (QA_TH + HALO) * (QA_TW + HALO); i += 256) {
+        const int r = i / (QA_TW + HALO), c = i - r * (QA_TW + HALO);
+        const int gy = y0 + r, gx = x0 + c;
+        const bool ok = gy < H && gx < W;
+        lx[r][c] = ok ? to_im(px[(size_t)gy * W + gx], scale) : 0.f;
+        ly[r][c] = ok ? to_im(py[(size_t)gy * W + gx], scale) : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (QA_TH + HALO) * QA_TW; i += 256) {      // horizontal 7-sums of x, y, xx, yy, xy
+        const int r = i / QA_TW, c = i - r * QA_TW;
+        double sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+#pragma unroll
+        for (int d = 0; d < WIN; ++d) {
+            const double a = lx[r][c + d], b = ly[r][c + d];
+            sx += a; sy += b; sxx += a * a; syy += b * b; sxy += a * b;
+        }
+        hs[0][r][c] = sx; hs[1][r][c] = sy; hs[2][r][c] = sxx; hs[3][r][c] = syy; hs[4][r][c] = sxy;
+    }
+    __syncthreads();
+    const int r = threadIdx.x / QA_TW, c = threadIdx.x - r * QA_TW;
+    double S = 0.0;
+    if (y0 + r < Ho && x0 + c < Wo) {
+        double s[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            double a = 0;
+#pragma unroll
+            for (int d = 0; d < WIN; ++d) a += hs[q][r + d][c];
+            s[q] = a * (1.0 / (WIN * WIN));
+        }
+        const double cov_norm = (double)(WIN * WIN) / (WIN * WIN - 1.0);
+        const double ux = s[0], uy = s[1];
+        const double vx = cov_norm * (s[2] - ux * ux), vy = cov_norm * (s[3] - uy * uy), vxy = cov_norm * (s[4] - ux * uy);
+        const double C1 = (0.01 * (double)scale) * (0.01 * (double)scale), C2 = (0.03 * (double)scale) * (0.03 * (double)scale);
+        S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux * ux + uy * uy + C1) * (vx + vy + C2));
+    }
+    const double tot = block_sum(S, red);
+    if (threadIdx.x == 0) part[(size_t)plane * tiles_x * tiles_y + blockIdx.x] = tot;
+}
+
+// squared error of the x255-clipped images: grid (RED_BLOCKS, N)
+__global__ __launch_bounds__(256) void sqerr_kernel(const float* __restrict__ est, const float* __restrict__ ref, double* __restrict__ part, size_t chw, float scale) {
+    __shared__ double red[256];
+    const float* a = est + (size_t)blockIdx.y * chw;
+    const float* b = ref + (size_t)blockIdx.y * chw;
+    double s = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < chw; i += (size_t)RED_BLOCKS * 256) {
+        const double d = (double)to_im(b[i], scale) - (double)to_im(a[i], scale);
+        s += d * d;
+    }
+    const double tot = block_sum(s, red);
+    if (threadIdx.x == 0) part[(size_t)blockIdx.y * RED_BLOCKS + blockIdx.x] = tot;
+}
+
+// one workgroup per image: out[2n] = PSNR, out[2n+1] = SSIM
+__global__ __launch_bounds__(256) void qa_final_kernel(const double* __restrict__ sq, const double* __restrict__ ss, double* __restrict__ out, int C,
+                                                       int tiles, size_t chw, size_t windows, float scale) {
+    __shared__ double red[256];
+    const int n = blockIdx.x;
+    double a = 0.0;
+    for (int i = threadIdx.x; i < RED_BLOCKS; i += 256) a += sq[(size_t)n * RED_BLOCKS + i];
+    const double err = block_sum(a, red) / (double)chw;
+    double ssim = 0.0;
+    for (int c = 0; c < C; ++c) {                      // mean over channels of the per-channel means (multichannel=True)
+        double b = 0.0;
+        for (int i = threadIdx.x; i < tiles; i += 256) b += ss[((size_t)n * C + c) * tiles + i];
+        ssim += block_sum(b, red) / (double)windows;
+    }
+    if (threadIdx.x == 0) {
+        out[2 * n] = 10.0 * log10((double)scale * (double)scale / err);
+        out[2 * n + 1] = ssim / C;
+    }
+}
+
+// illuminance correction, pass 1: per-block partial <p,s> and <p,p> over s != 1 (p clamped to [0,1]); grid (RED_BLOCKS, N)
+__global__ __launch_bounds__(256) void illum_dot_kernel(const float* __restrict__ pred, const float* __restrict__ src, double* __restrict__ part, size_t chw,
+                                                        size_t src_stride) {
+    __shared__ double red[256];
+    const float* p = pred + (size_t)blockIdx.y * chw;
+    const float* s = src + (size_t)blockIdx.y * src_stride;
+    double num = 0.0, den = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < chw; i += (size_t)RED_BLOCKS * 256) {
+        const float sv = s[i];
+        if (sv != 1.0f) {
+            const double pv = fminf(fmaxf(p[i], 0.f), 1.f);
+            num += pv * (double)sv; den += pv * pv;
+        }
+    }
+    const double tn = block_sum(num, red), td = block_sum(den, red);
+    if (threadIdx.x == 0) { part[((size_t)blockIdx.y * RED_BLOCKS + blockIdx.x) * 2] = tn; part[((size_t)blockIdx.y * RED_BLOCKS + blockIdx.x) * 2 + 1] = td; }
+}
+
+__global__ __launch_bounds__(256) void illum_alpha_kernel(const double* __restrict__ part, float* __restrict__ alpha) {
+    __shared__ double red[256];
+    const int n = blockIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < RED_BLOCKS; i += 256) { a += part[((size_t)n * RED_BLOCKS + i) * 2]; b += part[((size_t)n * RED_BLOCKS + i) * 2 + 1]; }
+    const double num = block_sum(a, red), den = block_sum(b, red);
+    if (threadIdx.x == 0) alpha[n] = (float)num / (float)den;             // num / den as fp32 tensors (ELD_model.py:164-166)
+}
+
+__global__ __launch_bounds__(256) void illum_scale_kernel(const float* __restrict__ pred, const float* __restrict__ alpha, float* __restrict__ out, size_t chw) {
+    const float a = alpha[blockIdx.y];
+    const size_t base = (size_t)blockIdx.y * chw;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < chw; i += (size_t)gridDim.x * 256)
+        out[base + i] = a * fminf(fmaxf(pred[base + i], 0.f), 1.f);
+}
+
+inline size_t qa_tiles(int H, int W) { return (size_t)((W - HALO + QA_TW - 1) / QA_TW) * ((H - HALO + QA_TH - 1) / QA_TH); }
+
+}  // namespace
+
+extern "C" size_t eld_quality_assess_workspace_bytes(int N, int C, int H, int W) {
+    if (N < 1 || C < 1 || H < WIN || W < WIN) return 0;
+    return ((size_t)N * RED_BLOCKS + (size_t)N * C * qa_tiles(H, W)) * sizeof(double);
+}
+
+extern "C" int eld_quality_assess(const float* est, const float* ref, double* out, void* ws, size_t ws_bytes, int N, int C, int H, int W,
+                                  float data_range, void* stream) {
+    if (N == 0) return 0;
+    if (!est || !ref || !out || !ws || N < 0 || C < 1 || H < WIN || W < WIN || !(data_range > 0.f)) return ELD_EINVAL;
+    if (ws_bytes < eld_quality_assess_workspace_bytes(N, C, H, W)) return ELD_EWS;
+    hipStream_t st = as_stream(stream);
+    double* sq = (double*)ws;
+    double* ss = sq + (size_t)N * RED_BLOCKS;
+    const int tiles_x = (W - HALO + QA_TW - 1) / QA_TW, tiles_y = (H - HALO + QA_TH - 1) / QA_TH;
+    const size_t chw = (size_t)C * H * W;
+    hipLaunchKernelGGL(sqerr_kernel, dim3(RED_BLOCKS, N), dim3(256), 0, st, est, ref, sq, chw, data_range);
+    ELD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ssim_kernel, dim3(tiles_x * tiles_y, N * C), dim3(256), 0, st, est, ref, ss, H, W, tiles_x, tiles_y, data_range);
+    ELD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(qa_final_kernel, dim3(N), dim3(256), 0, st, sq, ss, out, C, tiles_x * tiles_y, chw, (size_t)(H - HALO) * (W - HALO), data_range);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t eld_illuminance_correct_workspace_bytes(int N) { return N < 1 ? 0 : (size_t)N * RED_BLOCKS * 2 * sizeof(double) + (size_t)N * sizeof(float); }
+
+extern "C" int eld_illuminance_correct(const float* predict, const float* source, float* out, void* ws, size_t ws_bytes, int N, int source_N,
+                                       size_t chw, void* stream) {
+    if (N == 0) return 0;
+    if (!predict || !source || !out || !ws || N < 0 || chw == 0 || (source_N != N && source_N != 1)) return ELD_EINVAL;
+    if (ws_bytes < eld_illuminance_correct_workspace_bytes(N)) return ELD_EWS;
+    hipStream_t st = as_stream(stream);
+    double* part = (double*)ws;
+    float* alpha = (float*)(part + (size_t)N * RED_BLOCKS * 2);
+    hipLaunchKernelGGL(illum_dot_kernel, dim3(RED_BLOCKS, N), dim3(256), 0, st, predict, source, part, chw, source_N == 1 ? (size_t)0 : chw);
+    ELD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(illum_alpha_kernel, dim3(N), dim3(256), 0, st, part, alpha);
+    ELD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(illum_scale_kernel, dim3(1024, N), dim3(256), 0, st, predict, alpha, out, chw);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}

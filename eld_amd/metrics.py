@@ -1,6 +1,8 @@
 """Evaluation metrics on device: what the reference's eval path computes with scikit-image on the host
 (util/index.py:76-81 `quality_assess`: PSNR and multichannel SSIM with data_range=255 on the x255-clipped float
-images of `tensor2im`, models/ELD_model.py:23-38).  HBM-bound torch reductions; no host round trip of the frames.
+images of `tensor2im`, models/ELD_model.py:23-38).  `quality_assess_frames` / `illuminance_correct` run the HIP kernels of
+csrc/eval.hip (one pass over the frames, double accumulation, no host round trip); `psnr` / `ssim` below are the same
+formulas in torch ops for tensors that are not on the GPU.
 scikit-image is absent from this stack, so SSIM restates skimage.metrics.structural_similarity's defaults
 (7x7 uniform window, K1=0.01, K2=0.03, sample covariance, border of 3 cropped, mean over channels) -- the oracle
 statement is oracle/metrics_ref.py (NumPy + scipy.ndimage)."""
@@ -36,3 +38,33 @@ def ssim(x, y, data_range=255.0, win_size=7, K1=0.01, K2=0.03):
 def quality_assess(X, Y, data_range=255.0):
     """util/index.py:76-81 for one image (C,H,W on device): Y correct, X estimate."""
     return {'PSNR': float(psnr(Y, X, data_range)), 'SSIM': float(ssim(Y, X, data_range))}
+
+
+def quality_assess_frames(est, ref, data_range=255.0):
+    """util/index.py:76-81 per image, fused with tensor2im (ELD_model.py:23-38): est/ref are CUDA (N,C,H,W) float32 tensors in
+    [0,1] units; returns a CUDA float64 tensor (N,2) = [PSNR, SSIM] per image (csrc/eval.hip eld_quality_assess)."""
+    from . import _lib as L
+    assert est.is_cuda and ref.is_cuda and est.shape == ref.shape and est.dim() == 4
+    est, ref = est.contiguous().float(), ref.contiguous().float()
+    N, C, H, W = est.shape
+    lib = L.lib()
+    ws = torch.empty(lib.eld_quality_assess_workspace_bytes(N, C, H, W), dtype=torch.uint8, device=est.device)
+    out = torch.empty((N, 2), dtype=torch.float64, device=est.device)
+    L.check(lib.eld_quality_assess(L.dptr(est), L.dptr(ref), L.dptr(out), L.dptr(ws), ws.numel(), N, C, H, W, float(data_range), L.cur_stream()),
+            'eld_quality_assess')
+    return out
+
+
+def illuminance_correct(predict, source):
+    """models/ELD_model.py:138-169 on the device (csrc/eval.hip): one least-squares gain per image over source != 1."""
+    from . import _lib as L
+    assert predict.is_cuda and source.is_cuda and predict.dim() == 4
+    predict, source = predict.contiguous().float(), source.contiguous().float()
+    N = predict.shape[0]
+    assert source.shape[0] in (1, N) and source.shape[1:] == predict.shape[1:]
+    lib = L.lib()
+    ws = torch.empty(lib.eld_illuminance_correct_workspace_bytes(N), dtype=torch.uint8, device=predict.device)
+    out = torch.empty_like(predict)
+    L.check(lib.eld_illuminance_correct(L.dptr(predict), L.dptr(source), L.dptr(out), L.dptr(ws), ws.numel(), N, source.shape[0],
+                                        predict[0].numel(), L.cur_stream()), 'eld_illuminance_correct')
+    return out

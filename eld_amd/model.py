@@ -239,10 +239,10 @@ class ELDModel:
         out = self.forward()
         if correct:                                  # IlluminanceCorrect, ELD_model.py:138-169
             out = illuminance_correct(out, self.target)
-        from .metrics import quality_assess
-        a = torch.clamp(out[0] * 255.0, 0, 255)      # tensor2im, ELD_model.py:23-38 (float, not rounded); only image 0 of the batch
-        b = torch.clamp(self.target[0] * 255.0, 0, 255)
-        return quality_assess(a, b)                  # util/index.py:76-81: {'PSNR', 'SSIM'}
+        from .metrics import quality_assess_frames
+        q = quality_assess_frames(out[:1], self.target[:1])      # tensor2im (ELD_model.py:23-38: image 0, x255, clipped, not rounded)
+        psnr, ssim = q[0].tolist()                               # + util/index.py:76-81, fused on the device
+        return {'PSNR': psnr, 'SSIM': ssim}
 
     # ---- checkpoints (base_model.py:55-66, ELD_model.py:492-523) -----------------------------------------------
     def state_dict(self):
@@ -271,15 +271,9 @@ class ELDModel:
 
 
 def illuminance_correct(predict, source):
-    """ELD_model.py:138-169: alpha = <p,s>/<p,p> over source != 1 on the [0,1]-clamped prediction, per image."""
-    outs = []
-    for i in range(predict.shape[0]):
-        p = torch.clamp(predict[i:i + 1], 0, 1)
-        s = source[i:i + 1] if source.shape[0] != 1 else source
-        m = s != 1
-        pc, sc = p[m], s[m]
-        outs.append(torch.dot(pc, sc) / torch.dot(pc, pc) * p)
-    return torch.cat(outs, 0)
+    """ELD_model.py:138-169: alpha = <p,s>/<p,p> over source != 1 on the [0,1]-clamped prediction, per image (csrc/eval.hip)."""
+    from .metrics import illuminance_correct as _ic
+    return _ic(predict, source)
 
 
 def eld_model():                                     # models/__init__.py:3-4

@@ -163,6 +163,21 @@ int eld_l1_loss(const float* out, const float* target, float* dout, float* loss,
 int eld_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1,
                   double beta2, double eps, double weight_decay, int step, double grad_scale, void* stream);
 
+/* ---- evaluation side -------------------------------------------------------------------------
+ * util/index.py:76-81 quality_assess on the images of tensor2im (models/ELD_model.py:23-38: clip(x*255, 0, 255)):
+ * est/ref are NCHW float32 in [0,1] units; out[2n] = PSNR (dB), out[2n+1] = SSIM of image n, as device doubles.
+ * SSIM = skimage.metrics.structural_similarity(data_range=255, multichannel=True) with its defaults (7x7 uniform window,
+ * K1=0.01, K2=0.03, sample covariance, windows inside the image, mean over channels); scikit-image is a third-party
+ * dependency the reference does not pin. */
+size_t eld_quality_assess_workspace_bytes(int N, int C, int H, int W);
+int eld_quality_assess(const float* est, const float* ref, double* out, void* ws, size_t ws_bytes, int N, int C, int H, int W,
+                       float data_range, void* stream);
+/* models/ELD_model.py:138-169 IlluminanceCorrect: out[n] = <p,s>/<p,p> * p, p = clamp(predict[n], 0, 1), sums over the
+ * elements with source != 1; source_N is N or 1 (one source for all).  chw = elements per image. */
+size_t eld_illuminance_correct_workspace_bytes(int N);
+int eld_illuminance_correct(const float* predict, const float* source, float* out, void* ws, size_t ws_bytes, int N, int source_N,
+                            size_t chw, void* stream);
+
 /* ---- single layers on NHWC float32 tensors with reference-layout weights; used by the parity tests ---- */
 size_t eld_layer_workspace_bytes(int N, int H, int W, int Cin, int Cout);
 /* out = [lrelu](conv3x3(cat[in0,in1]) + bias).  nn.Conv2d(k=3,p=1) + torch.max(0.2x,x)  (Unet.py:11-44,102-104) */

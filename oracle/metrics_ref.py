@@ -32,3 +32,24 @@ def ssim_channel(x, y, data_range=255.0, win_size=7, K1=0.01, K2=0.03):
 def ssim(x, y, data_range=255.0):
     """x, y: (C,H,W); multichannel=True -> mean of the per-channel SSIMs."""
     return float(np.mean([ssim_channel(x[c], y[c], data_range) for c in range(x.shape[0])]))
+
+
+def tensor2im(x):
+    """models/ELD_model.py:23-38 for one (C,H,W) image in [0,1] units: x*255 clipped to [0,255], float32, not rounded
+    (the transpose to HWC does not change the metrics)."""
+    return np.clip(np.asarray(x, np.float32) * np.float32(255.0), 0, 255)
+
+
+def illuminance_correct(predict, source):
+    """models/ELD_model.py:138-169 per image: p = clip(predict,0,1); alpha = <p,s>/<p,p> over source != 1 (float32 ratio of the
+    two dot products, accumulated here in float64); out = alpha * p.  predict: (N,C,H,W); source: (N or 1,C,H,W)."""
+    predict, source = np.asarray(predict, np.float32), np.asarray(source, np.float32)
+    out = np.empty_like(predict)
+    for i in range(predict.shape[0]):
+        p = np.clip(predict[i], 0, 1)
+        s = source[i] if source.shape[0] != 1 else source[0]
+        m = s != 1
+        num = np.dot(p[m].astype(np.float64), s[m].astype(np.float64))
+        den = np.dot(p[m].astype(np.float64), p[m].astype(np.float64))
+        out[i] = np.float32(num) / np.float32(den) * p
+    return out

@@ -329,3 +329,33 @@ def test_two_rank_training_equals_global_batch(eld_lib, tmp_path):
     assert np.array_equal(res[0][2], res[1][2])      # replicas stay identical
     assert abs(res[0][1] - loss) < 1e-6 and abs(res[1][1] - loss) < 1e-6
     assert np.abs(res[0][2] - ref).max() < 3e-5      # Adam moves every weight ~lr per step; sign-unstable tiny gradients may differ
+
+
+@pytest.mark.parametrize('shape', [(2, 4, 64, 80), (1, 4, 37, 41), (3, 3, 7, 129), (1, 4, 512, 512)])
+def test_quality_assess_kernel_vs_oracle(eld_lib, shape):
+    """csrc/eval.hip eld_quality_assess == tensor2im + PSNR + SSIM of oracle/metrics_ref.py (float64), per image."""
+    from eld_amd.metrics import quality_assess_frames
+    from oracle import metrics_ref as M
+    g = torch.Generator().manual_seed(shape[2] * shape[3])
+    ref = torch.rand(*shape, generator=g) * 1.1 - 0.05                 # some values outside [0,1]: the clip matters
+    est = ref + 0.05 * torch.randn(*shape, generator=g)
+    q = quality_assess_frames(est.cuda(), ref.cuda()).cpu().numpy()
+    for n in range(shape[0]):
+        a, b = M.tensor2im(est[n].numpy()), M.tensor2im(ref[n].numpy())
+        assert abs(q[n, 0] - M.psnr(b, a)) < 1e-9
+        assert abs(q[n, 1] - M.ssim(b, a)) < 1e-9
+    same = quality_assess_frames(ref.cuda(), ref.cuda()).cpu().numpy()
+    assert np.all(np.isinf(same[:, 0])) and np.all(np.abs(same[:, 1] - 1.0) < 1e-12)
+
+
+@pytest.mark.parametrize('shape,one_source', [((2, 4, 32, 48), False), ((3, 4, 16, 16), True), ((1, 4, 512, 512), False)])
+def test_illuminance_correct_kernel_vs_oracle(eld_lib, shape, one_source):
+    from eld_amd.model import illuminance_correct
+    from oracle import metrics_ref as M
+    g = torch.Generator().manual_seed(3)
+    pred = torch.rand(*shape, generator=g) * 1.4 - 0.2
+    src = torch.rand(*((1,) + shape[1:] if one_source else shape), generator=g)
+    src[src > 0.9] = 1.0                                               # saturated pixels are excluded from the fit
+    got = illuminance_correct(pred.cuda(), src.cuda()).cpu().numpy()
+    ref = M.illuminance_correct(pred.numpy(), src.numpy())
+    assert np.abs(got - ref).max() <= 2e-7 * max(1.0, float(np.abs(ref).max()))
