@@ -41,6 +41,7 @@ SIGNATURES = {
     'eld_unet_backward_bf16': (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
     'eld_unet_backward_buckets': (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     'eld_conv_fp32_algo': (_i, [_i]),
+    'eld_isp_process': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _i, _vp]),
     'eld_quality_assess_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'eld_quality_assess': (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _f, _vp]),
     'eld_illuminance_correct_workspace_bytes': (_sz, [_i]),
@@ -77,6 +78,10 @@ def load_library(path=None):
         raise LibraryMissing(
             '%s not found: the HIP extension has not been built.  Run `python __graft_entry__.py` '
             '(hipcc --offload-arch=gfx950) first; eld_amd has no CPU fallback.' % p)
+    # PyTorch-ROCm ships its own copy of the HIP runtime; device memory, streams and events are torch's, so libeld_amd must
+    # bind to THAT runtime instance: import torch first (a libamdhip64 loaded by us before torch's is a second runtime with
+    # no device context -- every launch then fails with hipErrorNoDevice).
+    import torch  # noqa: F401
     lib_ = C.CDLL(p)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib_, name)          # AttributeError if the symbol is not exported

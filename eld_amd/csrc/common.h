@@ -6,6 +6,15 @@
 
 #define ELD_WAVE 64
 
+// Kernel launch: the per-thread "last error" of the HIP runtime is shared with every other user of the runtime in the process
+// (PyTorch's own probes and event queries leave hipErrorNotReady / hipErrorNoDevice behind), so it is cleared right before
+// the launch; ELD_LAUNCH_CHECK() after it then reports this launch only.
+#define ELD_LAUNCH(...)                            \
+    do {                                           \
+        (void)hipGetLastError();                   \
+        hipLaunchKernelGGL(__VA_ARGS__);           \
+    } while (0)
+
 #define ELD_LAUNCH_CHECK()                         \
     do {                                           \
         hipError_t e__ = hipGetLastError();        \

@@ -94,10 +94,10 @@ static int launch_first_t(const float* x, const float* w, const float* bias, TO*
     if (tiles <= 0) return 0;
     const int grid = tiles < 2048 ? tiles : 2048;
     switch (Cin) {
-        case 1: hipLaunchKernelGGL((conv_first_fwd_kernel<1, TO>), dim3(grid), dim3(256), 0, st, x, w, bias, out, N, H, W, lrelu); break;
-        case 2: hipLaunchKernelGGL((conv_first_fwd_kernel<2, TO>), dim3(grid), dim3(256), 0, st, x, w, bias, out, N, H, W, lrelu); break;
-        case 3: hipLaunchKernelGGL((conv_first_fwd_kernel<3, TO>), dim3(grid), dim3(256), 0, st, x, w, bias, out, N, H, W, lrelu); break;
-        case 4: hipLaunchKernelGGL((conv_first_fwd_kernel<4, TO>), dim3(grid), dim3(256), 0, st, x, w, bias, out, N, H, W, lrelu); break;
+        case 1: ELD_LAUNCH((conv_first_fwd_kernel<1, TO>), dim3(grid), dim3(256), 0, st, x, w, bias, out, N, H, W, lrelu); break;
+        case 2: ELD_LAUNCH((conv_first_fwd_kernel<2, TO>), dim3(grid), dim3(256), 0, st, x, w, bias, out, N, H, W, lrelu); break;
+        case 3: ELD_LAUNCH((conv_first_fwd_kernel<3, TO>), dim3(grid), dim3(256), 0, st, x, w, bias, out, N, H, W, lrelu); break;
+        case 4: ELD_LAUNCH((conv_first_fwd_kernel<4, TO>), dim3(grid), dim3(256), 0, st, x, w, bias, out, N, H, W, lrelu); break;
         default: return ELD_ENOTSUP;
     }
     ELD_LAUNCH_CHECK();
@@ -224,14 +224,14 @@ static int launch_first_wgrad_t(const TG* g, const float* x, float* dw, float* d
     if (tiles <= 0) return 0;
     const int grid = tiles < FW_BLOCKS ? tiles : FW_BLOCKS;
     switch (Cin) {
-        case 1: hipLaunchKernelGGL((conv_first_wgrad_kernel<1, TG>), dim3(grid), dim3(256), 0, st, g, x, part, N, H, W); break;
-        case 2: hipLaunchKernelGGL((conv_first_wgrad_kernel<2, TG>), dim3(grid), dim3(256), 0, st, g, x, part, N, H, W); break;
-        case 3: hipLaunchKernelGGL((conv_first_wgrad_kernel<3, TG>), dim3(grid), dim3(256), 0, st, g, x, part, N, H, W); break;
-        case 4: hipLaunchKernelGGL((conv_first_wgrad_kernel<4, TG>), dim3(grid), dim3(256), 0, st, g, x, part, N, H, W); break;
+        case 1: ELD_LAUNCH((conv_first_wgrad_kernel<1, TG>), dim3(grid), dim3(256), 0, st, g, x, part, N, H, W); break;
+        case 2: ELD_LAUNCH((conv_first_wgrad_kernel<2, TG>), dim3(grid), dim3(256), 0, st, g, x, part, N, H, W); break;
+        case 3: ELD_LAUNCH((conv_first_wgrad_kernel<3, TG>), dim3(grid), dim3(256), 0, st, g, x, part, N, H, W); break;
+        case 4: ELD_LAUNCH((conv_first_wgrad_kernel<4, TG>), dim3(grid), dim3(256), 0, st, g, x, part, N, H, W); break;
         default: return ELD_ENOTSUP;
     }
     ELD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(conv_first_wgrad_reduce_kernel, dim3((2 * 32 * 32 + 32 + 255) / 256), dim3(256), 0, st, part, dw, db, grid, 9 * Cin);
+    ELD_LAUNCH(conv_first_wgrad_reduce_kernel, dim3((2 * 32 * 32 + 32 + 255) / 256), dim3(256), 0, st, part, dw, db, grid, 9 * Cin);
     ELD_LAUNCH_CHECK();
     return 0;
 }

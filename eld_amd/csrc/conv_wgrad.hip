@@ -319,7 +319,7 @@ static int launch_w(WgradArgs a, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
+    ELD_LAUNCH(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
     ELD_LAUNCH_CHECK();
     return 0;
 }
@@ -395,8 +395,8 @@ template <int SL>
 static void launch_red(const float* part, const float* bpart, float* wgrad, float* bgrad, int psplit, int T, int CA, int CBp, int CBr, hipStream_t st) {
     const size_t pairs = (size_t)CA * CBp;
     const unsigned blocks = (unsigned)((pairs + 4 * (64 / SL) - 1) / (4 * (64 / SL)));
-    if (T == 9) hipLaunchKernelGGL((wgrad_reduce_kernel<SL, 9>), dim3(blocks), dim3(256), 0, st, part, bpart, wgrad, bgrad, psplit, CA, CBp, CBr);
-    else hipLaunchKernelGGL((wgrad_reduce_kernel<SL, 4>), dim3(blocks), dim3(256), 0, st, part, bpart, wgrad, bgrad, psplit, CA, CBp, CBr);
+    if (T == 9) ELD_LAUNCH((wgrad_reduce_kernel<SL, 9>), dim3(blocks), dim3(256), 0, st, part, bpart, wgrad, bgrad, psplit, CA, CBp, CBr);
+    else ELD_LAUNCH((wgrad_reduce_kernel<SL, 4>), dim3(blocks), dim3(256), 0, st, part, bpart, wgrad, bgrad, psplit, CA, CBp, CBr);
 }
 
 int launch_wgrad_reduce(const float* part, const float* bpart, float* wgrad, float* bgrad, int psplit, int T, int CA,

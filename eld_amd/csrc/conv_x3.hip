@@ -514,7 +514,7 @@ int launch_x3(ConvArgs a, hipStream_t st) {
     if (per_cu < 1) per_cu = 1;
     long long grid = (long long)num_cus() * per_cu;
     if (grid > tiles) grid = tiles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, st, a);
+    ELD_LAUNCH(kern, dim3((unsigned)grid), dim3(256), lds_bytes, st, a);
     ELD_LAUNCH_CHECK();
     return 0;
 }
@@ -536,7 +536,7 @@ int launch_x3_gemm(ConvArgs a, hipStream_t st) {
     }
     long long grid = (long long)num_cus() * 2;
     if (grid > tiles) grid = tiles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds_bytes, st, a);
+    ELD_LAUNCH(kern, dim3((unsigned)grid), dim3(256), lds_bytes, st, a);
     ELD_LAUNCH_CHECK();
     return 0;
 }

@@ -149,6 +149,56 @@ __global__ __launch_bounds__(256) void illum_scale_kernel(const float* __restric
         out[base + i] = a * fminf(fmaxf(pred[base + i], 0.f), 1.f);
 }
 
+// ---- raw -> sRGB ISP: util/process.py:52-68 `process`, one pass: 16 B read + 12 B written per RGBG position.
+//      gains (15-19) -> clamp -> binning R, (G1+G2)/2, B (42-49) -> 3x3 CCM with j ascending (22-31) -> clamp -> gamma
+//      compression max(x,1e-8)^(1/gamma) (34-39) or piecewise-linear camera response (71-83) -> truncating 8-bit quantiser.
+//      The power is evaluated in double and rounded once (the correctly rounded float result): the reference's vectorised
+//      powf is within 1 ulp of it, which the truncating quantiser can turn into a +-1 code difference on isolated pixels.
+__device__ __forceinline__ float isp_quant(float v) {
+    int q = (int)(v * 255.0f);                                     // .int(): truncation toward zero
+    q = q < 0 ? 0 : (q > 255 ? 255 : q);
+    return (float)q / 255.0f;
+}
+
+__global__ __launch_bounds__(256) void isp_kernel(const float* __restrict__ bayer, const float* __restrict__ wbs, const float* __restrict__ ccms,
+                                                  float* __restrict__ out, size_t hw, float inv_gamma, const float* __restrict__ crf_E,
+                                                  const float* __restrict__ crf_f, int crf_n) {
+    const int n = blockIdx.y;
+    const float* wb = wbs + 4 * n;
+    const float* cm = ccms + 9 * n;
+    const float w0 = wb[0], w1 = wb[1], w2 = wb[2], w3 = wb[3];
+    float m[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) m[i] = cm[i];
+    const float* src = bayer + (size_t)n * 4 * hw;
+    float* dst = out + (size_t)n * 3 * hw;
+    const double ig = (double)inv_gamma;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (size_t)gridDim.x * 256) {
+        const float c0 = fminf(fmaxf(src[i] * w0, 0.f), 1.f), c1 = fminf(fmaxf(src[hw + i] * w1, 0.f), 1.f);
+        const float c2 = fminf(fmaxf(src[2 * hw + i] * w2, 0.f), 1.f), c3 = fminf(fmaxf(src[3 * hw + i] * w3, 0.f), 1.f);
+        const float r = c0, g = (c1 + c3) / 2.0f, b = c2;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = r * m[3 * c];
+            v = v + g * m[3 * c + 1];
+            v = v + b * m[3 * c + 2];
+            v = fminf(fmaxf(v, 0.f), 1.f);
+            float o;
+            if (crf_n > 0) {
+                int lo = 0, hi = crf_n;                              // searchsorted(E, v, 'left') - 1, clamped to [0, n-2]
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (crf_E[mid] < v) lo = mid + 1; else hi = mid; }
+                int ind = lo - 1;
+                ind = ind < 0 ? 0 : (ind > crf_n - 2 ? crf_n - 2 : ind);
+                const float slope = (crf_f[ind + 1] - crf_f[ind]) / (crf_E[ind + 1] - crf_E[ind]);
+                o = crf_f[ind] + slope * (v - crf_E[ind]);
+            } else {
+                o = (float)pow((double)fmaxf(v, 1e-8f), ig);
+            }
+            dst[c * hw + i] = isp_quant(o);
+        }
+    }
+}
+
 inline size_t qa_tiles(int H, int W) { return (size_t)((W - HALO + QA_TW - 1) / QA_TW) * ((H - HALO + QA_TH - 1) / QA_TH); }
 
 }  // namespace
@@ -168,11 +218,11 @@ extern "C" int eld_quality_assess(const float* est, const float* ref, double* ou
     double* ss = sq + (size_t)N * RED_BLOCKS;
     const int tiles_x = (W - HALO + QA_TW - 1) / QA_TW, tiles_y = (H - HALO + QA_TH - 1) / QA_TH;
     const size_t chw = (size_t)C * H * W;
-    hipLaunchKernelGGL(sqerr_kernel, dim3(RED_BLOCKS, N), dim3(256), 0, st, est, ref, sq, chw, data_range);
+    ELD_LAUNCH(sqerr_kernel, dim3(RED_BLOCKS, N), dim3(256), 0, st, est, ref, sq, chw, data_range);
     ELD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ssim_kernel, dim3(tiles_x * tiles_y, N * C), dim3(256), 0, st, est, ref, ss, H, W, tiles_x, tiles_y, data_range);
+    ELD_LAUNCH(ssim_kernel, dim3(tiles_x * tiles_y, N * C), dim3(256), 0, st, est, ref, ss, H, W, tiles_x, tiles_y, data_range);
     ELD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(qa_final_kernel, dim3(N), dim3(256), 0, st, sq, ss, out, C, tiles_x * tiles_y, chw, (size_t)(H - HALO) * (W - HALO), data_range);
+    ELD_LAUNCH(qa_final_kernel, dim3(N), dim3(256), 0, st, sq, ss, out, C, tiles_x * tiles_y, chw, (size_t)(H - HALO) * (W - HALO), data_range);
     ELD_LAUNCH_CHECK();
     return 0;
 }
@@ -187,11 +237,23 @@ extern "C" int eld_illuminance_correct(const float* predict, const float* source
     hipStream_t st = as_stream(stream);
     double* part = (double*)ws;
     float* alpha = (float*)(part + (size_t)N * RED_BLOCKS * 2);
-    hipLaunchKernelGGL(illum_dot_kernel, dim3(RED_BLOCKS, N), dim3(256), 0, st, predict, source, part, chw, source_N == 1 ? (size_t)0 : chw);
+    ELD_LAUNCH(illum_dot_kernel, dim3(RED_BLOCKS, N), dim3(256), 0, st, predict, source, part, chw, source_N == 1 ? (size_t)0 : chw);
     ELD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(illum_alpha_kernel, dim3(N), dim3(256), 0, st, part, alpha);
+    ELD_LAUNCH(illum_alpha_kernel, dim3(N), dim3(256), 0, st, part, alpha);
     ELD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(illum_scale_kernel, dim3(1024, N), dim3(256), 0, st, predict, alpha, out, chw);
+    ELD_LAUNCH(illum_scale_kernel, dim3(1024, N), dim3(256), 0, st, predict, alpha, out, chw);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int eld_isp_process(const float* bayer, const float* wbs, const float* ccms, float* out, int N, int H, int W, float gamma,
+                               const float* crf_E, const float* crf_f, int crf_n, void* stream) {
+    if (N == 0) return 0;
+    if (!bayer || !wbs || !ccms || !out || N < 0 || H < 1 || W < 1 || !(gamma > 0.f)) return ELD_EINVAL;
+    if (crf_n != 0 && (crf_n < 2 || !crf_E || !crf_f)) return ELD_EINVAL;
+    const size_t hw = (size_t)H * W;
+    const unsigned bx = (unsigned)((hw + 255) / 256 < 2048 ? (hw + 255) / 256 : 2048);
+    ELD_LAUNCH(isp_kernel, dim3(bx, N), dim3(256), 0, as_stream(stream), bayer, wbs, ccms, out, hw, (float)(1.0 / (double)gamma), crf_E, crf_f, crf_n);
     ELD_LAUNCH_CHECK();
     return 0;
 }

@@ -451,7 +451,7 @@ __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a)
 template <bool VEC, uint32_t TFLAGS, bool DEBUG>
 static int launch_noise(const NoiseArgs& a, int N, hipStream_t st) {
     dim3 grid((a.ngroups + GROUPS_PER_BLOCK - 1) / GROUPS_PER_BLOCK, N);
-    hipLaunchKernelGGL((noise_kernel<VEC, TFLAGS, DEBUG>), grid, dim3(NOISE_THREADS), 0, st, a);
+    ELD_LAUNCH((noise_kernel<VEC, TFLAGS, DEBUG>), grid, dim3(NOISE_THREADS), 0, st, a);
     ELD_LAUNCH_CHECK();
     return 0;
 }
@@ -516,7 +516,7 @@ extern "C" int eld_philox_words(uint32_t* out, uint32_t n, uint32_t index0, uint
     SamplerRng rng;
     rng.key.k0 = (uint32_t)seed; rng.key.k1 = (uint32_t)(seed >> 32);
     rng.sid_lo = (uint32_t)sample_id; rng.sid_hi = (uint32_t)(sample_id >> 32);
-    hipLaunchKernelGGL(philox_words_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream_h), out, n, index0, rng, stream, iter);
+    ELD_LAUNCH(philox_words_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream_h), out, n, index0, rng, stream, iter);
     ELD_LAUNCH_CHECK();
     return 0;
 }
@@ -553,8 +553,8 @@ static int bayer_launch(bool pack, const float* src, float* dst, int N, int h, i
     if (total == 0) return 0;
     if (!src || !dst) return ELD_EINVAL;
     const int blocks = (int)min((total + 255) / 256, (size_t)8192);
-    if (pack) hipLaunchKernelGGL(bayer_kernel<true>, dim3(blocks), dim3(256), 0, as_stream(stream), src, dst, N, h, w);
-    else hipLaunchKernelGGL(bayer_kernel<false>, dim3(blocks), dim3(256), 0, as_stream(stream), src, dst, N, h, w);
+    if (pack) ELD_LAUNCH(bayer_kernel<true>, dim3(blocks), dim3(256), 0, as_stream(stream), src, dst, N, h, w);
+    else ELD_LAUNCH(bayer_kernel<false>, dim3(blocks), dim3(256), 0, as_stream(stream), src, dst, N, h, w);
     ELD_LAUNCH_CHECK();
     return 0;
 }
@@ -594,7 +594,7 @@ extern "C" int eld_augment(const float* in, float* out, const int32_t* aug, int 
     if (!in || !out || !aug || in == out) return ELD_EINVAL;
     if (H != W) return ELD_ENOTSUP;                        // a batch with transposed members must stay rectangular-compatible
     dim3 grid((unsigned)min((chw + 255) / 256, (size_t)4096), N);
-    hipLaunchKernelGGL(augment_kernel, grid, dim3(256), 0, as_stream(stream), in, out, aug, C, H, W, flags);
+    ELD_LAUNCH(augment_kernel, grid, dim3(256), 0, as_stream(stream), in, out, aug, C, H, W, flags);
     ELD_LAUNCH_CHECK();
     return 0;
 }

@@ -24,7 +24,7 @@ __global__ void nchw_to_nhwc16_kernel(const float* __restrict__ x, float* __rest
 int launch_nchw_to_nhwc16(const float* x, float* y, int N, int C, int H, int W, hipStream_t st) {
     const size_t total = (size_t)N * H * W;
     if (!total) return 0;
-    hipLaunchKernelGGL(nchw_to_nhwc16_kernel, dim3((unsigned)min((total + 255) / 256, (size_t)16384)), dim3(256), 0, st, x, y, N, C, (size_t)H * W);
+    ELD_LAUNCH(nchw_to_nhwc16_kernel, dim3((unsigned)min((total + 255) / 256, (size_t)16384)), dim3(256), 0, st, x, y, N, C, (size_t)H * W);
     ELD_LAUNCH_CHECK();
     return 0;
 }
@@ -56,7 +56,7 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ in, float* __restri
 int launch_maxpool_fwd(const float* in, float* out, int N, int Ho, int Wo, int C, hipStream_t st) {
     const size_t total = (size_t)N * Ho * Wo * (C / 4);
     if (!total) return 0;
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)min((total + 255) / 256, (size_t)32768)), dim3(256), 0, st, in, out, N, Ho, Wo, C);
+    ELD_LAUNCH(maxpool_fwd_kernel, dim3((unsigned)min((total + 255) / 256, (size_t)32768)), dim3(256), 0, st, in, out, N, Ho, Wo, C);
     ELD_LAUNCH_CHECK();
     return 0;
 }
@@ -107,7 +107,7 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ act, const float* _
 int launch_maxpool_bwd(const float* act, const float* dp, const float* skip, float* g, int N, int Ho, int Wo, int C, hipStream_t st) {
     const size_t total = (size_t)N * Ho * Wo * (C / 4);
     if (!total) return 0;
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)min((total + 255) / 256, (size_t)32768)), dim3(256), 0, st, act, dp, skip, g, N, Ho, Wo, C);
+    ELD_LAUNCH(maxpool_bwd_kernel, dim3((unsigned)min((total + 255) / 256, (size_t)32768)), dim3(256), 0, st, act, dp, skip, g, N, Ho, Wo, C);
     ELD_LAUNCH_CHECK();
     return 0;
 }
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 int launch_head_fwd(const float* in, const float* w, const float* b, float* out, int N, int H, int W, int OC, hipStream_t st) {
     const size_t total = (size_t)N * H * W;
     if (!total) return 0;
-    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)min((total + 255) / 256, (size_t)16384)), dim3(256), 0, st, in, w, b, out, N, (size_t)H * W, OC);
+    ELD_LAUNCH(head_fwd_kernel, dim3((unsigned)min((total + 255) / 256, (size_t)16384)), dim3(256), 0, st, in, w, b, out, N, (size_t)H * W, OC);
     ELD_LAUNCH_CHECK();
     return 0;
 }
@@ -232,9 +232,9 @@ int launch_head_bwd(const float* dout, const float* act, const float* w, float* 
     const size_t total = (size_t)N * H * W;
     if (!total) return 0;
     const int nb = (int)min((total + 255) / 256, (size_t)HEAD_BLOCKS);
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(nb), dim3(256), 0, st, dout, act, w, g, part, N, (size_t)H * W, OC);
+    ELD_LAUNCH(head_bwd_kernel, dim3(nb), dim3(256), 0, st, dout, act, w, g, part, N, (size_t)H * W, OC);
     ELD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3((132 + 15) / 16), dim3(256), 0, st, part, dw, db, nb, OC);
+    ELD_LAUNCH(head_bwd_reduce_kernel, dim3((132 + 15) / 16), dim3(256), 0, st, part, dw, db, nb, OC);
     ELD_LAUNCH_CHECK();
     return 0;
 }
@@ -292,9 +292,9 @@ int launch_colsum(const float* x, float* out, float* part, size_t P, int C, hipS
     const int ppb = 256 / (C / 4);
     const int nb = (int)min((P + ppb - 1) / ppb, (size_t)COLSUM_BLOCKS);
     if (nb == 0) return 0;
-    hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, st, x, part, P, C);
+    ELD_LAUNCH(colsum_kernel, dim3(nb), dim3(256), 0, st, x, part, P, C);
     ELD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, out, nb, C);
+    ELD_LAUNCH(colsum_reduce_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, out, nb, C);
     ELD_LAUNCH_CHECK();
     return 0;
 }
@@ -328,7 +328,7 @@ __global__ void pack_kernel(const float* __restrict__ src, float* __restrict__ d
 
 int launch_pack(const float* src, float* dst, int kind, int Cout, int Cin, int Cinp, int T, hipStream_t st) {
     const size_t total = (size_t)T * Cout * (kind == PACK_CONV_FWD ? Cinp : Cin);
-    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, dst, kind, Cout, Cin, Cinp, T);
+    ELD_LAUNCH(pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, dst, kind, Cout, Cin, Cinp, T);
     ELD_LAUNCH_CHECK();
     return 0;
 }
@@ -371,7 +371,7 @@ int launch_pack_all(PackJobs& jobs, const float* params, float* ws, hipStream_t 
         blocks += (int)((total + 255) / 256);
     }
     if (!blocks) return 0;
-    hipLaunchKernelGGL(pack_all_kernel, dim3(blocks), dim3(256), 0, st, jobs, params, ws);
+    ELD_LAUNCH(pack_all_kernel, dim3(blocks), dim3(256), 0, st, jobs, params, ws);
     ELD_LAUNCH_CHECK();
     return 0;
 }
@@ -429,9 +429,9 @@ size_t l1_ws_floats() { return L1_BLOCKS; }
 int launch_l1(const float* out, const float* tgt, float* dout, float* loss, float* part, size_t n, float grad_scale, hipStream_t st) {
     if (n == 0) return ELD_EINVAL;
     const int nb = (int)min((n / 4 + 255) / 256 + 1, (size_t)L1_BLOCKS);
-    hipLaunchKernelGGL(l1_kernel, dim3(nb), dim3(256), 0, st, out, tgt, dout, part, n, grad_scale / (float)n);
+    ELD_LAUNCH(l1_kernel, dim3(nb), dim3(256), 0, st, out, tgt, dout, part, n, grad_scale / (float)n);
     ELD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(l1_reduce_kernel, dim3(1), dim3(256), 0, st, part, loss, nb, 1.0f / (float)n);
+    ELD_LAUNCH(l1_reduce_kernel, dim3(1), dim3(256), 0, st, part, loss, nb, 1.0f / (float)n);
     ELD_LAUNCH_CHECK();
     return 0;
 }
@@ -461,7 +461,7 @@ int launch_adam(float* p, const float* g, float* m, float* v, size_t n, double l
     if (!n) return 0;
     const double bc1 = 1.0 - pow(b1, (double)step);
     const double bc2 = 1.0 - pow(b2, (double)step);
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n, (float)(lr / bc1), (float)b1,
+    ELD_LAUNCH(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, g, m, v, n, (float)(lr / bc1), (float)b1,
                        (float)b2, (float)eps, (float)wd, (float)sqrt(bc2), (float)gscale);
     ELD_LAUNCH_CHECK();
     return 0;
@@ -494,7 +494,7 @@ __global__ void maxpool_fwd_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* _
 int launch_maxpool_fwd_bf16(const bf16_t* in, bf16_t* out, int N, int Ho, int Wo, int C, hipStream_t st) {
     const size_t total = (size_t)N * Ho * Wo * (C / 4);
     if (!total) return 0;
-    hipLaunchKernelGGL(maxpool_fwd_bf16_kernel, dim3((unsigned)min((total + 255) / 256, (size_t)32768)), dim3(256), 0, st, in, out, N, Ho, Wo, C);
+    ELD_LAUNCH(maxpool_fwd_bf16_kernel, dim3((unsigned)min((total + 255) / 256, (size_t)32768)), dim3(256), 0, st, in, out, N, Ho, Wo, C);
     ELD_LAUNCH_CHECK();
     return 0;
 }
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const bf16_t* __rest
 int launch_head_fwd_bf16(const bf16_t* in, const float* w, const float* b, float* out, int N, int H, int W, int OC, hipStream_t st) {
     const size_t total = (size_t)N * H * W;
     if (!total) return 0;
-    hipLaunchKernelGGL(head_fwd_bf16_kernel, dim3((unsigned)min((total + 255) / 256, (size_t)16384)), dim3(256), 0, st, in, w, b, out, N, (size_t)H * W, OC);
+    ELD_LAUNCH(head_fwd_bf16_kernel, dim3((unsigned)min((total + 255) / 256, (size_t)16384)), dim3(256), 0, st, in, w, b, out, N, (size_t)H * W, OC);
     ELD_LAUNCH_CHECK();
     return 0;
 }
@@ -569,7 +569,7 @@ __global__ void maxpool_bwd_bf16_kernel(const bf16_t* __restrict__ act, const bf
 int launch_maxpool_bwd_bf16(const bf16_t* act, const bf16_t* dp, const bf16_t* skip, bf16_t* g, int N, int Ho, int Wo, int C, hipStream_t st) {
     const size_t total = (size_t)N * Ho * Wo * (C / 4);
     if (!total) return 0;
-    hipLaunchKernelGGL(maxpool_bwd_bf16_kernel, dim3((unsigned)min((total + 255) / 256, (size_t)32768)), dim3(256), 0, st, act, dp, skip, g, N, Ho, Wo, C);
+    ELD_LAUNCH(maxpool_bwd_bf16_kernel, dim3((unsigned)min((total + 255) / 256, (size_t)32768)), dim3(256), 0, st, act, dp, skip, g, N, Ho, Wo, C);
     ELD_LAUNCH_CHECK();
     return 0;
 }
@@ -633,9 +633,9 @@ int launch_head_bwd_bf16(const float* dout, const bf16_t* act, const float* w, b
     const size_t total = (size_t)N * H * W;
     if (!total) return 0;
     const int nb = (int)min((total + 255) / 256, (size_t)HEAD_BLOCKS);
-    hipLaunchKernelGGL(head_bwd_bf16_kernel, dim3(nb), dim3(256), 0, st, dout, act, w, g, part, N, (size_t)H * W, OC);
+    ELD_LAUNCH(head_bwd_bf16_kernel, dim3(nb), dim3(256), 0, st, dout, act, w, g, part, N, (size_t)H * W, OC);
     ELD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(head_bwd_reduce_kernel, dim3((132 + 15) / 16), dim3(256), 0, st, part, dw, db, nb, OC);
+    ELD_LAUNCH(head_bwd_reduce_kernel, dim3((132 + 15) / 16), dim3(256), 0, st, part, dw, db, nb, OC);
     ELD_LAUNCH_CHECK();
     return 0;
 }
@@ -675,9 +675,9 @@ int launch_colsum_bf16(const bf16_t* x, float* out, float* part, size_t P, int C
     const int ppb = 256 / (C / 4);
     const int nb = (int)min((P + ppb - 1) / ppb, (size_t)COLSUM_BLOCKS);
     if (nb == 0) return 0;
-    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(nb), dim3(256), 0, st, x, part, P, C);
+    ELD_LAUNCH(colsum_bf16_kernel, dim3(nb), dim3(256), 0, st, x, part, P, C);
     ELD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, out, nb, C);
+    ELD_LAUNCH(colsum_reduce_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, out, nb, C);
     ELD_LAUNCH_CHECK();
     return 0;
 }

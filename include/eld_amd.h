@@ -178,6 +178,12 @@ size_t eld_illuminance_correct_workspace_bytes(int N);
 int eld_illuminance_correct(const float* predict, const float* source, float* out, void* ws, size_t ws_bytes, int N, int source_N,
                             size_t chw, void* stream);
 
+/* util/process.py:52-68 `process`: bayer (N,4,H,W) RGBG in [0,1] -> out (N,3,H,W) sRGB, quantised to
+ * k/255.  wbs (N,4), ccms (N,3,3) row-major, all device float32.  crf_n = 0: gamma compression with 1/gamma; crf_n >= 2:
+ * camera response by piecewise-linear interpolation of (crf_E, crf_f), ascending crf_E (torchinterp1d's rule). */
+int eld_isp_process(const float* bayer, const float* wbs, const float* ccms, float* out, int N, int H, int W, float gamma,
+                    const float* crf_E, const float* crf_f, int crf_n, void* stream);
+
 /* ---- single layers on NHWC float32 tensors with reference-layout weights; used by the parity tests ---- */
 size_t eld_layer_workspace_bytes(int N, int H, int W, int Cin, int Cout);
 /* out = [lrelu](conv3x3(cat[in0,in1]) + bias).  nn.Conv2d(k=3,p=1) + torch.max(0.2x,x)  (Unet.py:11-44,102-104) */

@@ -90,15 +90,36 @@ class FakeLMDB:
         return self.records[int(key.decode('ascii'))]
 
 
+def mint_isp():
+    """tests/golden/isp.npz: util/process.py:52-68 `process` (gamma branch) of the reference on seeded RGBG batches."""
+    import torch
+    import util.process as ref_process
+    rng = np.random.RandomState(77)
+    cases = {}
+    for name, shape in (('a', (2, 4, 24, 40)), ('b', (1, 4, 7, 129)), ('c', (3, 4, 16, 16))):
+        bayer = (rng.rand(*shape) ** 2.0 * 1.2 - 0.05).astype(np.float32)          # some values outside [0,1]
+        wb = np.stack([np.array([rng.uniform(1.5, 2.5), 1.0, rng.uniform(1.2, 2.0), 1.0], np.float32) for _ in range(shape[0])])
+        ccm = np.stack([(np.eye(3) + rng.uniform(-0.3, 0.3, (3, 3))).astype(np.float32) for _ in range(shape[0])])
+        ccm /= ccm.sum(axis=2, keepdims=True)
+        out = ref_process.process(torch.from_numpy(bayer), torch.from_numpy(wb), torch.from_numpy(ccm), gamma=2.2, CRF=None).numpy()
+        cases.update({name + '_bayer': bayer, name + '_wb': wb, name + '_ccm': ccm.astype(np.float32), name + '_out': out})
+    np.savez_compressed(os.path.join(GOLD, 'isp.npz'), torch_version=torch.__version__, **cases)
+    print('isp golden written')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', default='/root/reference')
+    ap.add_argument('--only', default='', help="'isp': mint only tests/golden/isp.npz")
     args = ap.parse_args()
     ref = os.path.abspath(args.ref)
     os.makedirs(GOLD, exist_ok=True)
     os.chdir(ref)                       # noise.py:187 loads camera_params relative to CWD
     sys.path.insert(0, ref)
     sys.path.insert(0, ROOT)
+    if args.only == 'isp':
+        install_stubs()
+        return mint_isp()
     import noise as ref_noise           # the reference module itself
     from oracle import noise_ref as O
 
@@ -244,6 +265,7 @@ def main():
                         loss=float(loss), names=np.array(names), gsum=np.array(gsum), gabs=np.array(gabs),
                         wsum=np.array(wsum), torch_version=torch.__version__,
                         **{'grad_' + k.replace('.', '__'): v for k, v in keep.items()})
+    mint_isp()
     print('golden vectors written to', GOLD)
 
 
