@@ -211,6 +211,28 @@ def main():
                            'traffic': (round(traffic['unet_conv_bytes_per_pass'] * B / traffic.get('frames_per_pass', 1)) if traffic and full_frame and args.precision == 'fp32' and 'unet_conv_bytes_per_pass' in traffic else None),
                            'fwd_ms': round(t_f, 3), 'bwd_ms': round(t_b, 3),
                            'fwd_tflops': round(FLOP_FWD_PER_PIX * B * 4.0 * Hh * Ww / (t_f * 1e-3) / 1e12, 2)}
+        # one launch of the dominant kernel, timed live: conv7_1's forward (256 -> 128 channels at 1/4 resolution, the step's
+        # median 3x3 layer) through the single-layer entry point -- conv_x3_kernel<64,2> (or conv_igemm_kernel<float,0,64,2>)
+        if args.precision == 'fp32' and Hh % 4 == 0 and Ww % 4 == 0:
+            lib = eld_amd.load_library()
+            h4, w4, ci, co = Hh // 4, Ww // 4, 256, 128
+            xl = torch.randn(B, h4, w4, ci, device=dev)
+            wl = torch.randn(co, ci, 3, 3, device=dev) * 0.02
+            bl = torch.zeros(co, device=dev)
+            ol = torch.empty(B, h4, w4, co, device=dev)
+            wsl = torch.empty(lib.eld_layer_workspace_bytes(B, h4, w4, ci, co), dtype=torch.uint8, device=dev)
+
+            def one():
+                L.check(lib.eld_conv3x3_forward(L.dptr(xl), ci, None, 0, L.dptr(wl), L.dptr(bl), L.dptr(ol), B, h4, w4, co, 1, L.dptr(wsl), wsl.numel(),
+                                                L.cur_stream()), 'eld_conv3x3_forward')
+            one(); torch.cuda.synchronize()
+            t_l = timed_events(one, 5)
+            fl = 2.0 * B * h4 * w4 * co * ci * 9
+            res['roofline']['per_launch'] = {'kernel': ('conv_x3_kernel<64, 2, true>' if x3 else 'conv_igemm_kernel<float, 0, 64, 2>') +
+                                             ' (+ its 50 us weight-pack launch): conv7_1 forward, %d x %dx%d, 256 -> 128 channels' % (B, h4, w4),
+                                             'algorithmic_gflop': round(fl / 1e9, 1), 'ms': round(t_l, 4), 'achieved': round(fl / (t_l * 1e-3) / 1e12, 2),
+                                             'frac': round(fl / (t_l * 1e-3) / 1e12 / peak, 4)}
+            del xl, wl, ol, wsl
         # sampler alone (HBM-bound: 8 B per raw pixel), batch of 8 resident images
         nb = 8
         yb = synth_clean(nb, Hh, Ww, dev, seed=99)

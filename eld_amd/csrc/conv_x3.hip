@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
             const bool last_chunk = c0 + CK >= Cin;
 #pragma unroll 1
             for (int ky = 0; ky < 3; ++ky) {
+                __builtin_amdgcn_s_setprio(3);   // the short staging section goes ahead of the co-resident workgroup's MFMA stream
                 __syncthreads();                 // every wave is done with the previous stage's operands
                 if (ky == 0 && !(a.dbg & 16)) store_A();
                 if (!(a.dbg & 8)) store_B();
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
                 }
                 if (a.dbg & 2) continue;
                 uint4 fx[DB ? 2 : 1][3][RPW], fw[DB ? 2 : 1][3][NT];
+                __builtin_amdgcn_s_setprio(0);
                 auto read_tap = [&](int kx, uint4 (&X)[3][RPW], uint4 (&Wt)[3][NT]) {
 #pragma unroll
                     for (int r = 0; r < RPW; ++r) {
@@ -205,15 +207,19 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
                         const int cur = kx & 1;
                         if (kx + 1 < 3) read_tap(kx + 1, fx[cur ^ 1], fw[cur ^ 1]);
                         __builtin_amdgcn_sched_barrier(0);
-                        // six piece products, smallest first; the accumulators of the wave rotate inside each product
+                        // six piece products per (row, channel block), smallest first.  The pixel operand is held for up to six
+                        // consecutive MFMAs (fewer operand-bus toggles: these kernels run at the power limit) while the two
+                        // accumulators of the row alternate.
 #pragma unroll
-                        for (int q = 0; q < 6; ++q)
+                        for (int r = 0; r < RPW; ++r)
 #pragma unroll
-                            for (int r = 0; r < RPW; ++r)
+                            for (int j = 2; j >= 0; --j)
 #pragma unroll
-                                for (int tt = 0; tt < NT; ++tt)
-                                    acc[r][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[cur][WI[q]][tt]),
-                                                                                         __builtin_bit_cast(bf16x8, fx[cur][XI[q]][r]), acc[r][tt], 0, 0, 0);
+                                for (int i = 0; i + j <= 2; ++i)
+#pragma unroll
+                                    for (int tt = 0; tt < NT; ++tt)
+                                        acc[r][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[cur][i][tt]),
+                                                                                             __builtin_bit_cast(bf16x8, fx[cur][j][r]), acc[r][tt], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 } else {                         // register budget: one fragment set, the compiler interleaves reads and MFMAs
@@ -512,7 +518,8 @@ int launch_x3(ConvArgs a, hipStream_t st) {
     int per_cu = (int)((160 * 1024) / lds_bytes);
     if (per_cu > 2) per_cu = 2;
     if (per_cu < 1) per_cu = 1;
-    long long grid = (long long)num_cus() * per_cu;
+    if (a.dbg & 64) per_cu = 1;
+    long long grid = (long long)num_cus() * per_cu * ((a.dbg & 128) ? 2 : 1);
     if (grid > tiles) grid = tiles;
     ELD_LAUNCH(kern, dim3((unsigned)grid), dim3(256), lds_bytes, st, a);
     ELD_LAUNCH_CHECK();
