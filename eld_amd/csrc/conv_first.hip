@@ -202,12 +202,24 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const TG* __restr
     }
 }
 
-// dW[co][k] (OIHW, k < K) and db[co] from the per-workgroup partials, fixed order
-__global__ void conv_first_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nblocks, int K) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;        // 0 .. 32*64 + 32
-    if (t >= 2 * 32 * 32 + 32) return;
+// dW[co][k] (OIHW, k < K) and db[co] from the per-workgroup partials, fixed order: 16 outputs x 16 partial slices per
+// workgroup, 4 loads in flight per lane, slices combined through LDS
+__global__ __launch_bounds__(256) void conv_first_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nblocks, int K) {
+    constexpr int NOUT = 2 * 32 * 32 + 32;
+    __shared__ float sh[16][16];
+    const int tl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int t = blockIdx.x * 16 + tl;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * (2 * 32 * 32 + 32) + t];
+    if (t < NOUT) {
+        int b = sl;
+        for (; b + 48 < nblocks; b += 64)
+            s += (part[(size_t)b * NOUT + t] + part[(size_t)(b + 16) * NOUT + t]) + (part[(size_t)(b + 32) * NOUT + t] + part[(size_t)(b + 48) * NOUT + t]);
+        for (; b < nblocks; b += 16) s += part[(size_t)b * NOUT + t];
+    }
+    sh[sl][tl] = s;
+    __syncthreads();
+    if (sl != 0 || t >= NOUT) return;
+    for (int k = 1; k < 16; ++k) s += sh[k][tl];
     if (t < 2 * 32 * 32) {
         const int jt = t / 1024, co = (t / 32) % 32, j = jt * 32 + (t % 32);
         if (j < K) dw[co * K + j] = s;
@@ -231,7 +243,7 @@ static int launch_first_wgrad_t(const TG* g, const float* x, float* dw, float* d
         default: return ELD_ENOTSUP;
     }
     ELD_LAUNCH_CHECK();
-    ELD_LAUNCH(conv_first_wgrad_reduce_kernel, dim3((2 * 32 * 32 + 32 + 255) / 256), dim3(256), 0, st, part, dw, db, grid, 9 * Cin);
+    ELD_LAUNCH(conv_first_wgrad_reduce_kernel, dim3((2 * 32 * 32 + 32 + 15) / 16), dim3(256), 0, st, part, dw, db, grid, 9 * Cin);
     ELD_LAUNCH_CHECK();
     return 0;
 }

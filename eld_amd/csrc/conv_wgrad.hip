@@ -348,33 +348,65 @@ int launch_wgrad(const WgradArgs& a, int mode, hipStream_t st) {
     return ELD_EINVAL;
 }
 
-// out[(i*CBr + j)*T + tap] = sum_s part[s][tap][i][j].  One lane group (SL lanes) per (i, j) pair: slice k of the group
-// sums partials k, k+SL, ... for all T taps, slices are combined by a fixed xor-shuffle tree (fixed order -> run-to-run
-// bit-stable), and lane 0 of the group writes the pair's T consecutive outputs (reads coalesced along j, writes
-// contiguous per pair instead of a 4-byte scatter at stride T).
-template <int SL, int T>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart, float* __restrict__ wgrad,
-                                                           float* __restrict__ bgrad, int psplit, int CA, int CBp, int CBr) {
-    constexpr int PPW = 64 / SL;                 // (i,j) pairs per wave
+// out[(i*CBr + j)*T + tap] = sum_s part[s][tap][i][j];  bgrad[i] = sum_s bpart[s][i].
+// A workgroup = 64 consecutive (i, j) pairs (lanes: coalesced 256-byte reads along j) x NW waves; wave w sums the partials
+// w, w + NW, ... for all T taps with 4 loads in flight, the waves are combined through LDS in a fixed order (run-to-run
+// bit-stable), and wave 0 writes the pair's T consecutive outputs.  The last ceil(CA/64) workgroups do the bias sums the
+// same way.
+template <int T>
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart, float* __restrict__ wgrad,
+                                                            float* __restrict__ bgrad, int psplit, int CA, int CBp, int CBr, int pair_blocks) {
+    extern __shared__ float sh[];                 // [NW][T][64]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, NW = blockDim.x >> 6;
     const size_t pairs = (size_t)CA * CBp, plane = pairs * T;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int p_in_wave = lane % PPW, slice = lane / PPW;
-    const size_t pr = ((size_t)blockIdx.x * 4 + wave) * PPW + p_in_wave;
+    if ((int)blockIdx.x >= pair_blocks) {         // bias block: 64 channels
+        const int c = ((int)blockIdx.x - pair_blocks) * 64 + lane;
+        float b = 0.f;
+        if (c < CA) {
+            int k = w;
+            for (; k + 3 * NW < psplit; k += 4 * NW)
+                b += (bpart[(size_t)k * CA + c] + bpart[(size_t)(k + NW) * CA + c]) + (bpart[(size_t)(k + 2 * NW) * CA + c] + bpart[(size_t)(k + 3 * NW) * CA + c]);
+            for (; k < psplit; k += NW) b += bpart[(size_t)k * CA + c];
+        }
+        sh[w * 64 + lane] = b;
+        __syncthreads();
+        if (w == 0 && c < CA) {
+            for (int ww = 1; ww < NW; ++ww) b += sh[ww * 64 + lane];
+            bgrad[c] = b;
+        }
+        return;
+    }
+    const size_t pr = (size_t)blockIdx.x * 64 + lane;
     float s[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) s[t] = 0.f;
     if (pr < pairs) {
-        for (int k = slice; k < psplit; k += SL) {
-            const float* p = part + (size_t)k * plane + pr;
+        int k = w;
+        for (; k + NW < psplit; k += 2 * NW) {
+            const float* p0 = part + (size_t)k * plane + pr;
+            const float* p1 = part + (size_t)(k + NW) * plane + pr;
+            float a[T], b[T];
 #pragma unroll
-            for (int t = 0; t < T; ++t) s[t] += p[(size_t)t * pairs];
+            for (int t = 0; t < T; ++t) { a[t] = p0[(size_t)t * pairs]; b[t] = p1[(size_t)t * pairs]; }
+#pragma unroll
+            for (int t = 0; t < T; ++t) s[t] += a[t] + b[t];
+        }
+        for (; k < psplit; k += NW) {
+            const float* p0 = part + (size_t)k * plane + pr;
+#pragma unroll
+            for (int t = 0; t < T; ++t) s[t] += p0[(size_t)t * pairs];
         }
     }
+    if (NW > 1) {
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+        for (int t = 0; t < T; ++t) sh[(w * T + t) * 64 + lane] = s[t];
+        __syncthreads();
+        if (w == 0)
+            for (int ww = 1; ww < NW; ++ww)
 #pragma unroll
-        for (int off = PPW; off < 64; off <<= 1) s[t] += __shfl_xor(s[t], off, 64);
-    if (slice == 0 && pr < pairs) {
+                for (int t = 0; t < T; ++t) s[t] += sh[(ww * T + t) * 64 + lane];
+    }
+    if (w == 0 && pr < pairs) {
         const int j = (int)(pr % CBp), i = (int)(pr / CBp);
         if (j < CBr) {
             float* o = wgrad + ((size_t)i * CBr + j) * T;
@@ -382,29 +414,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
             for (int t = 0; t < T; ++t) o[t] = s[t];
         }
     }
-    if (bgrad && blockIdx.x == 0) {
-        for (int c = threadIdx.x; c < CA; c += 256) {
-            float b = 0.f;
-            for (int k = 0; k < psplit; ++k) b += bpart[(size_t)k * CA + c];
-            bgrad[c] = b;
-        }
-    }
-}
-
-template <int SL>
-static void launch_red(const float* part, const float* bpart, float* wgrad, float* bgrad, int psplit, int T, int CA, int CBp, int CBr, hipStream_t st) {
-    const size_t pairs = (size_t)CA * CBp;
-    const unsigned blocks = (unsigned)((pairs + 4 * (64 / SL) - 1) / (4 * (64 / SL)));
-    if (T == 9) ELD_LAUNCH((wgrad_reduce_kernel<SL, 9>), dim3(blocks), dim3(256), 0, st, part, bpart, wgrad, bgrad, psplit, CA, CBp, CBr);
-    else ELD_LAUNCH((wgrad_reduce_kernel<SL, 4>), dim3(blocks), dim3(256), 0, st, part, bpart, wgrad, bgrad, psplit, CA, CBp, CBr);
 }
 
 int launch_wgrad_reduce(const float* part, const float* bpart, float* wgrad, float* bgrad, int psplit, int T, int CA,
                         int CBp, int CBr, hipStream_t st) {
     if (T != 9 && T != 4) return ELD_EINVAL;
-    if (psplit >= 64) launch_red<16>(part, bpart, wgrad, bgrad, psplit, T, CA, CBp, CBr, st);
-    else if (psplit >= 8) launch_red<4>(part, bpart, wgrad, bgrad, psplit, T, CA, CBp, CBr, st);
-    else launch_red<1>(part, bpart, wgrad, bgrad, psplit, T, CA, CBp, CBr, st);
+    int NW = 1;
+    while (NW < 16 && NW < psplit) NW <<= 1;
+    const size_t pairs = (size_t)CA * CBp;
+    const int pair_blocks = (int)((pairs + 63) / 64);
+    const int blocks = pair_blocks + (bgrad ? (CA + 63) / 64 : 0);
+    const size_t lds = (size_t)NW * T * 64 * sizeof(float);
+    if (T == 9) ELD_LAUNCH((wgrad_reduce_kernel<9>), dim3(blocks), dim3(64 * NW), lds, st, part, bpart, wgrad, bgrad, psplit, CA, CBp, CBr, pair_blocks);
+    else ELD_LAUNCH((wgrad_reduce_kernel<4>), dim3(blocks), dim3(64 * NW), lds, st, part, bpart, wgrad, bgrad, psplit, CA, CBp, CBr, pair_blocks);
     ELD_LAUNCH_CHECK();
     return 0;
 }

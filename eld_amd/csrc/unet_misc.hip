@@ -273,16 +273,24 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     }
 }
 
-// one wave per 4 channels: 16 lanes per channel split the partials, fixed xor-shuffle tree (deterministic)
-__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nblocks, int C) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = (blockIdx.x * 4 + wave) * 4 + (lane & 3), slice = lane >> 2;
+// 64 channels per workgroup (lanes) x 16 waves over the per-block partials, 4 loads in flight, fixed-order LDS combine
+__global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int nblocks, int C) {
+    __shared__ float sh[16 * 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
-    if (c < C)
-        for (int b = slice; b < nblocks; b += 16) s += part[(size_t)b * C + c];
-#pragma unroll
-    for (int off = 4; off < 64; off <<= 1) s += __shfl_xor(s, off, 64);
-    if (slice == 0 && c < C) out[c] = s;
+    if (c < C) {
+        int b = w;
+        for (; b + 48 < nblocks; b += 64)
+            s += (part[(size_t)b * C + c] + part[(size_t)(b + 16) * C + c]) + (part[(size_t)(b + 32) * C + c] + part[(size_t)(b + 48) * C + c]);
+        for (; b < nblocks; b += 16) s += part[(size_t)b * C + c];
+    }
+    sh[w * 64 + lane] = s;
+    __syncthreads();
+    if (w == 0 && c < C) {
+        for (int ww = 1; ww < 16; ++ww) s += sh[ww * 64 + lane];
+        out[c] = s;
+    }
 }
 
 size_t colsum_ws_floats(int C) { return (size_t)COLSUM_BLOCKS * C; }
@@ -294,7 +302,7 @@ int launch_colsum(const float* x, float* out, float* part, size_t P, int C, hipS
     if (nb == 0) return 0;
     ELD_LAUNCH(colsum_kernel, dim3(nb), dim3(256), 0, st, x, part, P, C);
     ELD_LAUNCH_CHECK();
-    ELD_LAUNCH(colsum_reduce_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, out, nb, C);
+    ELD_LAUNCH(colsum_reduce_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, part, out, nb, C);
     ELD_LAUNCH_CHECK();
     return 0;
 }
@@ -677,7 +685,7 @@ int launch_colsum_bf16(const bf16_t* x, float* out, float* part, size_t P, int C
     if (nb == 0) return 0;
     ELD_LAUNCH(colsum_bf16_kernel, dim3(nb), dim3(256), 0, st, x, part, P, C);
     ELD_LAUNCH_CHECK();
-    ELD_LAUNCH(colsum_reduce_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, out, nb, C);
+    ELD_LAUNCH(colsum_reduce_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, part, out, nb, C);
     ELD_LAUNCH_CHECK();
     return 0;
 }
