@@ -384,3 +384,46 @@ def test_bf16x3_is_as_accurate_as_fp32_mfma(lib):
     (m0, r0), (m1, r1) = errs
     assert m1 < 3e-5 and r1 < 2e-6, errs          # O(1) outputs up to |4|, K = 4608
     assert r1 <= 1.5 * r0 + 1e-8 and m1 <= 2.0 * m0 + 1e-8, errs
+
+
+def test_unet_full_frame_properties(lib):
+    """BASELINE.json configs[1] size (1 x 4 x 1424 x 2128), where the fp64 oracle is out of reach: size-independent properties.
+      * crop consistency: away from the crop border (beyond the receptive field) the output of a 16-aligned 512x512 crop
+        equals the full-frame output (the result must not depend on tile position / image size);
+      * the two fp32 product schemes (fp32 MFMA, 3-piece bf16 split) agree within the fp32 tolerance on the whole frame;
+      * the backward is linear in dout and its bias gradient of the head is the plain sum of dout (a checksum of checksums)."""
+    from eld_amd.unet import UNetSeeInDark
+    torch.manual_seed(5)
+    net = UNetSeeInDark(4, 4).cuda()
+    g = torch.Generator(device='cuda').manual_seed(9)
+    H, W = 1424, 2128
+    x = torch.rand(1, 4, H, W, device='cuda', generator=g)
+    prev = lib.eld_conv_fp32_algo(-1)
+    try:
+        lib.eld_conv_fp32_algo(1)
+        with torch.no_grad():
+            full = net(x)
+            y0, x0 = 448, 800
+            crop = net(x[:, :, y0:y0 + 512, x0:x0 + 512].contiguous())
+        m = 200                                              # > receptive-field radius of the 5-scale U-Net
+        a, b = full[:, :, y0 + m:y0 + 512 - m, x0 + m:x0 + 512 - m], crop[:, :, m:512 - m, m:512 - m]
+        assert float((a - b).abs().max()) <= 1e-6
+        lib.eld_conv_fp32_algo(0)
+        with torch.no_grad():
+            full_mfma = net(x)
+        assert float((full - full_mfma).abs().max()) <= 1e-5 * (1.0 + float(full.abs().max()))
+        lib.eld_conv_fp32_algo(1)
+        out, key, _ = net._engine_forward(x, save=True)
+        d1 = torch.randn(1, 4, H, W, device='cuda', generator=g) / (4.0 * H * W)
+        d2 = torch.randn(1, 4, H, W, device='cuda', generator=g) / (4.0 * H * W)
+        g1 = net._engine_backward(d1, key, tuple(x.shape)).clone()
+        g2 = net._engine_backward(d2, key, tuple(x.shape)).clone()
+        g12 = net._engine_backward((d1 + d2).contiguous(), key, tuple(x.shape)).clone()
+        scale = float(torch.maximum(g1.abs(), g2.abs()).max())
+        assert float((g12 - (g1 + g2)).abs().max()) <= 2e-5 * scale
+        offs = net._offsets
+        head_bias = g12[offs[-2]:offs[-1]]                   # conv10_1.bias: d loss / d bias[c] = sum of dout[:, c]
+        ref = (d1 + d2).double().sum(dim=(0, 2, 3)).float()
+        assert float((head_bias - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-9
+    finally:
+        lib.eld_conv_fp32_algo(prev)
