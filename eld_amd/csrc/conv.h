@@ -36,6 +36,7 @@ struct ConvArgs {
     int tiles_x, tiles_y;
     int dtype;          // DT_F32 / DT_BF16
     int dbg;            // ablation switches for tools/ (env ELD_CONV_DBG): 1 skip epilogue, 2 skip MFMA, 4 skip staging loads
+    unsigned long long* prof;   // dev tool (eld_debug_conv_prof): per-stage s_memtime stamps of the first workgroups; null in production
 };
 
 // d/dx max(0.2x, x) as autograd computes it for torch.max(0.2*x, x) (models/arch/Unet.py:102-104):
@@ -62,6 +63,7 @@ int launch_conv(const ConvArgs& a, int mode, hipStream_t st);
 // set < 0 only queries.  Initial value from env ELD_FP32_CONV (mfma | x3).  Returns the value in force before the call.
 int conv_fp32_algo(int set);
 int launch_conv_x3(const ConvArgs& a, hipStream_t st);
+void conv_x3_set_prof(unsigned long long* buf);      // dev tool: 8 workgroups x 4 waves x 128 stages x 6 stamps
 int launch_conv_x3_gemm(const ConvArgs& a, int mode, hipStream_t st);      // transposed-conv directions; ELD_ENOTSUP if not covered
 
 // dW-type reduction:  P[tap][i][j] = sum_pixels G[pixel][i] * X[pixel (+) tap][j]

@@ -134,16 +134,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
     };
 
     int t = blockIdx.x;
+    int pstage = 0;
     if (t >= total_tiles) return;
-    // The two workgroups of a CU run the same (stage skeleton -> MFMA phase) cycle; started together they stay in lockstep
-    // (both stage, then both contend for the matrix pipe).  The second wave of workgroups starts half a period late so that
-    // one stages while the other feeds the pipe.
-    const int stag_mode = (a.dbg >> 16) & 3;
-    const bool late = stag_mode == 0 ? blockIdx.x >= (gridDim.x >> 1) : (stag_mode == 1 ? ((blockIdx.x >> 3) & 1) : (stag_mode == 2 ? (blockIdx.x & 1) : ((blockIdx.x >> 8) & 1)));
-    if (late) {
-        const int n = (a.dbg >> 8) & 0xFF;
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
-    }
     setup_load(t);
     load_A(0);
     {
@@ -168,10 +160,17 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
 #pragma unroll 1
             for (int ky = 0; ky < 3; ++ky) {
                 __builtin_amdgcn_s_setprio(3);   // the short staging section goes ahead of the co-resident workgroup's MFMA stream
+                unsigned long long* pf = nullptr;
+                if (a.prof && blockIdx.x < 8 && lane == 0 && pstage < 128) pf = a.prof + (((size_t)blockIdx.x * 4 + wave) * 128 + pstage) * 6;
+                ++pstage;
+                if (pf) pf[0] = __builtin_amdgcn_s_memtime();
                 __syncthreads();                 // every wave is done with the previous stage's operands
+                if (pf) pf[1] = __builtin_amdgcn_s_memtime();
                 if (ky == 0 && !(a.dbg & 16)) store_A();
                 if (!(a.dbg & 8)) store_B();
+                if (pf) { __builtin_amdgcn_s_waitcnt(0xC07F); pf[2] = __builtin_amdgcn_s_memtime(); }
                 __syncthreads();
+                if (pf) pf[3] = __builtin_amdgcn_s_memtime();
                 if (!(a.dbg & 4)) {
                     if (ky == 0) {               // the halo tile of the next chunk / next tile has three stages to arrive
                         if (!last_chunk) load_A(c0 + CK);
@@ -202,6 +201,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
                 constexpr int XI[6] = {2, 1, 0, 1, 0, 0};
                 if constexpr (DB) {
                     read_tap(0, fx[0], fw[0]);
+                    if (pf) { __builtin_amdgcn_s_waitcnt(0xC07F); pf[4] = __builtin_amdgcn_s_memtime(); }
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         const int cur = kx & 1;
@@ -222,6 +222,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
                                                                                              __builtin_bit_cast(bf16x8, fx[cur][j][r]), acc[r][tt], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                    if (pf) pf[5] = __builtin_amdgcn_s_memtime();
                 } else {                         // register budget: one fragment set, the compiler interleaves reads and MFMAs
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
@@ -550,8 +551,13 @@ int launch_x3_gemm(ConvArgs a, hipStream_t st) {
 
 }  // namespace
 
+static unsigned long long* g_prof = nullptr;
+void conv_x3_set_prof(unsigned long long* buf) { g_prof = buf; }
+
 // a: fp32 CONV_3X3 arguments already validated by launch_conv
-int launch_conv_x3(const ConvArgs& a, hipStream_t st) {
+int launch_conv_x3(const ConvArgs& a_in, hipStream_t st) {
+    ConvArgs a = a_in;
+    a.prof = g_prof;
     if ((size_t)a.H * a.W * a.C0 * 4 >= 0xFFFFFFF0ull) return ELD_ENOTSUP;
     return a.Nout % 64 == 0 ? launch_x3<64, 2, true>(a, st) : launch_x3<32, 4, false>(a, st);
 }

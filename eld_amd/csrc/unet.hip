@@ -540,6 +540,8 @@ extern "C" int eld_unet_backward_buckets(const float* dout, const float* params,
     return marks.next == n_buckets ? 0 : ELD_EINVAL;
 }
 
+extern "C" void eld_debug_conv_prof(void* buf) { conv_x3_set_prof((unsigned long long*)buf); }
+
 extern "C" int eld_conv_fp32_algo(int algo) { return conv_fp32_algo(algo); }
 
 extern "C" size_t eld_l1_workspace_bytes(void) { return l1_ws_floats() * sizeof(float); }

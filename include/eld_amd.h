@@ -184,6 +184,10 @@ int eld_illuminance_correct(const float* predict, const float* source, float* ou
 int eld_isp_process(const float* bayer, const float* wbs, const float* ccms, float* out, int N, int H, int W, float gamma,
                     const float* crf_E, const float* crf_f, int crf_n, void* stream);
 
+/* Dev tool (tools/conv_phase_profile.py): device buffer of 8 x 4 x 128 x 6 uint64 that conv_x3_kernel fills with s_memtime
+ * stamps of its stage phases (first 8 workgroups, first 128 stages); NULL switches it off (default). */
+void eld_debug_conv_prof(void* buf);
+
 /* ---- single layers on NHWC float32 tensors with reference-layout weights; used by the parity tests ---- */
 size_t eld_layer_workspace_bytes(int N, int H, int W, int Cin, int Cout);
 /* out = [lrelu](conv3x3(cat[in0,in1]) + bias).  nn.Conv2d(k=3,p=1) + torch.max(0.2x,x)  (Unet.py:11-44,102-104) */

@@ -6,7 +6,7 @@ import eld_amd
 from eld_amd import _lib as L
 lib = eld_amd.load_library()
 H0, W0 = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1424, 2128)
-N = 1
+N = int(os.environ.get("LAYER_N", "1"))
 
 def ev(fn, reps=3):
     fn(); torch.cuda.synchronize()
