@@ -35,7 +35,7 @@ struct ConvArgs {
     int Cout_t;         // EPI_CONVT_FWD: real Cout (Nout = 4*Cout_t, n = tap*Cout_t + co)
     int tiles_x, tiles_y;
     int dtype;          // DT_F32 / DT_BF16
-    int dbg;            // ablation switches for tools/ (env ELD_CONV_DBG): 1 skip epilogue, 2 skip MFMA, 4 skip staging loads
+    int dbg;            // ablation switches for tools/ (env ELD_CONV_DBG): 1 skip epilogue, 4 skip staging loads, 8/16 skip slab/halo stores (conv_x3), 64 one workgroup per CU
     unsigned long long* prof;   // dev tool (eld_debug_conv_prof): per-stage s_memtime stamps of the first workgroups; null in production
 };
 

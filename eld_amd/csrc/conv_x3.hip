@@ -180,7 +180,6 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
                     else if (!last_chunk) load_B(nb, c0 + CK, 0);
                     else if (t_next < total_tiles) load_B(t_next % NB, 0, 0);
                 }
-                if (a.dbg & 2) continue;
                 uint4 fx[DB ? 2 : 1][3][RPW], fw[DB ? 2 : 1][3][NT];
                 __builtin_amdgcn_s_setprio(0);
                 auto read_tap = [&](int kx, uint4 (&X)[3][RPW], uint4 (&Wt)[3][NT]) {
