@@ -49,6 +49,7 @@ SIGNATURES = {
     'eld_illuminance_correct': (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _sz, _vp]),
     'eld_l1_workspace_bytes': (_sz, []),
     'eld_l1_loss': (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _f, _vp]),
+    'eld_mse_loss': (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _f, _vp]),
     'eld_adam_step': (_i, [_vp, _vp, _vp, _vp, _sz, _d, _d, _d, _d, _d, _i, _d, _vp]),
     'eld_layer_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'eld_conv3x3_forward': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),

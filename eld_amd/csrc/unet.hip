@@ -551,6 +551,11 @@ extern "C" int eld_l1_loss(const float* out, const float* target, float* dout, f
     return launch_l1(out, target, dout, loss, (float*)ws, n, grad_scale, as_stream(stream));
 }
 
+extern "C" int eld_mse_loss(const float* out, const float* target, float* dout, float* loss, void* ws, size_t n, float grad_scale, void* stream) {
+    if (!out || !target || !loss || !ws || n == 0) return ELD_EINVAL;
+    return launch_mse(out, target, dout, loss, (float*)ws, n, grad_scale, as_stream(stream));
+}
+
 extern "C" int eld_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1,
                              double beta2, double eps, double weight_decay, int step, double grad_scale, void* stream) {
     if (n == 0) return 0;

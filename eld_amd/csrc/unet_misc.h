@@ -19,6 +19,7 @@ struct PackJobs { int n; PackJob job[24]; };
 int launch_pack_all(PackJobs& jobs, const float* params, float* ws, hipStream_t st);
 size_t l1_ws_floats();
 int launch_l1(const float* out, const float* tgt, float* dout, float* loss, float* part, size_t n, float grad_scale, hipStream_t st);
+int launch_mse(const float* out, const float* tgt, float* dout, float* loss, float* part, size_t n, float grad_scale, hipStream_t st);
 int launch_adam(float* p, const float* g, float* m, float* v, size_t n, double lr, double b1, double b2, double eps, double wd,
                 int step, double gscale, hipStream_t st);
 

@@ -389,6 +389,7 @@ int launch_pack_all(PackJobs& jobs, const float* params, float* ws, hipStream_t 
 //   dout = sign(out - target) * scale / numel     (torch: sign(0) = 0)
 // ------------------------------------------------------------------------------------------------
 #define L1_BLOCKS 1024
+template <int MSE>
 __global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ out, const float* __restrict__ tgt, float* __restrict__ dout,
                                                  float* __restrict__ part, size_t n, float gscale) {
     float s = 0.f;
@@ -396,8 +397,11 @@ __global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ out, 
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const float4 a = reinterpret_cast<const float4*>(out)[i], b = reinterpret_cast<const float4*>(tgt)[i];
         const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
-        s += fabsf(d0) + fabsf(d1) + fabsf(d2) + fabsf(d3);
-        if (dout) {
+        if (MSE) s += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        else s += fabsf(d0) + fabsf(d1) + fabsf(d2) + fabsf(d3);
+        if (dout && MSE) {
+            reinterpret_cast<float4*>(dout)[i] = make_float4(2.0f * d0 * gscale, 2.0f * d1 * gscale, 2.0f * d2 * gscale, 2.0f * d3 * gscale);
+        } else if (dout) {
             float4 g;
             g.x = d0 > 0.f ? gscale : (d0 < 0.f ? -gscale : 0.f);
             g.y = d1 > 0.f ? gscale : (d1 < 0.f ? -gscale : 0.f);
@@ -409,8 +413,8 @@ __global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ out, 
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const size_t i = n4 * 4 + threadIdx.x;
         const float d = out[i] - tgt[i];
-        s += fabsf(d);
-        if (dout) dout[i] = d > 0.f ? gscale : (d < 0.f ? -gscale : 0.f);
+        s += MSE ? d * d : fabsf(d);
+        if (dout) dout[i] = MSE ? 2.0f * d * gscale : (d > 0.f ? gscale : (d < 0.f ? -gscale : 0.f));
     }
     __shared__ float sh[4];
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
@@ -437,7 +441,18 @@ size_t l1_ws_floats() { return L1_BLOCKS; }
 int launch_l1(const float* out, const float* tgt, float* dout, float* loss, float* part, size_t n, float grad_scale, hipStream_t st) {
     if (n == 0) return ELD_EINVAL;
     const int nb = (int)min((n / 4 + 255) / 256 + 1, (size_t)L1_BLOCKS);
-    ELD_LAUNCH(l1_kernel, dim3(nb), dim3(256), 0, st, out, tgt, dout, part, n, grad_scale / (float)n);
+    ELD_LAUNCH(l1_kernel<0>, dim3(nb), dim3(256), 0, st, out, tgt, dout, part, n, grad_scale / (float)n);
+    ELD_LAUNCH_CHECK();
+    ELD_LAUNCH(l1_reduce_kernel, dim3(1), dim3(256), 0, st, part, loss, nb, 1.0f / (float)n);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
+// nn.MSELoss (models/losses.py:34): mean (out - target)^2, gradient 2 (out - target) * grad_scale / n
+int launch_mse(const float* out, const float* tgt, float* dout, float* loss, float* part, size_t n, float grad_scale, hipStream_t st) {
+    if (n == 0) return ELD_EINVAL;
+    const int nb = (int)min((n / 4 + 255) / 256 + 1, (size_t)L1_BLOCKS);
+    ELD_LAUNCH(l1_kernel<1>, dim3(nb), dim3(256), 0, st, out, tgt, dout, part, n, grad_scale / (float)n);
     ELD_LAUNCH_CHECK();
     ELD_LAUNCH(l1_reduce_kernel, dim3(1), dim3(256), 0, st, part, loss, nb, 1.0f / (float)n);
     ELD_LAUNCH_CHECK();

@@ -109,8 +109,8 @@ class ELDModel:
             D.broadcast_(self.netG.flat_params, 0)          # identical replicas
         self.loss_pixel = None
         self.loss_name = getattr(opt, 'loss', 'l1')
-        if self.loss_name != 'l1':
-            raise NotImplementedError("only --loss l1 (the reference's default, train_options.py) is fused")
+        if self.loss_name not in ('l1', 'l2'):                   # models/losses.py:31-36
+            raise NotImplementedError('loss %r: the reference knows l1 and l2' % (self.loss_name,))
         if self.isTrain:
             self.optimizer_G = FusedAdam(self.netG, lr=opt.lr, betas=(getattr(opt, 'beta1', 0.9), 0.999),
                                          weight_decay=getattr(opt, 'wd', 0.0))
@@ -202,8 +202,9 @@ class ELDModel:
         out, key, _ = net._engine_forward(x, save=True, bf16=net.train_precision == 'bf16')      # forward()
         self.output = out
         dout = torch.empty_like(out)
-        L.check(L.lib().eld_l1_loss(L.dptr(out), L.dptr(self.target.contiguous()), L.dptr(dout), L.dptr(self._loss_buf), L.dptr(self._l1_ws),
-                                    out.numel(), 1.0, L.cur_stream()), 'eld_l1_loss')           # backward_G(): L1 + its gradient
+        loss_fn = L.lib().eld_mse_loss if self.loss_name == 'l2' else L.lib().eld_l1_loss
+        L.check(loss_fn(L.dptr(out), L.dptr(self.target.contiguous()), L.dptr(dout), L.dptr(self._loss_buf), L.dptr(self._l1_ws),
+                        out.numel(), 1.0, L.cur_stream()), 'eld_%s_loss' % self.loss_name)      # backward_G(): loss + its gradient
         if self.world > 1 and opt.grads.is_cuda:                              # data-parallel exchange (new):
             if self._buckets is None:                                         # buckets all-reduced under the rest of the backward
                 self._buckets = D.GradBuckets(opt.grads.numel(), opt.grads.device)

@@ -158,6 +158,8 @@ int eld_conv_fp32_algo(int algo);
 
 size_t eld_l1_workspace_bytes(void);
 int eld_l1_loss(const float* out, const float* target, float* dout, float* loss, void* ws, size_t n, float grad_scale, void* stream);
+/* --loss l2: nn.MSELoss (models/losses.py:34), same contract and workspace as eld_l1_loss. */
+int eld_mse_loss(const float* out, const float* target, float* dout, float* loss, void* ws, size_t n, float grad_scale, void* stream);
 /* torch.optim.Adam step over a flat buffer (models/ELD_model.py:400-401,475); step counts from 1;
  * the gradient is multiplied by grad_scale first (1/world_size after a sum all-reduce). */
 int eld_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, size_t n, double lr, double beta1,

@@ -359,3 +359,22 @@ def test_illuminance_correct_kernel_vs_oracle(eld_lib, shape, one_source):
     got = illuminance_correct(pred.cuda(), src.cuda()).cpu().numpy()
     ref = M.illuminance_correct(pred.numpy(), src.numpy())
     assert np.abs(got - ref).max() <= 2e-7 * max(1.0, float(np.abs(ref).max()))
+
+
+def test_l2_loss_training_step(eld_lib, tmp_path):
+    """--loss l2 (train_options / models/losses.py:34): one fused step == torch-CPU forward, MSELoss, backward, Adam."""
+    m = new_model(tmp_path, loss='l2')
+    sd = {k: v.detach().cpu().clone() for k, v in m.netG.state_dict().items()}
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    opt = torch.optim.Adam(list(params.values()), lr=1e-4, betas=(0.9, 0.999))
+    x, t = batch(seed=4)
+    m.set_input({'input': x, 'target': t}, 'train')
+    m.optimize_parameters()
+    loss = m.get_current_errors()['Pixel']
+    lref = torch.nn.functional.mse_loss(U.unet_forward(params, x), t)
+    lref.backward()
+    opt.step()
+    assert abs(loss - float(lref)) < 1e-6
+    got = m.netG.state_dict()
+    for k, v in params.items():
+        assert float(((got[k].cpu() - sd[k]) - (v.detach() - sd[k])).abs().max()) < 2e-5, k

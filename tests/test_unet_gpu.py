@@ -209,6 +209,13 @@ def test_l1_and_adam(lib):
     lref.backward()
     assert abs(float(loss) - float(lref)) < 1e-6
     assert torch.equal(dout.cpu(), o.grad)
+    # --loss l2 (models/losses.py:34): nn.MSELoss and its gradient
+    L.check(lib.eld_mse_loss(L.dptr(od_), L.dptr(td_), L.dptr(dout), L.dptr(loss), L.dptr(ws), n, 1.0, L.cur_stream()))
+    o2 = out.clone().requires_grad_(True)
+    lref2 = F.mse_loss(o2, tgt)
+    lref2.backward()
+    assert abs(float(loss) - float(lref2)) < 1e-6 * float(lref2)
+    assert float((dout.cpu() - o2.grad).abs().max()) <= 1e-7 * float(o2.grad.abs().max())
     # Adam: 5 steps vs torch.optim.Adam on CPU
     p = torch.randn(10007, generator=g)
     pr = p.clone().requires_grad_(True)

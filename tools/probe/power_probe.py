@@ -23,3 +23,19 @@ bench(xr, torch.zeros_like(wr), 'random x, zero w')
 bench(xr.round(), wr, 'integer-valued x (1 piece), random w')
 xb = xr.bfloat16().float(); wb = wr.bfloat16().float()
 bench(xb, wb, 'bf16-representable x and w')
+
+# weight gradient of the same layer
+dw = torch.empty(Co, Ci, 3, 3, device='cuda'); db = torch.empty(Co, device='cuda')
+def benchw(g, x, tag):
+    def run(): L.check(lib.eld_conv3x3_backward_weight(L.dptr(g), L.dptr(x), Ci, None, 0, L.dptr(dw), L.dptr(db), N, H, W, Co, L.dptr(ws), ws.numel(), L.cur_stream()))
+    for _ in range(3): run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): run()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    print('wgrad %-28s %.3f ms  %.1f TF/s' % (tag, ms, 2.0 * N * H * W * Co * Ci * 9 / ms / 1e9))
+gr = torch.randn(N, H, W, Co, device='cuda')
+benchw(gr, xr, 'random g, random x')
+benchw(torch.zeros_like(gr), torch.zeros_like(xr), 'zero g, zero x')
