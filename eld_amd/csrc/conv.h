@@ -37,11 +37,33 @@ struct ConvArgs {
     int dtype;          // DT_F32 / DT_BF16
     int dbg;            // ablation switches for tools/ (env ELD_CONV_DBG): 1 skip epilogue, 4 skip staging loads, 8/16 skip slab/halo stores (conv_x3), 64 one workgroup per CU
     unsigned long long* prof;   // dev tool (eld_debug_conv_prof): per-stage s_memtime stamps of the first workgroups; null in production
+    // two-piece fp16 product scheme (conv_fp32_algo 2): device floats holding an upper bound of max|.| of each operand tensor
+    // (read as power-of-two scales that bring the operands into the fp16 range) and, optionally, where to accumulate
+    // max|out| of what this launch writes (atomic max on the bit pattern; the slot is zeroed by the caller)
+    const float* amax_in0; const float* amax_in1; const float* amax_w;
+    float* amax_out0; float* amax_out1;
 };
 
 // d/dx max(0.2x, x) as autograd computes it for torch.max(0.2*x, x) (models/arch/Unet.py:102-104):
 // ties (x == 0) split the gradient evenly between the two branches -> 0.6.  The saved tensor is the
 // post-activation value, whose sign equals the pre-activation's.
+// power-of-two scale that maps a tensor with max|x| <= *slot into [2^14, 2^15) (fp16 holds 65504); 1 for an all-zero tensor
+__device__ __forceinline__ float h2_scale(float amax) {
+    const int e = (int)((__float_as_uint(amax) >> 23) & 0xFFu);
+    if (e == 0) return 1.0f;
+    int se = 268 - e;                                   // biased exponent of 2^(14 - (e - 127))
+    se = se < 1 ? 1 : (se > 254 ? 254 : se);
+    return __uint_as_float((unsigned)se << 23);
+}
+// atomic max of |v| over a wave into *slot (non-negative floats order like their bit patterns)
+__device__ __forceinline__ void amax_accumulate(float* slot, float v) {
+    unsigned b = __float_as_uint(v) & 0x7FFFFFFFu;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const unsigned o = __shfl_xor(b, off, 64); b = b > o ? b : o; }
+    // the plain read first keeps almost every wave off the atomic (the slot only grows; a stale read just costs one atomic)
+    if ((threadIdx.x & 63) == 0 && b > *reinterpret_cast<volatile unsigned*>(slot)) atomicMax(reinterpret_cast<unsigned*>(slot), b);
+}
+
 __device__ __forceinline__ float lrelu_slope(float y) { return y > 0.f ? 1.0f : (y < 0.f ? 0.2f : 0.6f); }
 
 // bfloat16 <-> float (round to nearest even; NaN not special-cased: activations are finite)
@@ -80,6 +102,7 @@ struct WgradArgs {
     int psplit;
     int tiles_x, tiles_y;
     int dtype;           // DT_F32 / DT_BF16 inputs (partials and accumulation are always fp32)
+    const float* amax_g; const float* amax_x0; const float* amax_x1;     // algo 2 only: see ConvArgs
 };
 
 int launch_wgrad(const WgradArgs& a, int mode, hipStream_t st);

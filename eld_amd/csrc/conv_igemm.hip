@@ -31,7 +31,21 @@
 #define ELD_FP32_CONV_DEFAULT 1
 #define PS 20           // LDS pixel stride in 4-byte words: one 64-byte K chunk (16 fp32 / 32 bf16 channels) + 16 bytes pad
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #define TW 32
+
+// experimental (ELD_FP32_CONV=h2): four fp32 values * scale -> two fp16 pieces each (round-toward-zero, residual exact), piece p
+// at byte offset 32p of the LDS row
+__device__ __forceinline__ void split_h2(float* row, float4 v, float scale) {
+    typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+    const float x0 = v.x * scale, x1 = v.y * scale, x2 = v.z * scale, x3 = v.w * scale;
+    const h2 a01 = __builtin_amdgcn_cvt_pkrtz(x0, x1), a23 = __builtin_amdgcn_cvt_pkrtz(x2, x3);
+    // first piece truncated (the residual is then exact and has the operand's sign), second piece rounded to nearest: the
+    // pair represents the scaled operand to 2^-22 relative, without the bias two truncations would leave
+    const h2 b01 = {(__fp16)(x0 - (float)a01[0]), (__fp16)(x1 - (float)a01[1])}, b23 = {(__fp16)(x2 - (float)a23[0]), (__fp16)(x3 - (float)a23[1])};
+    *reinterpret_cast<uint2*>(row) = make_uint2(__builtin_bit_cast(unsigned, a01), __builtin_bit_cast(unsigned, a23));
+    *reinterpret_cast<uint2*>(row + 8) = make_uint2(__builtin_bit_cast(unsigned, b01), __builtin_bit_cast(unsigned, b23));
+}
 
 template <int MODE, int RPW>
 struct Geo {
@@ -40,7 +54,7 @@ struct Geo {
     static constexpr int A_PIX = MODE == CONV_3X3 ? (TH + 2) * (TW + 2) : (MODE == CONV_1X1 ? TH * TW : 4 * TH * TW);
 };
 
-template <typename T, int MODE, int BN, int RPW>
+template <typename T, int MODE, int BN, int RPW, bool H2 = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     using G = Geo<MODE, RPW>;
     constexpr int ES = sizeof(T);               // element size of activations / packed weights
@@ -59,6 +73,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     const int Ws = MODE == CONV_GATHER2X2 ? 2 * a.W : a.W;
     const int total_tiles = a.tiles_x * a.tiles_y * a.N * NB;
     const int Cs0 = a.C0;                                       // channels per source tensor
+    float sc_a = 1.0f, sc_w = 1.0f;                              // H2: power-of-two operand scales (exact), undone in the epilogue
+    if constexpr (H2) {
+        float ma = *a.amax_in0;
+        if (a.amax_in1) ma = fmaxf(ma, *a.amax_in1);
+        sc_a = h2_scale(ma);
+        sc_w = h2_scale(*a.amax_w);
+    }
 
     // Persistent workgroup: walks tiles blockIdx.x, +gridDim.x, ... and streams (tile, chunk) work items
     // through a register-staged software pipeline (write-after-barrier): the global loads of the NEXT work
@@ -138,12 +159,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int u = tid + it * 256;
-            if (u < A_UNITS) *reinterpret_cast<float4*>(ldsA + (u >> 2) * PS + (u & 3) * 4) = ra[it];
+            if constexpr (H2) { if (u < A_UNITS) split_h2(ldsA + (u >> 2) * PS + (u & 3) * 2, ra[it], sc_a); }
+            else if (u < A_UNITS) *reinterpret_cast<float4*>(ldsA + (u >> 2) * PS + (u & 3) * 4) = ra[it];
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             const int u = tid + it * 256;
-            if (u < B_UNITS) *reinterpret_cast<float4*>(ldsB + (u >> 2) * PS + (u & 3) * 4) = rb[it];
+            if constexpr (H2) { if (u < B_UNITS) split_h2(ldsB + (u >> 2) * PS + (u & 3) * 2, rb[it], sc_w); }
+            else if (u < B_UNITS) *reinterpret_cast<float4*>(ldsB + (u >> 2) * PS + (u & 3) * 4) = rb[it];
         }
     };
 
@@ -183,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
             float4 fa[2][RPW], fb[2][NT];
             auto read_group = [&](int g, float4 (&A)[RPW], float4 (&B)[NT]) {
                 const int tap = g >> 1, q = g & 1;
-                const int ko = ES == 4 ? hi * 8 + q * 4 : hi * 4 + q * 8;      // word offset of this lane's 16 bytes inside the pixel row
+                const int ko = (ES == 4 && !H2) ? hi * 8 + q * 4 : hi * 4 + q * 8;      // H2: q = piece, bf16: q = k-step      // word offset of this lane's 16 bytes inside the pixel row
 #pragma unroll
                 for (int r = 0; r < RPW; ++r) {
                     const int row = wave * RPW + r;
@@ -196,6 +219,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) B[tt] = *reinterpret_cast<const float4*>(ldsB + (tap * BN + tt * 32 + m) * PS + ko);
             };
+            if constexpr (H2) {
+                // two fp16 pieces per operand (x = x1 + x2 to 22 bits): x1 w1 + x1 w2 + x2 w1 on v_mfma_f32_32x32x16_f16
+#pragma unroll
+                for (int tap = 0; tap < TAPS; ++tap) {
+                    read_group(2 * tap, fa[0], fb[0]);
+                    read_group(2 * tap + 1, fa[1], fb[1]);
+#pragma unroll
+                    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                        for (int tt = 0; tt < NT; ++tt) {
+                            acc[r][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fb[1][tt]), __builtin_bit_cast(half8, fa[0][r]), acc[r][tt], 0, 0, 0);
+                            acc[r][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fb[0][tt]), __builtin_bit_cast(half8, fa[1][r]), acc[r][tt], 0, 0, 0);
+                            acc[r][tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, fb[0][tt]), __builtin_bit_cast(half8, fa[0][r]), acc[r][tt], 0, 0, 0);
+                        }
+                    if constexpr (RPW * NT >= 4 && RPW == 4) __builtin_amdgcn_sched_barrier(0);      // 16-row tiles: keep later taps' reads from piling up (register budget)
+                }
+            } else {
             read_group(0, fa[0], fb[0]);
 #pragma unroll
             for (int g = 0; g < 2 * TAPS; ++g) {
@@ -225,12 +265,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            }
         }
 
         // ---- epilogue.  The MFMA ran as D[channel][pixel] (A = weights, B = pixels), so lane (m, hi) owns pixel
         //      x0 + m and, in accumulator quad q, the four CONSECUTIVE channels 8q + 4hi .. +3 of its 32-channel block:
         //      every access is one 16-byte dwordx4 per lane (4 per 32x32 tile), the bounds test is one lane mask, and
         //      all loads (bias, saved activations) are issued before the first store.
+        float tmax0 = 0.f, tmax1 = 0.f;     // H2: max|out| of this tile per destination tensor
         {
             const int x = x0 + m;
             const bool xok = x < a.W;
@@ -245,6 +287,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
                     float4 v[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = make_float4(acc[r][tt][4 * q], acc[r][tt][4 * q + 1], acc[r][tt][4 * q + 2], acc[r][tt][4 * q + 3]);
+                    if constexpr (H2) {
+                        const float ia = 1.0f / sc_a, iw = 1.0f / sc_w;      // powers of two: exact
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            v[q].x = v[q].x * ia * iw; v[q].y = v[q].y * ia * iw; v[q].z = v[q].z * ia * iw; v[q].w = v[q].w * ia * iw;
+                        }
+                    }
                     T* dst[4];
                     if (a.epi == EPI_FWD) {
                         float4 bs[4];
@@ -299,6 +348,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
                     for (int q = 0; q < 4; ++q) {
                         asm volatile("" : "+v"(v[q].x), "+v"(v[q].y), "+v"(v[q].z), "+v"(v[q].w));     // final values: no load result is consumed below
                     }
+                    if constexpr (H2) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float mq = fmaxf(fmaxf(fabsf(v[q].x), fabsf(v[q].y)), fmaxf(fabsf(v[q].z), fabsf(v[q].w)));
+                            if (a.epi == EPI_GRAD && nbase + 8 * q >= a.split) tmax1 = fmaxf(tmax1, mq); else tmax0 = fmaxf(tmax0, mq);
+                        }
+                    }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         if constexpr (ES == 4) *reinterpret_cast<float4*>(dst[q]) = v[q];
@@ -306,6 +362,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
                     }
                 }
             }
+        }
+        if constexpr (H2) {                 // wave-uniform control flow: every lane takes part in the shuffles
+            if (a.amax_out0) amax_accumulate(a.amax_out0, tmax0);
+            if (a.amax_out1) amax_accumulate(a.amax_out1, tmax1);
         }
         if (t_next >= total_tiles) break;
         t = t_next;
@@ -323,7 +383,7 @@ static int num_cus() {
     return n;
 }
 
-template <typename T, int MODE, int BN, int RPW>
+template <typename T, int MODE, int BN, int RPW, bool H2 = false>
 static int launch_t(ConvArgs a, hipStream_t st) {
     using G = Geo<MODE, RPW>;
     a.tiles_x = (a.W + TW - 1) / TW;
@@ -332,7 +392,7 @@ static int launch_t(ConvArgs a, hipStream_t st) {
     const long long tiles = (long long)a.tiles_x * a.tiles_y * a.N * (a.Nout / BN);
     if (tiles <= 0) return 0;
     if (tiles > 0x7fffffffLL) return ELD_ENOTSUP;
-    auto kern = conv_igemm_kernel<T, MODE, BN, RPW>;
+    auto kern = conv_igemm_kernel<T, MODE, BN, RPW, H2>;
     static bool attr_set = false;     // per instantiation
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -367,9 +427,10 @@ int conv_fp32_algo(int set) {
         const char* e = getenv("ELD_FP32_CONV");
         algo = (e && (e[0] == 'm' || e[0] == '0')) ? 0 : ELD_FP32_CONV_DEFAULT;
         if (e && (e[0] == 'x' || e[0] == '1')) algo = 1;
+        if (e && (e[0] == 'h' || e[0] == '2')) algo = 2;
     }
     const int prev = algo;
-    if (set == 0 || set == 1) algo = set;
+    if (set >= 0 && set <= 2) algo = set;
     return prev;
 }
 
@@ -389,6 +450,16 @@ int launch_conv(const ConvArgs& a_in, int mode, hipStream_t st) {
     if (mode != CONV_3X3 && conv_fp32_algo(-1) == 1) {
         const int rc = launch_conv_x3_gemm(a, mode, st);
         if (rc != ELD_ENOTSUP) return rc;
+    }
+    if (conv_fp32_algo(-1) == 2) {                    // two fp16 pieces per operand, three products; needs the operand bounds
+        if (!a.amax_in0 || !a.amax_w) return ELD_EINVAL;
+        const bool n64 = a.Nout % 64 == 0;
+        switch (mode) {
+            case CONV_3X3: return n64 ? launch_t<float, CONV_3X3, 64, 2, true>(a, st) : launch_t<float, CONV_3X3, 32, 4, true>(a, st);
+            case CONV_1X1: return n64 ? launch_t<float, CONV_1X1, 64, 2, true>(a, st) : launch_t<float, CONV_1X1, 32, 2, true>(a, st);
+            case CONV_GATHER2X2: return n64 ? launch_t<float, CONV_GATHER2X2, 64, 1, true>(a, st) : launch_t<float, CONV_GATHER2X2, 32, 1, true>(a, st);
+        }
+        return ELD_EINVAL;
     }
     return launch_dt<float>(a, mode, st);
 }

@@ -24,6 +24,7 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 // BFM = true (bf16 inputs only): the tiles stay bf16 in LDS, untransposed [pixel][channel], and the contraction runs on
 // v_mfma_f32_32x32x16_bf16 with K = 16 consecutive pixels of a row: lane (channel = lane&31, kb = lane>>5) gathers its
@@ -35,15 +36,15 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 // g1x1 + g1x2 + g2x1 + g1x3 + g2x2 + g3x1 on v_mfma_f32_32x32x16_bf16: fp32-level accuracy at 6 x 32 matrix-pipe
 // cycles per 16 k instead of 8 x 64.  The three horizontal taps of a kernel row share one 10-pixel window per piece
 // (10 ds_read_u16 + 4 v_alignbit instead of 24 reads).
-enum { ALG_F32 = 0, ALG_BFM = 1, ALG_X3 = 2 };
+enum { ALG_F32 = 0, ALG_BFM = 1, ALG_X3 = 2, ALG_H2 = 3 };      // ALG_H2: two fp16 pieces per fp32 operand, three products (conv_fp32_algo 2)
 
 template <typename T, int MODE, int WCO, int TH, int ALG>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
-    constexpr bool BFM = ALG == ALG_BFM, X3 = ALG == ALG_X3;
-    static_assert(!X3 || sizeof(T) == 4, "x3: fp32 inputs");
+    constexpr bool BFM = ALG == ALG_BFM, X3 = ALG == ALG_X3, H2 = ALG == ALG_H2;
+    static_assert(!(X3 || H2) || sizeof(T) == 4, "x3 / h2: fp32 inputs");
     constexpr int ES = sizeof(T);            // element size of g / x in HBM (float or bf16); accumulation is fp32
     constexpr int EPU = 16 / ES;             // elements per 16-byte staging unit
-    constexpr int LES = X3 ? 6 : (BFM ? 2 : 4);   // bytes per element in LDS (x3: three bf16 planes)
+    constexpr int LES = X3 ? 6 : (BFM ? 2 : 4);   // bytes per element in LDS (x3: three bf16 planes; h2: two fp16 planes = 4)
     constexpr int TAPS = MODE == CONV_3X3 ? 9 : 4;
     constexpr int WPIX = 4 / WCO;
     constexpr int COB = 32 * WCO;
@@ -72,6 +73,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     if (j0 < a.C0) { xsrc = static_cast<const char*>(a.x0); Cs = a.C0; cs = j0; } else { xsrc = static_cast<const char*>(a.x1); Cs = a.C1; cs = j0 - a.C0; }
     const int jvalid = min(JB, CB - j0 > 0 ? (j0 < a.C0 ? a.C0 - j0 : CB - j0) : 0);   // channels of this tile that exist
 
+    float sc_g = 1.0f, sc_x = 1.0f;              // H2: power-of-two operand scales
+    if constexpr (H2) {
+        sc_g = h2_scale(*a.amax_g);
+        float mx = *a.amax_x0;
+        if (a.amax_x1) mx = fmaxf(mx, *a.amax_x1);
+        sc_x = h2_scale(mx);
+    }
     f32x16 acc[TAPS];
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
@@ -128,7 +136,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     };
     constexpr int GPL = TPIX * COB, XPL = X_PIX * JB;                 // x3: elements per piece plane
     auto put = [&](float* dst, int u, const float4& raw, int plane_elems, int e0) {      // e0: element index of the unit inside a bf16 plane            // LDS rows are unit-linear: [lp][COB] and [hp][JB]
-        if constexpr (X3) {
+        if constexpr (H2) {
+            typedef __fp16 h2v __attribute__((ext_vector_type(2)));
+            bf16_t* d = reinterpret_cast<bf16_t*>(dst) + e0;
+            const float sc = plane_elems == GPL ? sc_g : sc_x;
+            const float x0 = raw.x * sc, x1 = raw.y * sc, x2 = raw.z * sc, x3 = raw.w * sc;
+            const h2v a01 = __builtin_amdgcn_cvt_pkrtz(x0, x1), a23 = __builtin_amdgcn_cvt_pkrtz(x2, x3);
+            const h2v b01 = {(__fp16)(x0 - (float)a01[0]), (__fp16)(x1 - (float)a01[1])}, b23 = {(__fp16)(x2 - (float)a23[0]), (__fp16)(x3 - (float)a23[1])};      // rounded to nearest
+            *reinterpret_cast<uint2*>(d) = make_uint2(__builtin_bit_cast(unsigned, a01), __builtin_bit_cast(unsigned, a23));
+            *reinterpret_cast<uint2*>(d + plane_elems) = make_uint2(__builtin_bit_cast(unsigned, b01), __builtin_bit_cast(unsigned, b23));
+        } else if constexpr (X3) {
             bf16_t* d = reinterpret_cast<bf16_t*>(dst) + e0;
             const unsigned x0 = __float_as_uint(raw.x), x1 = __float_as_uint(raw.y), x2 = __float_as_uint(raw.z), x3 = __float_as_uint(raw.w);
             const float r0 = raw.x - __uint_as_float(x0 & 0xFFFF0000u), r1 = raw.y - __uint_as_float(x1 & 0xFFFF0000u);
@@ -179,13 +196,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
         store_tile();
         __syncthreads();
         if (tile + a.psplit < ntiles) load_tile(tile + a.psplit);
-        if constexpr (X3 || BFM) {
-        // ---- bf16 MFMA, K = 16 consecutive pixels of a row per k-step.  Operands come straight out of the untransposed
+        if constexpr (X3 || BFM || H2) {
+        // ---- bf16 / fp16 MFMA, K = 16 consecutive pixels of a row per k-step.  Operands come straight out of the untransposed
         //      [pixel][32 channels] bf16 planes with ds_read_b64_tr_b16: a 16-lane group reads a [4 pixels][16 channels]
         //      block (lane i supplies the 8 bytes at pixel i/4, channels 4(i%4)..+3) and lane i receives the 4 pixel values
         //      of channel i -- two reads make one 8-k MFMA operand, no 16-bit gathers, no packing.  Shifted taps are just
         //      other immediate offsets (rows are 64 bytes, any pixel offset keeps the 8-byte alignment).
-        constexpr int NPC = X3 ? 3 : 1;
+        constexpr int NPC = X3 ? 3 : (H2 ? 2 : 1);
         constexpr int KSB = PW / 16;
         const int gi = lane & 15, gg = lane >> 4;                   // lane inside its 16-lane group, group: channels 16(gg&1).., k-half gg>>1 (= hi)
         const int lq0 = wpix * PW + 8 * hi + (gi >> 2);             // pixel row this lane ADDRESSES in k-step 0 (first 4-pixel block)
@@ -205,7 +222,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int pc = 0; pc < NPC; ++pc) {
                 ga[pc] = tr8(gq + pc * GPL + lrel * 32);
-                if (a.bpart) {
+                if (a.bpart && H2) {
+                    const half8 hq = __builtin_bit_cast(half8, ga[pc]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bsum += (float)hq[e];
+                } else if (a.bpart) {
                     const uint4 q = __builtin_bit_cast(uint4, ga[pc]);
                     bsum += __uint_as_float(q.x << 16) + __uint_as_float(q.x & 0xFFFF0000u) + __uint_as_float(q.y << 16) + __uint_as_float(q.y & 0xFFFF0000u)
                           + __uint_as_float(q.z << 16) + __uint_as_float(q.z & 0xFFFF0000u) + __uint_as_float(q.w << 16) + __uint_as_float(q.w & 0xFFFF0000u);
@@ -222,7 +243,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
                     for (int pc = 0; pc < NPC; ++pc) xb[tt][pc] = tr8(xq + pc * XPL + xoff * JB);
                 }
-                if constexpr (X3) {
+                if constexpr (H2) {
+                    constexpr int GI[3] = {0, 1, 0};
+                    constexpr int XI[3] = {1, 0, 0};
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+#pragma unroll
+                        for (int tt = 0; tt < TROW; ++tt)
+                            acc[t0 + tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, ga[GI[q]]), __builtin_bit_cast(half8, xb[tt][XI[q]]),
+                                                                                  acc[t0 + tt], 0, 0, 0);
+                } else if constexpr (X3) {
                     constexpr int GI[6] = {0, 1, 2, 0, 1, 0};
                     constexpr int XI[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
@@ -285,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int row = (i & 3) + 8 * (i >> 2) + 4 * hi;
-                a.part[pbase + ((size_t)t * a.CA + i0 + wco * 32 + row) * a.CBp + j0 + m] = acc[t][i];
+                a.part[pbase + ((size_t)t * a.CA + i0 + wco * 32 + row) * a.CBp + j0 + m] = H2 ? acc[t][i] * (1.0f / sc_g) * (1.0f / sc_x) : acc[t][i];
             }
         }
     }
@@ -296,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
             const int wc = tid / 32, mm = tid % 32;
             float s = 0.f;
             for (int wp = 0; wp < WPIX; ++wp) s += red[(wp * WCO + wc) * 64 + mm] + red[(wp * WCO + wc) * 64 + 32 + mm];
-            a.bpart[(size_t)ps * a.CA + i0 + tid] = s;
+            a.bpart[(size_t)ps * a.CA + i0 + tid] = H2 ? s * (1.0f / sc_g) : s;
         }
     }
 }
@@ -307,7 +337,7 @@ static int launch_w(WgradArgs a, hipStream_t st) {
     constexpr int X_PIX = MODE == CONV_3X3 ? (TH + 2) * (TW + 2) : 4 * TH * TW;
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + TH - 1) / TH;
-    size_t lds_bytes = (size_t)(TH * TW * COB + X_PIX * JB) * (ALG == ALG_X3 ? 6 : (ALG == ALG_BFM ? 2 : 4));
+    size_t lds_bytes = (size_t)(TH * TW * COB + X_PIX * JB) * (ALG == ALG_X3 ? 6 : (ALG == ALG_BFM ? 2 : 4));      // ALG_H2: 2 planes x 2 B
     const size_t red_bytes = (size_t)4 * 16 * 64 * sizeof(float);
     if (lds_bytes < red_bytes) lds_bytes = red_bytes;
     const long long blocks = (long long)(a.CA / COB) * (a.CBp / JB) * a.psplit;
@@ -339,6 +369,12 @@ int launch_wgrad(const WgradArgs& a, int mode, hipStream_t st) {
         }
         if (mode == CONV_3X3) return c64 ? launch_w<bf16_t, CONV_3X3, 2, 4>(a, st) : launch_w<bf16_t, CONV_3X3, 1, 4>(a, st);
         if (mode == CONV_GATHER2X2) return c64 ? launch_w<bf16_t, CONV_GATHER2X2, 2, 2>(a, st) : launch_w<bf16_t, CONV_GATHER2X2, 1, 2>(a, st);
+        return ELD_EINVAL;
+    }
+    if (conv_fp32_algo(-1) == 2) {
+        if (!a.amax_g || !a.amax_x0) return ELD_EINVAL;
+        if (mode == CONV_3X3) return c64 ? launch_w<float, CONV_3X3, 2, 4, ALG_H2>(a, st) : launch_w<float, CONV_3X3, 1, 4, ALG_H2>(a, st);
+        if (mode == CONV_GATHER2X2) return c64 ? launch_w<float, CONV_GATHER2X2, 2, 2, ALG_H2>(a, st) : launch_w<float, CONV_GATHER2X2, 1, 2, ALG_H2>(a, st);
         return ELD_EINVAL;
     }
     if (mode == CONV_3X3 && conv_fp32_algo(-1) == 1) return c64 ? launch_w<float, CONV_3X3, 2, 2, ALG_X3>(a, st) : launch_w<float, CONV_3X3, 1, 2, ALG_X3>(a, st);

@@ -76,11 +76,19 @@ WgradGeom wgrad_geom(int mode, int CA, int CB, int N, int H, int W) {
 // ------------------------------------------------------------------------------------------------
 // layer helpers on packed weights
 // ------------------------------------------------------------------------------------------------
+// Operand bounds for the two-piece fp16 product scheme (conv_fp32_algo 2): set by the caller right before a helper call,
+// consumed (and cleared) by it.  Slots are device floats in the workspace.
+struct Amax { const float* in0 = nullptr; const float* in1 = nullptr; const float* w = nullptr; float* out0 = nullptr; float* out1 = nullptr; };
+thread_local Amax g_am;
+inline void take_amax(ConvArgs& a) { a.amax_in0 = g_am.in0; a.amax_in1 = g_am.in1; a.amax_w = g_am.w; a.amax_out0 = g_am.out0; a.amax_out1 = g_am.out1; g_am = Amax(); }
+inline void take_amax(WgradArgs& a) { a.amax_g = g_am.in0; a.amax_x0 = g_am.w; a.amax_x1 = g_am.in1; g_am = Amax(); }      // wgrad: in0 = G, w = X0, in1 = X1
+enum { S_W = 0, S_X = 23, S_EA = 24, S_EB = 29, S_UP = 34, S_DA = 38, S_DB = 42, S_GA = 46, S_GB = 47, S_SKIP = 48, S_COUNT = 64 };
 int conv_fwd(const float* in0, int C0, const float* in1, int C1, const float* wp, const float* bias, float* out, int N, int H, int W,
              int Cout, int lrelu, hipStream_t st) {
     ConvArgs a = {};
     a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1; a.wp = wp; a.N = N; a.H = H; a.W = W; a.Nout = Cout;
     a.epi = EPI_FWD; a.bias = bias; a.lrelu = lrelu; a.out0 = out;
+    take_amax(a);
     return launch_conv(a, CONV_3X3, st);
 }
 
@@ -90,6 +98,7 @@ int conv_bwd_data(const float* g, const float* wb, float* out0, float* out1, int
     ConvArgs a = {};
     a.in0 = g; a.C0 = Cout; a.wp = wb; a.N = N; a.H = H; a.W = W; a.Nout = Cin;
     a.epi = EPI_GRAD; a.out0 = out0; a.out1 = out1; a.split = split; a.act0 = act0; a.act1 = act1;
+    take_amax(a);
     return launch_conv(a, CONV_3X3, st);
 }
 
@@ -99,6 +108,7 @@ int conv_wgrad(const float* g, int Cout, const float* x0, int C0, const float* x
     WgradArgs a = {};
     a.g = g; a.CA = Cout; a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.N = N; a.H = H; a.W = W;
     a.part = part; a.bpart = db ? part + (size_t)q.psplit * q.T * q.CA * q.CBp : nullptr; a.CBp = q.CBp; a.psplit = q.psplit;
+    take_amax(a);
     int rc = launch_wgrad(a, CONV_3X3, st);
     if (rc) return rc;
     return launch_wgrad_reduce(part, a.bpart, dw, db, q.psplit, q.T, q.CA, q.CBp, Cin_real, st);
@@ -109,6 +119,7 @@ int convt_fwd(const float* in, const float* wf, const float* bias, float* out, i
     ConvArgs a = {};
     a.in0 = in; a.C0 = Cin; a.wp = wf; a.N = N; a.H = H; a.W = W; a.Nout = 4 * Cout;
     a.epi = EPI_CONVT_FWD; a.bias = bias; a.out0 = out; a.Cout_t = Cout;
+    take_amax(a);
     return launch_conv(a, CONV_1X1, st);
 }
 
@@ -117,6 +128,7 @@ int convt_bwd_data(const float* dout, const float* wb, const float* act, float* 
     ConvArgs a = {};
     a.in0 = dout; a.C0 = Cout; a.wp = wb; a.N = N; a.H = H; a.W = W; a.Nout = Cin;
     a.epi = EPI_GRAD; a.out0 = din; a.split = Cin; a.act0 = act;
+    take_amax(a);
     return launch_conv(a, CONV_GATHER2X2, st);
 }
 
@@ -126,6 +138,7 @@ int convt_wgrad(const float* in, const float* dout, float* dw, float* db, float*
     WgradArgs a = {};
     a.g = in; a.CA = Cin; a.x0 = dout; a.C0 = Cout; a.N = N; a.H = H; a.W = W;
     a.part = part; a.bpart = nullptr; a.CBp = q.CBp; a.psplit = q.psplit;
+    take_amax(a);
     int rc = launch_wgrad(a, CONV_GATHER2X2, st);
     if (rc) return rc;
     rc = launch_wgrad_reduce(part, nullptr, dw, nullptr, q.psplit, q.T, q.CA, q.CBp, Cout, st);
@@ -144,7 +157,7 @@ struct Plan {
     // offsets in floats
     size_t wp_fwd[NLAYERS], wp_bwd[NLAYERS];
     size_t x16, ea[NLEV], eb[NLEV], pool[NLEV - 1], up[NLEV - 1], da[NLEV - 1], db[NLEV - 1];
-    size_t gA, gB, skip[NLEV - 1], part;
+    size_t gA, gB, skip[NLEV - 1], part, amax;
     size_t total;     // floats
 };
 
@@ -194,11 +207,12 @@ int make_plan(Plan& P, int N, int H, int W, int in_ch, int out_ch) {
         pmax = f > pmax ? f : pmax;
     }
     P.part = take(pmax);
+    P.amax = take(S_COUNT);
     P.total = off;
     return 0;
 }
 
-int pack_weights(const Plan& P, const float* params, float* ws, bool for_backward, hipStream_t st, bool bf16 = false) {
+int pack_weights(const Plan& P, const float* params, float* ws, bool for_backward, hipStream_t st, bool bf16 = false, float* amax = nullptr) {
     PackJobs jobs;
     jobs.n = 0;
     for (int i = 0; i < NLAYERS; ++i) {
@@ -218,9 +232,10 @@ int pack_weights(const Plan& P, const float* params, float* ws, bool for_backwar
             continue;
         }
         J.bf16 = bf16 ? 1 : 0;
+        J.amax_slot = S_W + i;
         jobs.job[jobs.n++] = J;
     }
-    return launch_pack_all(jobs, params, ws, st);
+    return launch_pack_all(jobs, params, ws, st, amax);
 }
 
 #define RC(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
@@ -246,7 +261,14 @@ struct BucketMarks {
 
 int unet_forward(const Plan& P, const float* x, const float* prm, float* out, float* ws, hipStream_t st) {
     const int N = P.N;
-    RC(pack_weights(P, prm, ws, false, st));
+    const bool h2 = conv_fp32_algo(-1) == 2;                     // operand bounds ride along in the workspace
+    float* am = ws + P.amax;
+    auto AM = [&](int in0, int in1, int w, int out0) {
+        if (!h2) return;
+        g_am.in0 = am + in0; g_am.in1 = in1 >= 0 ? am + in1 : nullptr; g_am.w = am + w; g_am.out0 = am + out0;
+    };
+    if (h2 && hipMemsetAsync(am, 0, S_COUNT * sizeof(float), st) != hipSuccess) return (int)hipGetLastError();
+    RC(pack_weights(P, prm, ws, false, st, false, h2 ? am : nullptr));
     const bool first_direct = P.in_ch <= 4;        // conv1_1 straight from the NCHW planes (conv_first.hip)
     if (first_direct) {
         // keep the input for the backward's weight gradient (the backward entry point does not receive x)
@@ -259,18 +281,26 @@ int unet_forward(const Plan& P, const float* x, const float* prm, float* out, fl
         const LayerDef& A = P.L[2 * l]; const LayerDef& B = P.L[2 * l + 1];
         const float* src = l == 0 ? ws + P.x16 : ws + P.pool[l - 1];
         const int cin = l == 0 ? 16 : chan(l - 1);
-        if (l == 0 && first_direct)
+        if (l == 0 && first_direct) {
             RC(launch_conv_first_fwd(x, prm + A.w_off, prm + A.b_off, ws + P.ea[0], N, P.in_ch, P.H, P.W, 1, st));
-        else
-        RC(conv_fwd(src, cin, nullptr, 0, ws + P.wp_fwd[2 * l], prm + A.b_off, ws + P.ea[l], N, P.Hl[l], P.Wl[l], chan(l), 1, st));
+            if (h2) RC(launch_absmax(ws + P.ea[0], (size_t)N * P.H * P.W * chan(0), am + S_EA, st));
+        } else {
+            if (h2 && l == 0) RC(launch_absmax(ws + P.x16, (size_t)N * P.H * P.W * 16, am + S_X, st));
+            AM(l == 0 ? S_X : S_EB + l - 1, -1, S_W + 2 * l, S_EA + l);          // pooled input is bounded by its source's bound
+            RC(conv_fwd(src, cin, nullptr, 0, ws + P.wp_fwd[2 * l], prm + A.b_off, ws + P.ea[l], N, P.Hl[l], P.Wl[l], chan(l), 1, st));
+        }
+        AM(S_EA + l, -1, S_W + 2 * l + 1, S_EB + l);
         RC(conv_fwd(ws + P.ea[l], chan(l), nullptr, 0, ws + P.wp_fwd[2 * l + 1], prm + B.b_off, ws + P.eb[l], N, P.Hl[l], P.Wl[l], chan(l), 1, st));
         if (l < NLEV - 1) RC(launch_maxpool_fwd(ws + P.eb[l], ws + P.pool[l], N, P.Hl[l + 1], P.Wl[l + 1], chan(l), st));
     }
     for (int l = 3; l >= 0; --l) {
         const int iu = L_UP3 + 3 * (3 - l);
         const float* src = l == 3 ? ws + P.eb[4] : ws + P.db[l + 1];
+        AM(l == 3 ? S_EB + 4 : S_DB + l + 1, -1, S_W + iu, S_UP + l);
         RC(convt_fwd(src, ws + P.wp_fwd[iu], prm + P.L[iu].b_off, ws + P.up[l], N, P.Hl[l + 1], P.Wl[l + 1], chan(l + 1), chan(l), st));
+        AM(S_UP + l, S_EB + l, S_W + iu + 1, S_DA + l);
         RC(conv_fwd(ws + P.up[l], chan(l), ws + P.eb[l], chan(l), ws + P.wp_fwd[iu + 1], prm + P.L[iu + 1].b_off, ws + P.da[l], N, P.Hl[l], P.Wl[l], chan(l), 1, st));
+        AM(S_DA + l, -1, S_W + iu + 2, S_DB + l);
         RC(conv_fwd(ws + P.da[l], chan(l), nullptr, 0, ws + P.wp_fwd[iu + 2], prm + P.L[iu + 2].b_off, ws + P.db[l], N, P.Hl[l], P.Wl[l], chan(l), 1, st));
     }
     const LayerDef& Hd = P.L[L_HEAD];
@@ -323,30 +353,47 @@ int unet_forward_bf16(const Plan& P, const float* x, const float* prm, float* ou
 
 int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd, float* ws, hipStream_t st, BucketMarks& marks) {
     const int N = P.N;
-    RC(pack_weights(P, prm, ws, true, st));
+    const bool h2 = conv_fp32_algo(-1) == 2;
+    float* am = ws + P.amax;
+    if (h2 && hipMemsetAsync(am + S_GA, 0, (S_COUNT - S_GA) * sizeof(float), st) != hipSuccess) return (int)hipGetLastError();
+    RC(pack_weights(P, prm, ws, true, st, false, h2 ? am : nullptr));
     float* gA = ws + P.gA; float* gB = ws + P.gB; float* part = ws + P.part;
+    auto gs = [&](const float* buf) { return buf == gA ? (int)S_GA : (int)S_GB; };                 // slot of a ping-pong gradient buffer
+    auto fresh = [&](int slot) -> int {                                                               // zero a slot before its tensor is rewritten
+        if (!h2) return 0;
+        return hipMemsetAsync(am + slot, 0, sizeof(float), st) == hipSuccess ? 0 : (int)hipGetLastError();
+    };
+    auto WG = [&](int g, int x0, int x1) { if (h2) { g_am.in0 = am + g; g_am.w = am + x0; g_am.in1 = x1 >= 0 ? am + x1 : nullptr; } };
+    auto BD = [&](int g, int w, int o0, int o1) { if (h2) { g_am.in0 = am + g; g_am.w = am + w; g_am.out0 = am + o0; g_am.out1 = o1 >= 0 ? am + o1 : nullptr; } };
     const LayerDef& Hd = P.L[L_HEAD];
     // head: g (pre-activation grad of conv9_2) -> gA
     RC(launch_head_bwd(dout, ws + P.db[0], prm + Hd.w_off, gA, grd + Hd.w_off, grd + Hd.b_off, part, N, P.H, P.W, P.out_ch, st));
     RC(marks.done(P, L_HEAD, st));
+    if (h2) RC(launch_absmax(gA, (size_t)N * P.H * P.W * 32, am + S_GA, st));
     float* cur = gA; float* oth = gB;
     for (int l = 0; l <= 3; ++l) {            // decoder levels 0 (conv9) .. 3 (conv6)
         const int iu = L_UP3 + 3 * (3 - l);
         const int H = P.Hl[l], W = P.Wl[l], C = chan(l);
         // conv_2 of the level: input da[l]
+        WG(gs(cur), S_DA + l, -1);
         RC(conv_wgrad(cur, C, ws + P.da[l], C, nullptr, 0, C, grd + P.L[iu + 2].w_off, grd + P.L[iu + 2].b_off, part, N, H, W, st));
         RC(marks.done(P, iu + 2, st));
+        RC(fresh(gs(oth))); BD(gs(cur), S_W + iu + 2, gs(oth), -1);
         RC(conv_bwd_data(cur, ws + P.wp_bwd[iu + 2], oth, nullptr, C, ws + P.da[l], nullptr, N, H, W, C, C, st));
         { float* t = cur; cur = oth; oth = t; }
         // conv_1: input cat[up[l], eb[l]] -> d_up (raw) in oth, skip grad (raw) in skip[l]
+        WG(gs(cur), S_UP + l, S_EB + l);
         RC(conv_wgrad(cur, C, ws + P.up[l], C, ws + P.eb[l], C, 2 * C, grd + P.L[iu + 1].w_off, grd + P.L[iu + 1].b_off, part, N, H, W, st));
         RC(marks.done(P, iu + 1, st));
+        RC(fresh(gs(oth))); BD(gs(cur), S_W + iu + 1, gs(oth), S_SKIP + l);
         RC(conv_bwd_data(cur, ws + P.wp_bwd[iu + 1], oth, ws + P.skip[l], C, nullptr, nullptr, N, H, W, 2 * C, C, st));
         { float* t = cur; cur = oth; oth = t; }
         // transposed conv: input src (level l+1, 2C channels), output grad = cur (d_up)
         const float* src = l == 3 ? ws + P.eb[4] : ws + P.db[l + 1];
+        WG(l == 3 ? S_EB + 4 : S_DB + l + 1, gs(cur), -1);
         RC(convt_wgrad(src, cur, grd + P.L[iu].w_off, grd + P.L[iu].b_off, part, N, P.Hl[l + 1], P.Wl[l + 1], 2 * C, C, st));
         RC(marks.done(P, iu, st));
+        RC(fresh(gs(oth))); BD(gs(cur), S_W + iu, gs(oth), -1);
         RC(convt_bwd_data(cur, ws + P.wp_bwd[iu], src, oth, N, P.Hl[l + 1], P.Wl[l + 1], 2 * C, C, st));
         { float* t = cur; cur = oth; oth = t; }
     }
@@ -354,24 +401,31 @@ int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd
     for (int l = 4; l >= 0; --l) {
         const int H = P.Hl[l], W = P.Wl[l], C = chan(l);
         const int ia = 2 * l, ib = 2 * l + 1;
+        WG(gs(cur), S_EA + l, -1);
         RC(conv_wgrad(cur, C, ws + P.ea[l], C, nullptr, 0, C, grd + P.L[ib].w_off, grd + P.L[ib].b_off, part, N, H, W, st));
         RC(marks.done(P, ib, st));
+        RC(fresh(gs(oth))); BD(gs(cur), S_W + ib, gs(oth), -1);
         RC(conv_bwd_data(cur, ws + P.wp_bwd[ib], oth, nullptr, C, ws + P.ea[l], nullptr, N, H, W, C, C, st));
         { float* t = cur; cur = oth; oth = t; }
         if (l == 0) {
             if (P.in_ch <= 4)
                 RC(launch_conv_first_wgrad(cur, ws + P.x16, grd + P.L[ia].w_off, grd + P.L[ia].b_off, part, N, P.in_ch, H, W, st));
-            else
+            else {
+                WG(gs(cur), S_X, -1);
                 RC(conv_wgrad(cur, C, ws + P.x16, 16, nullptr, 0, P.in_ch, grd + P.L[ia].w_off, grd + P.L[ia].b_off, part, N, H, W, st));
+            }
             RC(marks.done(P, ia, st));
             break;
         }
         const int Cp = chan(l - 1);
+        WG(gs(cur), S_EB + l - 1, -1);                 // pooled activations are bounded by their source's bound
         RC(conv_wgrad(cur, C, ws + P.pool[l - 1], Cp, nullptr, 0, Cp, grd + P.L[ia].w_off, grd + P.L[ia].b_off, part, N, H, W, st));
         RC(marks.done(P, ia, st));
+        RC(fresh(gs(oth))); BD(gs(cur), S_W + ia, gs(oth), -1);
         RC(conv_bwd_data(cur, ws + P.wp_bwd[ia], oth, nullptr, Cp, nullptr, nullptr, N, H, W, Cp, C, st));      // d_pool (raw)
         { float* t = cur; cur = oth; oth = t; }
         RC(launch_maxpool_bwd(ws + P.eb[l - 1], cur, ws + P.skip[l - 1], oth, N, H, W, Cp, st));
+        if (h2) { RC(fresh(gs(oth))); RC(launch_absmax(oth, (size_t)N * 4 * H * W * Cp, am + gs(oth), st)); }
         { float* t = cur; cur = oth; oth = t; }
     }
     return 0;
@@ -572,7 +626,20 @@ extern "C" size_t eld_layer_workspace_bytes(int N, int H, int W, int Cin, int Co
     if (Cout % 32 == 0) { q = wgrad_geom(CONV_3X3, Cout, Cin, N, H, W).floats; p = q > p ? q : p; }
     if (Cin % 32 == 0) { q = wgrad_geom(CONV_GATHER2X2, Cin, Cout, N, H, W).floats; p = q > p ? q : p; }
     q = colsum_ws_floats(Cout > Cin ? Cout : Cin); p = q > p ? q : p;
-    return (align_up(f, 64) + align_up(p, 64)) * sizeof(float);
+    return (align_up(f, 64) + align_up(p, 64) + 64) * sizeof(float);      // + 64 operand-bound slots (conv_fp32_algo 2)
+}
+
+// operand bounds of a single-layer call under conv_fp32_algo 2: slots 0..2 = inputs (a, b, c), 3..4 = outputs
+static int layer_amax(void* ws, size_t ws_bytes, hipStream_t st, const float* a, size_t na, const float* b, size_t nb, const float* c, size_t nc, float** slots) {
+    *slots = nullptr;
+    if (conv_fp32_algo(-1) != 2) return 0;
+    float* am = (float*)ws + ws_bytes / sizeof(float) - 64;
+    if (hipMemsetAsync(am, 0, 64 * sizeof(float), st) != hipSuccess) return (int)hipGetLastError();
+    if (a) RC(launch_absmax(a, na, am + 0, st));
+    if (b) RC(launch_absmax(b, nb, am + 1, st));
+    if (c) RC(launch_absmax(c, nc, am + 2, st));
+    *slots = am;
+    return 0;
 }
 
 static int layer_ws(void* ws, size_t ws_bytes, int N, int H, int W, int Cin, int Cout, float** pack, float** part) {
@@ -593,6 +660,9 @@ extern "C" int eld_conv3x3_forward(const float* in0, int C0, const float* in1, i
     RC(layer_ws(ws, ws_bytes, N, H, W, C0 + C1, Cout, &pack, &part));
     hipStream_t st = as_stream(stream);
     RC(launch_pack(w, pack, PACK_CONV_FWD, Cout, C0 + C1, C0 + C1, 9, st));
+    float* am;
+    RC(layer_amax(ws, eld_layer_workspace_bytes(N, H, W, C0 + C1, Cout), st, in0, (size_t)N * H * W * C0, in1, (size_t)N * H * W * C1, pack, (size_t)9 * Cout * (C0 + C1), &am));
+    if (am) { g_am.in0 = am; g_am.in1 = in1 ? am + 1 : nullptr; g_am.w = am + 2; g_am.out0 = am + 3; }
     return conv_fwd(in0, C0, in1, C1, pack, bias, out, N, H, W, Cout, lrelu, st);
 }
 
@@ -604,6 +674,9 @@ extern "C" int eld_conv3x3_backward_data(const float* g, const float* w, float* 
     RC(layer_ws(ws, ws_bytes, N, H, W, Cin, Cout, &pack, &part));
     hipStream_t st = as_stream(stream);
     RC(launch_pack(w, pack, PACK_CONV_BWD, Cout, Cin, Cin, 9, st));
+    float* am;
+    RC(layer_amax(ws, eld_layer_workspace_bytes(N, H, W, Cin, Cout), st, g, (size_t)N * H * W * Cout, nullptr, 0, pack, (size_t)9 * Cout * Cin, &am));
+    if (am) { g_am.in0 = am; g_am.w = am + 2; g_am.out0 = am + 3; g_am.out1 = am + 4; }
     return conv_bwd_data(g, pack, din0, din1, split, act0, act1, N, H, W, Cin, Cout, st);
 }
 
@@ -613,6 +686,9 @@ extern "C" int eld_conv3x3_backward_weight(const float* g, const float* x0, int 
     if (!g || !x0 || !dw || Cout % 32 || C0 % 4 || C1 % 4) return ELD_EINVAL;
     float *pack, *part;
     RC(layer_ws(ws, ws_bytes, N, H, W, C0 + C1, Cout, &pack, &part));
+    float* am;
+    RC(layer_amax(ws, eld_layer_workspace_bytes(N, H, W, C0 + C1, Cout), as_stream(stream), g, (size_t)N * H * W * Cout, x1, (size_t)N * H * W * C1, x0, (size_t)N * H * W * C0, &am));
+    if (am) { g_am.in0 = am; g_am.in1 = x1 ? am + 1 : nullptr; g_am.w = am + 2; }
     return conv_wgrad(g, Cout, x0, C0, x1, C1, C0 + C1, dw, db, part, N, H, W, as_stream(stream));
 }
 
@@ -624,6 +700,9 @@ extern "C" int eld_convt2x2_forward(const float* in, const float* w, const float
     RC(layer_ws(ws, ws_bytes, N, H, W, Cin, Cout, &pack, &part));
     hipStream_t st = as_stream(stream);
     RC(launch_pack(w, pack, PACK_CONVT_FWD, Cout, Cin, Cin, 4, st));
+    float* am;
+    RC(layer_amax(ws, eld_layer_workspace_bytes(N, H, W, Cin, Cout), st, in, (size_t)N * H * W * Cin, nullptr, 0, pack, (size_t)4 * Cout * Cin, &am));
+    if (am) { g_am.in0 = am; g_am.w = am + 2; g_am.out0 = am + 3; }
     return convt_fwd(in, pack, bias, out, N, H, W, Cin, Cout, st);
 }
 
@@ -635,6 +714,9 @@ extern "C" int eld_convt2x2_backward_data(const float* dout, const float* w, con
     RC(layer_ws(ws, ws_bytes, N, H, W, Cin, Cout, &pack, &part));
     hipStream_t st = as_stream(stream);
     RC(launch_pack(w, pack, PACK_CONVT_BWD, Cout, Cin, Cin, 4, st));
+    float* am;
+    RC(layer_amax(ws, eld_layer_workspace_bytes(N, H, W, Cin, Cout), st, dout, (size_t)N * 4 * H * W * Cout, nullptr, 0, pack, (size_t)4 * Cout * Cin, &am));
+    if (am) { g_am.in0 = am; g_am.w = am + 2; g_am.out0 = am + 3; }
     return convt_bwd_data(dout, pack, act, din, N, H, W, Cin, Cout, st);
 }
 
@@ -644,6 +726,9 @@ extern "C" int eld_convt2x2_backward_weight(const float* in, const float* dout, 
     if (!in || !dout || !dw || Cin % 32 || Cout % 4) return ELD_EINVAL;
     float *pack, *part;
     RC(layer_ws(ws, ws_bytes, N, H, W, Cin, Cout, &pack, &part));
+    float* am;
+    RC(layer_amax(ws, eld_layer_workspace_bytes(N, H, W, Cin, Cout), as_stream(stream), in, (size_t)N * H * W * Cin, nullptr, 0, dout, (size_t)N * 4 * H * W * Cout, &am));
+    if (am) { g_am.in0 = am; g_am.w = am + 2; }
     return convt_wgrad(in, dout, dw, db, part, N, H, W, Cin, Cout, as_stream(stream));
 }
 

@@ -341,19 +341,41 @@ int launch_pack(const float* src, float* dst, int kind, int Cout, int Cin, int C
     return 0;
 }
 
+// max |x| of a tensor into *slot (atomic max on the bit pattern; slot zeroed by the caller) -- operand bound of the two-piece
+// fp16 product scheme for tensors whose producer does not report it
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, size_t n, float* __restrict__ slot) {
+    float mx = 0.f;
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) mx = fmaxf(mx, fabsf(x[n4 * 4 + threadIdx.x]));
+    amax_accumulate(slot, mx);
+}
+
+int launch_absmax(const float* x, size_t n, float* slot, hipStream_t st) {
+    if (!n) return 0;
+    const unsigned nb = (unsigned)min((n / 4 + 255) / 256 + 1, (size_t)2048);
+    ELD_LAUNCH(absmax_kernel, dim3(nb), dim3(256), 0, st, x, n, slot);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
 // all layers of the network in ONE launch: block b belongs to job j with first_block[j] <= b < first_block[j+1]
-__global__ void pack_all_kernel(const PackJobs jobs, const float* __restrict__ params, float* __restrict__ ws) {
+__global__ void pack_all_kernel(const PackJobs jobs, const float* __restrict__ params, float* __restrict__ ws, float* __restrict__ amax) {
     int j = 0;
     while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.job[j + 1].first_block) ++j;
     const PackJob J = jobs.job[j];
     const size_t total = (size_t)J.T * J.Cout * (J.kind == PACK_CONV_FWD ? J.Cinp : J.Cin);
     const size_t i = (size_t)(blockIdx.x - J.first_block) * blockDim.x + threadIdx.x;
-    if (i >= total) return;
+    const bool live = i < total;
     const float* src = params + J.src_off;
     float* dst = ws + J.dst_off;
     const int Cout = J.Cout, Cin = J.Cin, Cinp = J.Cinp, T = J.T;
-    float v;
-    if (J.kind == PACK_CONV_FWD) {
+    float v = 0.f;
+    if (!live) {
+    } else if (J.kind == PACK_CONV_FWD) {
         const int ci = (int)(i % Cinp); const int co = (int)((i / Cinp) % Cout); const int t = (int)(i / ((size_t)Cinp * Cout));
         v = ci < Cin ? src[((size_t)co * Cin + ci) * T + t] : 0.f;
     } else if (J.kind == PACK_CONV_BWD) {
@@ -366,11 +388,14 @@ __global__ void pack_all_kernel(const PackJobs jobs, const float* __restrict__ p
         const int co = (int)(i % Cout); const int ci = (int)((i / Cout) % Cin); const int t = (int)(i / ((size_t)Cout * Cin));
         v = src[((size_t)ci * Cout + co) * T + t];
     }
-    if (J.bf16) reinterpret_cast<bf16_t*>(dst)[i] = f2bf(v);
-    else dst[i] = v;
+    if (live) {
+        if (J.bf16) reinterpret_cast<bf16_t*>(dst)[i] = f2bf(v);
+        else dst[i] = v;
+    }
+    if (amax) amax_accumulate(amax + J.amax_slot, v);          // per-layer weight bound (all lanes take part)
 }
 
-int launch_pack_all(PackJobs& jobs, const float* params, float* ws, hipStream_t st) {
+int launch_pack_all(PackJobs& jobs, const float* params, float* ws, hipStream_t st, float* amax) {
     int blocks = 0;
     for (int j = 0; j < jobs.n; ++j) {
         PackJob& J = jobs.job[j];
@@ -379,7 +404,7 @@ int launch_pack_all(PackJobs& jobs, const float* params, float* ws, hipStream_t 
         blocks += (int)((total + 255) / 256);
     }
     if (!blocks) return 0;
-    ELD_LAUNCH(pack_all_kernel, dim3(blocks), dim3(256), 0, st, jobs, params, ws);
+    ELD_LAUNCH(pack_all_kernel, dim3(blocks), dim3(256), 0, st, jobs, params, ws, amax);
     ELD_LAUNCH_CHECK();
     return 0;
 }

@@ -152,7 +152,10 @@ int eld_unet_backward_buckets(const float* dout, const float* params, float* gra
 /* How the fp32 3x3 convolutions of eld_unet_forward/backward and eld_conv3x3_* form their products:
  *   0  v_mfma_f32_32x32x2_f32 (fp32 operands);
  *   1  every fp32 operand cut exactly into three bf16 pieces, six v_mfma_f32_32x32x16_bf16 per k-block, fp32 accumulate
- *      (same fp32-level accuracy, see csrc/conv_x3.hip).
+ *      (same fp32-level accuracy, see csrc/conv_x3.hip);
+ *   2  every fp32 operand scaled by a per-tensor power of two and cut into two fp16 pieces (22 significant bits), three
+ *      v_mfma_f32_32x32x16_f16 per k-block, fp32 accumulate: each product is good to 2^-22 instead of 2^-24, which stays
+ *      inside the fp32 dot-product error bound for every contraction length >= 4 (csrc/conv_igemm.hip, H2).
  * algo < 0 only queries.  Process-wide; returns the value in force before the call.  Initial value: env ELD_FP32_CONV. */
 int eld_conv_fp32_algo(int algo);
 

@@ -20,7 +20,7 @@ def lib(eld_lib):
     return eld_lib
 
 
-@pytest.fixture(params=[0, 1], ids=['fp32mfma', 'bf16x3'])
+@pytest.fixture(params=[0, 1, 2], ids=['fp32mfma', 'bf16x3', 'fp16x2'])
 def algo(request, lib):
     """Run the test under both fp32 conv product schemes (include/eld_amd.h eld_conv_fp32_algo); same tolerance for both."""
     prev = lib.eld_conv_fp32_algo(request.param)
