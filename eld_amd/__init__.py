@@ -15,3 +15,14 @@ from ._lib import load_library, lib, LibraryMissing  # noqa: F401
 
 __all__ = ['load_library', 'lib', 'LibraryMissing']
 __version__ = '0.1.0'
+
+
+FP32_PRODUCT_SCHEMES = {'mfma': 0, 'bf16x3': 1, 'fp16x2': 2}
+
+
+def set_fp32_products(scheme):
+    """How the fp32 convolutions form their products (process-wide; include/eld_amd.h eld_conv_fp32_algo): 'bf16x3' (default:
+    exact three-piece bf16 split, 6 MFMA products), 'fp16x2' (two fp16 pieces behind per-tensor power-of-two scales, 22-bit
+    products, 3 MFMA products, ~1.3x faster) or 'mfma' (v_mfma_f32_32x32x2_f32).  Returns the previous scheme's name."""
+    prev = load_library().eld_conv_fp32_algo(FP32_PRODUCT_SCHEMES[scheme])
+    return [k for k, v in FP32_PRODUCT_SCHEMES.items() if v == prev][0]
