@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
                     for (int tt = 0; tt < TROW; ++tt) acc[t0 + tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], xb[tt][0], acc[t0 + tt], 0, 0, 0);
                 }
-                if constexpr (X3 && MODE == CONV_3X3) __builtin_amdgcn_sched_barrier(0);      // keep the next row's reads below: 256-VGPR budget
+                if constexpr ((X3 || H2) && MODE == CONV_3X3) __builtin_amdgcn_sched_barrier(0);      // keep the next row's reads below: 256-VGPR budget
             }
         }
         } else if constexpr (!BFM) {
@@ -373,7 +373,8 @@ int launch_wgrad(const WgradArgs& a, int mode, hipStream_t st) {
     }
     if (conv_fp32_algo(-1) == 2) {
         if (!a.amax_g || !a.amax_x0) return ELD_EINVAL;
-        if (mode == CONV_3X3) return c64 ? launch_w<float, CONV_3X3, 2, 4, ALG_H2>(a, st) : launch_w<float, CONV_3X3, 1, 4, ALG_H2>(a, st);
+        // 64-channel blocks: 2-row tiles (the 4-row variant needs 60 staging registers on top of 144 accumulators and spills)
+        if (mode == CONV_3X3) return c64 ? launch_w<float, CONV_3X3, 2, 2, ALG_H2>(a, st) : launch_w<float, CONV_3X3, 1, 4, ALG_H2>(a, st);
         if (mode == CONV_GATHER2X2) return c64 ? launch_w<float, CONV_GATHER2X2, 2, 2, ALG_H2>(a, st) : launch_w<float, CONV_GATHER2X2, 1, 2, ALG_H2>(a, st);
         return ELD_EINVAL;
     }
