@@ -177,7 +177,11 @@ def main():
         'dtype': 'f32' if args.precision == 'fp32' else 'bf16', 'data': 'synthetic',
         'config': {'workload': 'BASELINE.json configs[%d]: full ELD noise model (%s, SonyA7S2 params) on 4x%dx%d packed raw + U-Net %s '
                                'train step (fwd, L1, bwd, Adam), %d frames per GPU' % (1 if args.precision == 'fp32' else 2, args.noise, Hh, Ww, args.precision, B),
-                   'images_per_gpu': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world, 'final_loss': loss},
+                   'images_per_gpu': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world, 'final_loss': loss,
+                   'fp32_products': (None if args.precision != 'fp32' else
+                                     {0: 'v_mfma_f32_32x32x2_f32', 1: 'fp32 operands cut exactly into 3 bf16 pieces, 6 bf16 MFMA products per k-block, fp32 accumulate '
+                                      '(each product exact to below fp32 rounding; eld_conv_fp32_algo 1)', 2: '2 fp16 pieces per operand (22-bit products), fp32 accumulate'}
+                                     [eld_amd.load_library().eld_conv_fp32_algo(-1)])},
     }
 
     if rank == 0:
