@@ -497,6 +497,11 @@ extern "C" int eld_noise_forward(const void* in, int in_dtype, float* out, const
         case PG: return launch_noise<true, PG, false>(a, N, st);
         case PG | ELD_CLIP: return launch_noise<true, PG | ELD_CLIP, false>(a, N, st);
         case ELD_READ_GAUSS: return launch_noise<true, ELD_READ_GAUSS, false>(a, N, st);
+        case ELD_READ_GAUSS | ELD_CLIP: return launch_noise<true, ELD_READ_GAUSS | ELD_CLIP, false>(a, N, st);
+        case ELD_SHOT_GAUSS | ELD_READ_GAUSS: return launch_noise<true, ELD_SHOT_GAUSS | ELD_READ_GAUSS, false>(a, N, st);                       // 'pg'
+        case ELD_SHOT_GAUSS | ELD_READ_GAUSS | ELD_CLIP: return launch_noise<true, ELD_SHOT_GAUSS | ELD_READ_GAUSS | ELD_CLIP, false>(a, N, st);
+        case 0u: return launch_noise<true, 0u, false>(a, N, st);                                                                                     // '' (scale only)
+        case ELD_CLIP: return launch_noise<true, ELD_CLIP, false>(a, N, st);
         default: return launch_noise<true, RUNTIME_FLAGS, false>(a, N, st);
     }
 }
