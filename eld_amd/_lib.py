@@ -10,6 +10,7 @@ LIB_PATH = os.path.join(_HERE, 'libeld_amd.so')
 
 # flags / enums of include/eld_amd.h
 SHOT_POISSON, SHOT_GAUSS, READ_GAUSS, READ_TL, ROW, QUANT, CBIAS, CLIP = 1, 2, 4, 8, 16, 32, 64, 128
+AUG_NOTRANSPOSE = 256
 IN_F32, IN_U16 = 0, 1
 NPLANES = 6
 PLANE = {'counts': 0, 'n_shot': 1, 'n_read': 2, 't_tl': 3, 'n_row': 4, 'u_q': 5}
@@ -29,6 +30,8 @@ SIGNATURES = {
     'eld_build_info': (C.c_char_p, []),
     'eld_error_string': (C.c_char_p, [_i]),
     'eld_noise_forward': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _u32, _u64, _vp, _vp, _vp]),
+    'eld_noise_forward_strided': (_i, [_vp, _i, _sz, _vp, _sz, _vp, _i, _i, _i, _i, _u32, _u64, _vp, _vp, _vp]),
+    'eld_augment_u16': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _u32, _vp]),
     'eld_philox_words': (_i, [_vp, _u32, _u32, _u64, _u32, _u32, _u64, _vp]),
     'eld_pack_bayer': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'eld_unpack_bayer': (_i, [_vp, _vp, _i, _i, _i, _vp]),
@@ -40,6 +43,8 @@ SIGNATURES = {
     'eld_unet_backward': (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
     'eld_unet_backward_bf16': (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _vp]),
     'eld_unet_backward_buckets': (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    'eld_unet_forward_ex': (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    'eld_unet_backward_ex': (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     'eld_conv_fp32_algo': (_i, [_i]),
     'eld_debug_conv_prof': (None, [_vp]),
     'eld_isp_process': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _i, _vp]),

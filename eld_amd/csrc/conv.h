@@ -35,6 +35,7 @@ struct ConvArgs {
     int Cout_t;         // EPI_CONVT_FWD: real Cout (Nout = 4*Cout_t, n = tap*Cout_t + co)
     int tiles_x, tiles_y;
     int dtype;          // DT_F32 / DT_BF16
+    int algo;           // fp32 product scheme of THIS call: 0 fp32 MFMA, 1 three bf16 pieces, 2 two fp16 pieces; < 0 = process default (conv_fp32_algo)
     int dbg;            // ablation switches for tools/ (env ELD_CONV_DBG): 1 skip epilogue, 4 skip staging loads, 8/16 skip slab/halo stores (conv_x3), 64 one workgroup per CU
     unsigned long long* prof;   // dev tool (eld_debug_conv_prof): per-stage s_memtime stamps of the first workgroups; null in production
     // two-piece fp16 product scheme (conv_fp32_algo 2): device floats holding an upper bound of max|.| of each operand tensor
@@ -83,7 +84,9 @@ __device__ __forceinline__ float4 unpack_bf4(uint2 p) {
 int launch_conv(const ConvArgs& a, int mode, hipStream_t st);
 // fp32 3x3 convolutions: 0 = exact-fp32 MFMA (conv_igemm.hip), 1 = three-piece bf16 split on the bf16 MFMA (conv_x3.hip).
 // set < 0 only queries.  Initial value from env ELD_FP32_CONV (mfma | x3).  Returns the value in force before the call.
+// This is only the DEFAULT for calls that do not name a scheme (ConvArgs::algo < 0); every launcher resolves it once per call.
 int conv_fp32_algo(int set);
+inline int resolve_algo(int algo) { return (algo >= 0 && algo <= 2) ? algo : conv_fp32_algo(-1); }
 int launch_conv_x3(const ConvArgs& a, hipStream_t st);
 void conv_x3_set_prof(unsigned long long* buf);      // dev tool: 8 workgroups x 4 waves x 128 stages x 6 stamps
 int launch_conv_x3_gemm(const ConvArgs& a, int mode, hipStream_t st);      // transposed-conv directions; ELD_ENOTSUP if not covered
@@ -102,6 +105,7 @@ struct WgradArgs {
     int psplit;
     int tiles_x, tiles_y;
     int dtype;           // DT_F32 / DT_BF16 inputs (partials and accumulation are always fp32)
+    int algo;            // as ConvArgs::algo
     const float* amax_g; const float* amax_x0; const float* amax_x1;     // algo 2 only: see ConvArgs
 };
 

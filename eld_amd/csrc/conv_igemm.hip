@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
             __syncthreads();                 // every wave is done reading the previous chunk
             store_chunk();
             __syncthreads();
-            if (!(a.dbg & 4)) {
+            if (!(ELD_DBG(a) & 4)) {
                 if (c0 + CK < Cin) {
                     load_chunk(c0 + CK);         // in flight during the MFMA phase below
                 } else if (t_next < total_tiles) {
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
                     load_chunk(0);
                 }
             }
-            if (a.dbg & 2) continue;
+            if (ELD_DBG(a) & 2) continue;
             // ---- MFMA over taps x the chunk's 64 bytes of K.  Group g = (tap, q): every lane reads 16 bytes per operand
             //      row (fp32: 4 channels of its k-half -> 4 x v_mfma_f32_32x32x2_f32; bf16: 8 channels = one whole
             //      v_mfma_f32_32x32x16_bf16 operand).  Fragments of group g+1 are read from LDS while group g's MFMAs
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
                 const int y = y0 + wave * RPW + r;
-                if (y >= a.H || (a.dbg & 1) || !xok) continue;
+                if (y >= a.H || (ELD_DBG(a) & 1) || !xok) continue;
                 const size_t pix = (size_t)(img * a.H + y) * a.W + x;
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) {
@@ -372,16 +372,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     }
 }
 
-static int num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
 
 template <typename T, int MODE, int BN, int RPW, bool H2 = false>
 static int launch_t(ConvArgs a, hipStream_t st) {
@@ -393,17 +383,13 @@ static int launch_t(ConvArgs a, hipStream_t st) {
     if (tiles <= 0) return 0;
     if (tiles > 0x7fffffffLL) return ELD_ENOTSUP;
     auto kern = conv_igemm_kernel<T, MODE, BN, RPW, H2>;
-    static bool attr_set = false;     // per instantiation
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static EldAttrOnce once;          // per instantiation, per device
+    { const int rc = once.ensure(kern, lds_bytes); if (rc) return rc; }
     // persistent grid: as many workgroups as are co-resident (LDS: 160 KiB per CU; registers: 2 waves per SIMD)
     int per_cu = (int)((160 * 1024) / lds_bytes);
     if (per_cu > 2) per_cu = 2;
     if (per_cu < 1) per_cu = 1;
-    long long grid = (long long)num_cus() * per_cu;
+    long long grid = (long long)eld_num_cus() * per_cu;
     if (grid > tiles) grid = tiles;
     ELD_LAUNCH(kern, dim3((unsigned)grid), dim3(256), lds_bytes, st, a);
     ELD_LAUNCH_CHECK();
@@ -436,9 +422,10 @@ int conv_fp32_algo(int set) {
 
 int launch_conv(const ConvArgs& a_in, int mode, hipStream_t st) {
     ConvArgs a = a_in;
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("ELD_CONV_DBG"); dbg = e ? atoi(e) : 0; }
-    a.dbg = dbg;
+    a.dbg = 0;
+#if ELD_DEV_TOOLS
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("ELD_CONV_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
+#endif
     const int Cin = a.C0 + a.C1;
     const int ck = a.dtype == DT_BF16 ? 32 : 16;
     if (Cin % ck || a.C0 % ck || a.Nout % 32) return ELD_EINVAL;
@@ -446,12 +433,13 @@ int launch_conv(const ConvArgs& a_in, int mode, hipStream_t st) {
     if (a.epi == EPI_GRAD && (a.split % 32)) return ELD_EINVAL;
     if (a.epi == EPI_CONVT_FWD && (a.Cout_t % 4)) return ELD_EINVAL;
     if (a.dtype == DT_BF16) return launch_dt<bf16_t>(a, mode, st);
-    if (mode == CONV_3X3 && a.epi != EPI_CONVT_FWD && conv_fp32_algo(-1) == 1) return launch_conv_x3(a, st);
-    if (mode != CONV_3X3 && conv_fp32_algo(-1) == 1) {
+    const int algo = resolve_algo(a.algo);
+    if (mode == CONV_3X3 && a.epi != EPI_CONVT_FWD && algo == 1) return launch_conv_x3(a, st);
+    if (mode != CONV_3X3 && algo == 1) {
         const int rc = launch_conv_x3_gemm(a, mode, st);
         if (rc != ELD_ENOTSUP) return rc;
     }
-    if (conv_fp32_algo(-1) == 2) {                    // two fp16 pieces per operand, three products; needs the operand bounds
+    if (algo == 2) {                    // two fp16 pieces per operand, three products; needs the operand bounds
         if (!a.amax_in0 || !a.amax_w) return ELD_EINVAL;
         const bool n64 = a.Nout % 64 == 0;
         switch (mode) {

@@ -343,12 +343,8 @@ static int launch_w(WgradArgs a, hipStream_t st) {
     const long long blocks = (long long)(a.CA / COB) * (a.CBp / JB) * a.psplit;
     if (blocks <= 0) return 0;
     auto kern = wgrad_kernel<T, MODE, WCO, TH, ALG>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static EldAttrOnce once;
+    { const int rc = once.ensure(kern, lds_bytes); if (rc) return rc; }
     ELD_LAUNCH(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
     ELD_LAUNCH_CHECK();
     return 0;
@@ -371,16 +367,17 @@ int launch_wgrad(const WgradArgs& a, int mode, hipStream_t st) {
         if (mode == CONV_GATHER2X2) return c64 ? launch_w<bf16_t, CONV_GATHER2X2, 2, 2>(a, st) : launch_w<bf16_t, CONV_GATHER2X2, 1, 2>(a, st);
         return ELD_EINVAL;
     }
-    if (conv_fp32_algo(-1) == 2) {
+    const int algo = resolve_algo(a.algo);
+    if (algo == 2) {
         if (!a.amax_g || !a.amax_x0) return ELD_EINVAL;
         // 64-channel blocks: 2-row tiles (the 4-row variant needs 60 staging registers on top of 144 accumulators and spills)
         if (mode == CONV_3X3) return c64 ? launch_w<float, CONV_3X3, 2, 2, ALG_H2>(a, st) : launch_w<float, CONV_3X3, 1, 4, ALG_H2>(a, st);
         if (mode == CONV_GATHER2X2) return c64 ? launch_w<float, CONV_GATHER2X2, 2, 2, ALG_H2>(a, st) : launch_w<float, CONV_GATHER2X2, 1, 2, ALG_H2>(a, st);
         return ELD_EINVAL;
     }
-    if (mode == CONV_3X3 && conv_fp32_algo(-1) == 1) return c64 ? launch_w<float, CONV_3X3, 2, 2, ALG_X3>(a, st) : launch_w<float, CONV_3X3, 1, 2, ALG_X3>(a, st);
+    if (mode == CONV_3X3 && algo == 1) return c64 ? launch_w<float, CONV_3X3, 2, 2, ALG_X3>(a, st) : launch_w<float, CONV_3X3, 1, 2, ALG_X3>(a, st);
     if (mode == CONV_3X3) return c64 ? launch_w<float, CONV_3X3, 2, 4>(a, st) : launch_w<float, CONV_3X3, 1, 4>(a, st);
-    if (mode == CONV_GATHER2X2 && conv_fp32_algo(-1) == 1) return c64 ? launch_w<float, CONV_GATHER2X2, 2, 2, ALG_X3>(a, st) : launch_w<float, CONV_GATHER2X2, 1, 2, ALG_X3>(a, st);
+    if (mode == CONV_GATHER2X2 && algo == 1) return c64 ? launch_w<float, CONV_GATHER2X2, 2, 2, ALG_X3>(a, st) : launch_w<float, CONV_GATHER2X2, 1, 2, ALG_X3>(a, st);
     if (mode == CONV_GATHER2X2) return c64 ? launch_w<float, CONV_GATHER2X2, 2, 2>(a, st) : launch_w<float, CONV_GATHER2X2, 1, 2>(a, st);
     return ELD_EINVAL;
 }

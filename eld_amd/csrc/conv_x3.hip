@@ -161,17 +161,17 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
             for (int ky = 0; ky < 3; ++ky) {
                 __builtin_amdgcn_s_setprio(3);   // the short staging section goes ahead of the co-resident workgroup's MFMA stream
                 unsigned long long* pf = nullptr;
-                if (a.prof && blockIdx.x < 8 && lane == 0 && pstage < 128) pf = a.prof + (((size_t)blockIdx.x * 4 + wave) * 128 + pstage) * 6;
+                if (ELD_PROF(a) && blockIdx.x < 8 && lane == 0 && pstage < 128) pf = ELD_PROF(a) + (((size_t)blockIdx.x * 4 + wave) * 128 + pstage) * 6;
                 ++pstage;
                 if (pf) pf[0] = __builtin_amdgcn_s_memtime();
                 __syncthreads();                 // every wave is done with the previous stage's operands
                 if (pf) pf[1] = __builtin_amdgcn_s_memtime();
-                if (ky == 0 && !(a.dbg & 16)) store_A();
-                if (!(a.dbg & 8)) store_B();
+                if (ky == 0 && !(ELD_DBG(a) & 16)) store_A();
+                if (!(ELD_DBG(a) & 8)) store_B();
                 if (pf) { __builtin_amdgcn_s_waitcnt(0xC07F); pf[2] = __builtin_amdgcn_s_memtime(); }
                 __syncthreads();
                 if (pf) pf[3] = __builtin_amdgcn_s_memtime();
-                if (!(a.dbg & 4)) {
+                if (!(ELD_DBG(a) & 4)) {
                     if (ky == 0) {               // the halo tile of the next chunk / next tile has three stages to arrive
                         if (!last_chunk) load_A(c0 + CK);
                         else if (t_next < total_tiles) { setup_load(t_next); load_A(0); }
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
                 const int y = y0 + wave * RPW + r;
-                if (y >= a.H || (a.dbg & 1) || !xok) continue;
+                if (y >= a.H || (ELD_DBG(a) & 1) || !xok) continue;
                 const size_t pix = (size_t)(img * a.H + y) * a.W + x;
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) {
@@ -488,17 +488,6 @@ __global__ __launch_bounds__(256, 2) void conv_x3_gemm_kernel(const ConvArgs a) 
     }
 }
 
-int num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
-
 template <int BN, int RPW, bool DB>
 int launch_x3(ConvArgs a, hipStream_t st) {
     constexpr int TH = 4 * RPW;
@@ -509,17 +498,13 @@ int launch_x3(ConvArgs a, hipStream_t st) {
     if (tiles <= 0) return 0;
     if (tiles > 0x7fffffffLL) return ELD_ENOTSUP;
     auto kern = conv_x3_kernel<BN, RPW, DB>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static EldAttrOnce once;
+    { const int rc = once.ensure(kern, lds_bytes); if (rc) return rc; }
     int per_cu = (int)((160 * 1024) / lds_bytes);
     if (per_cu > 2) per_cu = 2;
     if (per_cu < 1) per_cu = 1;
-    if (a.dbg & 64) per_cu = 1;
-    long long grid = (long long)num_cus() * per_cu * ((a.dbg & 128) ? 2 : 1);
+    if (ELD_DBG(a) & 64) per_cu = 1;
+    long long grid = (long long)eld_num_cus() * per_cu * ((ELD_DBG(a) & 128) ? 2 : 1);
     if (grid > tiles) grid = tiles;
     ELD_LAUNCH(kern, dim3((unsigned)grid), dim3(256), lds_bytes, st, a);
     ELD_LAUNCH_CHECK();
@@ -535,13 +520,9 @@ int launch_x3_gemm(ConvArgs a, hipStream_t st) {
     if (tiles <= 0) return 0;
     if (tiles > 0x7fffffffLL) return ELD_ENOTSUP;
     auto kern = conv_x3_gemm_kernel<MODE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    long long grid = (long long)num_cus() * 2;
+    static EldAttrOnce once;
+    { const int rc = once.ensure(kern, lds_bytes); if (rc) return rc; }
+    long long grid = (long long)eld_num_cus() * 2;
     if (grid > tiles) grid = tiles;
     ELD_LAUNCH(kern, dim3((unsigned)grid), dim3(256), lds_bytes, st, a);
     ELD_LAUNCH_CHECK();
@@ -550,13 +531,20 @@ int launch_x3_gemm(ConvArgs a, hipStream_t st) {
 
 }  // namespace
 
+#if ELD_DEV_TOOLS
 static unsigned long long* g_prof = nullptr;
 void conv_x3_set_prof(unsigned long long* buf) { g_prof = buf; }
+#else
+void conv_x3_set_prof(unsigned long long*) {}
+#endif
 
 // a: fp32 CONV_3X3 arguments already validated by launch_conv
 int launch_conv_x3(const ConvArgs& a_in, hipStream_t st) {
     ConvArgs a = a_in;
+    a.prof = nullptr;
+#if ELD_DEV_TOOLS
     a.prof = g_prof;
+#endif
     if ((size_t)a.H * a.W * a.C0 * 4 >= 0xFFFFFFF0ull) return ELD_ENOTSUP;
     return a.Nout % 64 == 0 ? launch_x3<64, 2, true>(a, st) : launch_x3<32, 4, false>(a, st);
 }

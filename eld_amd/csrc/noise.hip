@@ -36,6 +36,7 @@ struct NoiseArgs {
     const float* inject;
     float* dump;
     size_t total;          // N*C*H*W (plane stride of inject/dump)
+    size_t in_stride, out_stride;   // elements between consecutive images of in / out (chw when dense)
     uint32_t chw, ngroups, C, H, W;
     FastDiv divW, divH;    // divW divides by W/4 in the vector kernel, by W in the scalar kernel
     uint32_t flags, in_dtype;
@@ -151,7 +152,7 @@ __device__ __forceinline__ float row_normal(uint32_t srow, const SamplerRng& rng
 }
 
 template <bool VEC>
-__device__ __forceinline__ void load_y4(const NoiseArgs& a, size_t img_off, uint32_t e0, uint32_t nvalid, float (&y)[4]) {
+__device__ __forceinline__ void load_y4(const NoiseArgs& a, size_t img_off /* n * in_stride */, uint32_t e0, uint32_t nvalid, float (&y)[4]) {
     if (VEC) {
         if (a.in_dtype == ELD_IN_U16) {
             const ushort4 q = *reinterpret_cast<const ushort4*>(static_cast<const uint16_t*>(a.in) + img_off + e0);
@@ -194,7 +195,8 @@ __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a)
     const uint32_t tid = threadIdx.x;
     const uint32_t g_begin = blockIdx.x * GROUPS_PER_BLOCK;
     const uint32_t g_end = min(g_begin + GROUPS_PER_BLOCK, a.ngroups);
-    const size_t img_off = (size_t)n * a.chw;
+    const size_t img_off = (size_t)n * a.chw;                  // debug planes (inject / dump) are dense
+    const size_t in_off = (size_t)n * a.in_stride, out_off = (size_t)n * a.out_stride;
     const bool inject = DEBUG && a.inject != nullptr;
     const bool do_pois = MAYBE_P && (flags & ELD_SHOT_POISSON) && !inject;
     const float S = P.saturation, ratio = P.ratio, K = P.K;
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a)
                 float y[4] = {0.f, 0.f, 0.f, 0.f};
                 uint4 wd = make_uint4(0, 0, 0, 0), wd2 = make_uint4(0, 0, 0, 0);
                 if (gv) {
-                    load_y4<VEC>(a, img_off, e0, nvalid, y);
+                    load_y4<VEC>(a, in_off, e0, nvalid, y);
                     wd = rng.words(g, STREAM_POIS_U);
                     wd2 = rng.words(g, STREAM_POIS_V);
                 }
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a)
                 kk[e] = 0;
                 any_small |= small;
             }
-            if (__any(any_small) && !(a.dbg & 2)) {
+            if (__any(any_small) && !(ELD_DBG(a) & 2)) {
 #pragma unroll 1
                 for (int it = 1; it <= INV_ITERS1; ++it) {
                     bool act = false;
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a)
                 if (!ok[e]) continue;
                 if (lam[e] < 10.0f) {
                     if (r[e] > 0.f) pendI |= 1u << e;
-                } else if (a.dbg & 4) {
+                } else if (ELD_DBG(a) & 4) {
                     kk[e] = (int)lam[e];
                 } else {
                     Ptrs T;
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a)
         }
         __syncthreads();
         // ---- phase 2: drain the queues with dense lanes -------------------------------------------------------
-        const uint32_t nP = (a.dbg & 1) ? 0u : min(s_qn[0], (uint32_t)QP_CAP), nI = (a.dbg & 1) ? 0u : min(s_qn[1], (uint32_t)QI_CAP);
+        const uint32_t nP = (ELD_DBG(a) & 1) ? 0u : min(s_qn[0], (uint32_t)QP_CAP), nI = (ELD_DBG(a) & 1) ? 0u : min(s_qn[1], (uint32_t)QI_CAP);
         for (uint32_t q = tid; q < nP; q += NOISE_THREADS) {
             const uint2 en = s_qp[q];
             s_cnt[en.x] = ptrs_resolve(__uint_as_float(en.y), g_begin * 4u + en.x, rng);
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a)
         const uint32_t le0 = (uint32_t)it * (NOISE_THREADS * 4u) + tid * 4u;
 
         float y[4] = {0.f, 0.f, 0.f, 0.f};
-        if (!do_pois || !(flags & ELD_SHOT_POISSON) || DEBUG) load_y4<VEC>(a, img_off, e0, nvalid, y);
+        if (!do_pois || !(flags & ELD_SHOT_POISSON) || DEBUG) load_y4<VEC>(a, in_off, e0, nvalid, y);
         float4 cnt4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (do_pois) cnt4 = *reinterpret_cast<const float4*>(&s_cnt[le0]);
 
@@ -355,8 +357,8 @@ __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a)
         uint4 w_tl, w_q;
         float nrd[4], nsh[4];
         if (!inject) {
-            if (flags & ELD_READ_TL) w_tl = (a.dbg & 8) ? make_uint4(g, g * 3u, g * 5u, g * 7u) : rng.words(g, STREAM_TL);
-            if (flags & ELD_QUANT) w_q = (a.dbg & 8) ? make_uint4(g, g * 3u, g * 5u, g * 7u) : rng.words(g, STREAM_QUANT);
+            if (flags & ELD_READ_TL) w_tl = (ELD_DBG(a) & 8) ? make_uint4(g, g * 3u, g * 5u, g * 7u) : rng.words(g, STREAM_TL);
+            if (flags & ELD_QUANT) w_q = (ELD_DBG(a) & 8) ? make_uint4(g, g * 3u, g * 5u, g * 7u) : rng.words(g, STREAM_QUANT);
             if (flags & ELD_READ_GAUSS) {
                 const uint4 w = rng.words(g, STREAM_NREAD);
                 const float2 p0 = box_muller(w.x, w.y), p1 = box_muller(w.z, w.w);
@@ -439,11 +441,11 @@ __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a)
         }
 
         if (VEC) {
-            *reinterpret_cast<float4*>(a.out + img_off + e0) = make_float4(z[0], z[1], z[2], z[3]);
+            *reinterpret_cast<float4*>(a.out + out_off + e0) = make_float4(z[0], z[1], z[2], z[3]);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if ((uint32_t)j < nvalid) a.out[img_off + e0 + j] = z[j];
+                if ((uint32_t)j < nvalid) a.out[out_off + e0 + j] = z[j];
         }
     }
 }
@@ -456,9 +458,20 @@ static int launch_noise(const NoiseArgs& a, int N, hipStream_t st) {
     return 0;
 }
 
+extern "C" int eld_noise_forward_strided(const void* in, int in_dtype, size_t in_image_stride, float* out, size_t out_image_stride,
+                                         const EldNoiseParams* params, int N, int C, int H, int W, uint32_t flags, uint64_t seed,
+                                         const float* inject, float* dump, void* stream);
+
 extern "C" int eld_noise_forward(const void* in, int in_dtype, float* out, const EldNoiseParams* params,
                                  int N, int C, int H, int W, uint32_t flags, uint64_t seed,
                                  const float* inject, float* dump, void* stream) {
+    const size_t chw = (size_t)(C > 0 ? C : 0) * (H > 0 ? H : 0) * (W > 0 ? W : 0);
+    return eld_noise_forward_strided(in, in_dtype, chw, out, chw, params, N, C, H, W, flags, seed, inject, dump, stream);
+}
+
+extern "C" int eld_noise_forward_strided(const void* in, int in_dtype, size_t in_image_stride, float* out, size_t out_image_stride,
+                                         const EldNoiseParams* params, int N, int C, int H, int W, uint32_t flags, uint64_t seed,
+                                         const float* inject, float* dump, void* stream) {
     if (N < 0 || C < 0 || H < 0 || W < 0) return ELD_EINVAL;
     if (in_dtype != ELD_IN_F32 && in_dtype != ELD_IN_U16) return ELD_EINVAL;
     if ((flags & ELD_SHOT_POISSON) && (flags & ELD_SHOT_GAUSS)) return ELD_EINVAL;   // 'P' wins in the parser (noise.py:158-160)
@@ -471,18 +484,21 @@ extern "C" int eld_noise_forward(const void* in, int in_dtype, float* out, const
     NoiseArgs a;
     a.in = in; a.out = out; a.params = params; a.inject = inject; a.dump = dump;
     a.total = (size_t)N * chw;
+    if (out_image_stride < chw && N > 1) return ELD_EINVAL;          // outputs must not overlap (inputs may: stride 0 = one clean image)
+    a.in_stride = in_image_stride; a.out_stride = out_image_stride;
     a.chw = (uint32_t)chw;
     a.ngroups = (uint32_t)((chw + 3) / 4);
     a.C = C; a.H = H; a.W = W;
     a.divH = make_fastdiv((uint32_t)H);
     a.flags = flags; a.in_dtype = (uint32_t)in_dtype;
     a.key.k0 = (uint32_t)seed; a.key.k1 = (uint32_t)(seed >> 32);
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("ELD_NOISE_DBG"); dbg = e ? atoi(e) : 0; }
-    a.dbg = (uint32_t)dbg;
+    a.dbg = 0;
+#if ELD_DEV_TOOLS
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("ELD_NOISE_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = (uint32_t)dbg; }
+#endif
 
     const size_t in_align = (in_dtype == ELD_IN_U16) ? 8 : 16;
-    const bool vec = (W % 4 == 0) && ((uintptr_t)in % in_align == 0) && ((uintptr_t)out % 16 == 0);
+    const bool vec = (W % 4 == 0) && ((uintptr_t)in % in_align == 0) && ((uintptr_t)out % 16 == 0) && in_image_stride % 4 == 0 && out_image_stride % 4 == 0;
     a.divW = make_fastdiv(vec ? (uint32_t)W / 4u : (uint32_t)W);
     hipStream_t st = as_stream(stream);
     const bool debug = inject != nullptr || dump != nullptr;
@@ -575,10 +591,11 @@ extern "C" int eld_unpack_bayer(const float* packed, float* mosaic, int N, int h
 // Augmentation (sid_dataset.py:344-352): out = transpose?(flipW?(flipH?(x))) per image, optional clip (:354).
 //   no transpose: out[c][i][j] = x[c][fh(i)][fw(j)]      transpose: out[c][i][j] = x[c][fh(j)][fw(i)]
 // ---------------------------------------------------------------------------------------------
-__global__ void augment_kernel(const float* __restrict__ in, float* __restrict__ out, const int32_t* __restrict__ aug, int C, int H, int W, uint32_t flags) {
+template <typename TI>
+__global__ void augment_kernel(const TI* __restrict__ in, float* __restrict__ out, const int32_t* __restrict__ aug, int C, int H, int W, uint32_t flags) {
     const int n = blockIdx.y;
-    const int bits = aug[n];
-    const bool fh = bits & 1, fw = bits & 2, tr = bits & 4;
+    const int bits = aug ? aug[n] : 0;
+    const bool fh = bits & 1, fw = bits & 2, tr = (bits & 4) && !(flags & ELD_AUG_NOTRANSPOSE);
     const size_t chw = (size_t)C * H * W, hw = (size_t)H * W;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < chw; e += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(e / hw);
@@ -586,20 +603,34 @@ __global__ void augment_kernel(const float* __restrict__ in, float* __restrict__
         const int i = r / W, j = r - i * W;               // output coordinates (H == W when tr)
         const int a = tr ? j : i, b = tr ? i : j;         // coordinates in the flipped image
         const int sy = fh ? H - 1 - a : a, sx = fw ? W - 1 - b : b;
-        float v = in[(size_t)n * chw + (size_t)c * hw + (size_t)sy * W + sx];
+        float v;
+        if constexpr (sizeof(TI) == 2) v = fminf(fmaxf((float)in[(size_t)n * chw + (size_t)c * hw + (size_t)sy * W + sx] / 65535.0f, 0.f), 1.f);   // lmdb_dataset.py:38-39
+        else v = in[(size_t)n * chw + (size_t)c * hw + (size_t)sy * W + sx];
         if (flags & ELD_CLIP) v = fmaxf(fminf(v, 1.0f), 0.0f);
         out[(size_t)n * chw + e] = v;
     }
 }
 
-extern "C" int eld_augment(const float* in, float* out, const int32_t* aug, int N, int C, int H, int W, uint32_t flags, void* stream) {
+template <typename TI>
+static int augment_launch(const TI* in, float* out, const int32_t* aug, int N, int C, int H, int W, uint32_t flags, void* stream, bool need_aug) {
     if (N < 0 || C < 0 || H < 0 || W < 0) return ELD_EINVAL;
     const size_t chw = (size_t)C * H * W;
     if (N == 0 || chw == 0) return 0;
-    if (!in || !out || !aug || in == out) return ELD_EINVAL;
-    if (H != W) return ELD_ENOTSUP;                        // a batch with transposed members must stay rectangular-compatible
+    if (!in || !out || (need_aug && !aug) || (const void*)in == (const void*)out) return ELD_EINVAL;
+    if (!aug) flags |= ELD_AUG_NOTRANSPOSE;
+    // a transposed member of a batched tensor needs H == W; with ELD_AUG_NOTRANSPOSE the caller vouches that no image has bit 4
+    // set (the kernel then ignores that bit) and any H, W is accepted
+    if (H != W && !(flags & ELD_AUG_NOTRANSPOSE)) return ELD_ENOTSUP;
     dim3 grid((unsigned)min((chw + 255) / 256, (size_t)4096), N);
-    ELD_LAUNCH(augment_kernel, grid, dim3(256), 0, as_stream(stream), in, out, aug, C, H, W, flags);
+    ELD_LAUNCH(augment_kernel<TI>, grid, dim3(256), 0, as_stream(stream), in, out, aug, C, H, W, flags);
     ELD_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int eld_augment(const float* in, float* out, const int32_t* aug, int N, int C, int H, int W, uint32_t flags, void* stream) {
+    return augment_launch<float>(in, out, aug, N, C, H, W, flags, stream, true);
+}
+
+extern "C" int eld_augment_u16(const uint16_t* in, float* out, const int32_t* aug, int N, int C, int H, int W, uint32_t flags, void* stream) {
+    return augment_launch<uint16_t>(in, out, aug, N, C, H, W, flags, stream, false);
 }

@@ -80,8 +80,10 @@ WgradGeom wgrad_geom(int mode, int CA, int CB, int N, int H, int W) {
 // consumed (and cleared) by it.  Slots are device floats in the workspace.
 struct Amax { const float* in0 = nullptr; const float* in1 = nullptr; const float* w = nullptr; float* out0 = nullptr; float* out1 = nullptr; };
 thread_local Amax g_am;
-inline void take_amax(ConvArgs& a) { a.amax_in0 = g_am.in0; a.amax_in1 = g_am.in1; a.amax_w = g_am.w; a.amax_out0 = g_am.out0; a.amax_out1 = g_am.out1; g_am = Amax(); }
-inline void take_amax(WgradArgs& a) { a.amax_g = g_am.in0; a.amax_x0 = g_am.w; a.amax_x1 = g_am.in1; g_am = Amax(); }      // wgrad: in0 = G, w = X0, in1 = X1
+thread_local int g_algo = -1;      // fp32 product scheme of the entry point being executed on this thread (-1: process default)
+struct AlgoScope { int prev; explicit AlgoScope(int a) : prev(g_algo) { g_algo = resolve_algo(a); } ~AlgoScope() { g_algo = prev; } };
+inline void take_amax(ConvArgs& a) { a.algo = g_algo; a.amax_in0 = g_am.in0; a.amax_in1 = g_am.in1; a.amax_w = g_am.w; a.amax_out0 = g_am.out0; a.amax_out1 = g_am.out1; g_am = Amax(); }
+inline void take_amax(WgradArgs& a) { a.algo = g_algo; a.amax_g = g_am.in0; a.amax_x0 = g_am.w; a.amax_x1 = g_am.in1; g_am = Amax(); }      // wgrad: in0 = G, w = X0, in1 = X1
 enum { S_W = 0, S_X = 23, S_EA = 24, S_EB = 29, S_UP = 34, S_DA = 38, S_DB = 42, S_GA = 46, S_GB = 47, S_SKIP = 48, S_COUNT = 64 };
 int conv_fwd(const float* in0, int C0, const float* in1, int C1, const float* wp, const float* bias, float* out, int N, int H, int W,
              int Cout, int lrelu, hipStream_t st) {
@@ -261,7 +263,7 @@ struct BucketMarks {
 
 int unet_forward(const Plan& P, const float* x, const float* prm, float* out, float* ws, hipStream_t st) {
     const int N = P.N;
-    const bool h2 = conv_fp32_algo(-1) == 2;                     // operand bounds ride along in the workspace
+    const bool h2 = g_algo == 2;                                 // operand bounds ride along in the workspace
     float* am = ws + P.amax;
     auto AM = [&](int in0, int in1, int w, int out0) {
         if (!h2) return;
@@ -353,7 +355,7 @@ int unet_forward_bf16(const Plan& P, const float* x, const float* prm, float* ou
 
 int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd, float* ws, hipStream_t st, BucketMarks& marks) {
     const int N = P.N;
-    const bool h2 = conv_fp32_algo(-1) == 2;
+    const bool h2 = g_algo == 2;
     float* am = ws + P.amax;
     if (h2 && hipMemsetAsync(am + S_GA, 0, (S_COUNT - S_GA) * sizeof(float), st) != hipSuccess) return (int)hipGetLastError();
     RC(pack_weights(P, prm, ws, true, st, false, h2 ? am : nullptr));
@@ -533,65 +535,63 @@ extern "C" size_t eld_unet_workspace_bytes(int N, int H, int W, int in_ch, int o
     return P.total * sizeof(float);
 }
 
-extern "C" int eld_unet_forward(const float* x, const float* params, float* out, void* ws, size_t ws_bytes, int N, int H, int W,
-                                int in_ch, int out_ch, void* stream) {
-    if (N == 0) return 0;
-    Plan P;
+static int unet_entry_checks(Plan& P, const void* a, const void* b, const void* c, const void* ws, size_t ws_bytes, int N, int H, int W, int in_ch, int out_ch) {
     RC(make_plan(P, N, H, W, in_ch, out_ch));
-    if (!x || !params || !out || !ws) return ELD_EINVAL;
+    if (!a || !b || !c || !ws) return ELD_EINVAL;
     if (ws_bytes < P.total * sizeof(float)) return ELD_EWS;
-    return unet_forward(P, x, params, out, (float*)ws, as_stream(stream));
+    return 0;
 }
 
-extern "C" int eld_unet_forward_bf16(const float* x, const float* params, float* out, void* ws, size_t ws_bytes, int N, int H, int W,
-                                     int in_ch, int out_ch, void* stream) {
+extern "C" int eld_unet_forward_ex(const float* x, const float* params, float* out, void* ws, size_t ws_bytes, int N, int H, int W,
+                                   int in_ch, int out_ch, int precision, int fp32_algo, void* stream) {
     if (N == 0) return 0;
+    if ((precision != 0 && precision != 1) || fp32_algo > 2) return ELD_EINVAL;
     Plan P;
-    RC(make_plan(P, N, H, W, in_ch, out_ch));
-    if (!x || !params || !out || !ws) return ELD_EINVAL;
-    if (ws_bytes < P.total * sizeof(float)) return ELD_EWS;
-    return unet_forward_bf16(P, x, params, out, (float*)ws, as_stream(stream));
+    RC(unet_entry_checks(P, x, params, out, ws, ws_bytes, N, H, W, in_ch, out_ch));
+    AlgoScope scope(fp32_algo);
+    return precision == 1 ? unet_forward_bf16(P, x, params, out, (float*)ws, as_stream(stream)) : unet_forward(P, x, params, out, (float*)ws, as_stream(stream));
 }
 
-extern "C" int eld_unet_backward(const float* dout, const float* params, float* grads, void* ws, size_t ws_bytes, int N, int H, int W,
-                                 int in_ch, int out_ch, void* stream) {
+extern "C" int eld_unet_backward_ex(const float* dout, const float* params, float* grads, void* ws, size_t ws_bytes, int N, int H, int W,
+                                    int in_ch, int out_ch, int precision, int fp32_algo, const int64_t* bucket_start, void* const* bucket_event,
+                                    int n_buckets, void* stream) {
     if (N == 0) return 0;
+    if ((precision != 0 && precision != 1) || fp32_algo > 2) return ELD_EINVAL;
     Plan P;
-    RC(make_plan(P, N, H, W, in_ch, out_ch));
-    if (!dout || !params || !grads || !ws) return ELD_EINVAL;
-    if (ws_bytes < P.total * sizeof(float)) return ELD_EWS;
-    BucketMarks none;
-    return unet_backward(P, dout, params, grads, (float*)ws, as_stream(stream), none);
-}
-
-extern "C" int eld_unet_backward_bf16(const float* dout, const float* params, float* grads, void* ws, size_t ws_bytes, int N, int H, int W,
-                                      int in_ch, int out_ch, void* stream) {
-    if (N == 0) return 0;
-    Plan P;
-    RC(make_plan(P, N, H, W, in_ch, out_ch));
-    if (!dout || !params || !grads || !ws) return ELD_EINVAL;
-    if (ws_bytes < P.total * sizeof(float)) return ELD_EWS;
-    BucketMarks none;
-    return unet_backward_bf16(P, dout, params, grads, (float*)ws, as_stream(stream), none);
-}
-
-extern "C" int eld_unet_backward_buckets(const float* dout, const float* params, float* grads, void* ws, size_t ws_bytes, int N, int H, int W,
-                                         int in_ch, int out_ch, int precision, const int64_t* bucket_start, void* const* bucket_event,
-                                         int n_buckets, void* stream) {
-    if (N == 0) return 0;
-    Plan P;
-    RC(make_plan(P, N, H, W, in_ch, out_ch));
-    if (!dout || !params || !grads || !ws || n_buckets < 0 || (n_buckets > 0 && (!bucket_start || !bucket_event))) return ELD_EINVAL;
-    if (precision != 0 && precision != 1) return ELD_EINVAL;
+    RC(unet_entry_checks(P, dout, params, grads, ws, ws_bytes, N, H, W, in_ch, out_ch));
+    if (n_buckets < 0 || (n_buckets > 0 && (!bucket_start || !bucket_event))) return ELD_EINVAL;
     for (int k = 0; k < n_buckets; ++k)
         if (!bucket_event[k] || bucket_start[k] < 0 || (k > 0 && bucket_start[k] <= bucket_start[k - 1]) || (size_t)bucket_start[k] >= P.nparams) return ELD_EINVAL;
-    if (ws_bytes < P.total * sizeof(float)) return ELD_EWS;
     BucketMarks marks;
     marks.start = bucket_start; marks.event = bucket_event; marks.n = n_buckets;
+    AlgoScope scope(fp32_algo);
     const int rc = precision == 1 ? unet_backward_bf16(P, dout, params, grads, (float*)ws, as_stream(stream), marks)
                                   : unet_backward(P, dout, params, grads, (float*)ws, as_stream(stream), marks);
     if (rc) return rc;
     return marks.next == n_buckets ? 0 : ELD_EINVAL;
+}
+
+// the round-1 entry points: the fp32 product scheme is the process default (eld_conv_fp32_algo) at the time of EACH call
+extern "C" int eld_unet_forward(const float* x, const float* params, float* out, void* ws, size_t ws_bytes, int N, int H, int W,
+                                int in_ch, int out_ch, void* stream) {
+    return eld_unet_forward_ex(x, params, out, ws, ws_bytes, N, H, W, in_ch, out_ch, 0, -1, stream);
+}
+extern "C" int eld_unet_forward_bf16(const float* x, const float* params, float* out, void* ws, size_t ws_bytes, int N, int H, int W,
+                                     int in_ch, int out_ch, void* stream) {
+    return eld_unet_forward_ex(x, params, out, ws, ws_bytes, N, H, W, in_ch, out_ch, 1, -1, stream);
+}
+extern "C" int eld_unet_backward(const float* dout, const float* params, float* grads, void* ws, size_t ws_bytes, int N, int H, int W,
+                                 int in_ch, int out_ch, void* stream) {
+    return eld_unet_backward_ex(dout, params, grads, ws, ws_bytes, N, H, W, in_ch, out_ch, 0, -1, nullptr, nullptr, 0, stream);
+}
+extern "C" int eld_unet_backward_bf16(const float* dout, const float* params, float* grads, void* ws, size_t ws_bytes, int N, int H, int W,
+                                      int in_ch, int out_ch, void* stream) {
+    return eld_unet_backward_ex(dout, params, grads, ws, ws_bytes, N, H, W, in_ch, out_ch, 1, -1, nullptr, nullptr, 0, stream);
+}
+extern "C" int eld_unet_backward_buckets(const float* dout, const float* params, float* grads, void* ws, size_t ws_bytes, int N, int H, int W,
+                                         int in_ch, int out_ch, int precision, const int64_t* bucket_start, void* const* bucket_event,
+                                         int n_buckets, void* stream) {
+    return eld_unet_backward_ex(dout, params, grads, ws, ws_bytes, N, H, W, in_ch, out_ch, precision, -1, bucket_start, bucket_event, n_buckets, stream);
 }
 
 extern "C" void eld_debug_conv_prof(void* buf) { conv_x3_set_prof((unsigned long long*)buf); }
@@ -632,7 +632,7 @@ extern "C" size_t eld_layer_workspace_bytes(int N, int H, int W, int Cin, int Co
 // operand bounds of a single-layer call under conv_fp32_algo 2: slots 0..2 = inputs (a, b, c), 3..4 = outputs
 static int layer_amax(void* ws, size_t ws_bytes, hipStream_t st, const float* a, size_t na, const float* b, size_t nb, const float* c, size_t nc, float** slots) {
     *slots = nullptr;
-    if (conv_fp32_algo(-1) != 2) return 0;
+    if (g_algo != 2) return 0;
     float* am = (float*)ws + ws_bytes / sizeof(float) - 64;
     if (hipMemsetAsync(am, 0, 64 * sizeof(float), st) != hipSuccess) return (int)hipGetLastError();
     if (a) RC(launch_absmax(a, na, am + 0, st));
@@ -655,6 +655,7 @@ static int layer_ws(void* ws, size_t ws_bytes, int N, int H, int W, int Cin, int
 extern "C" int eld_conv3x3_forward(const float* in0, int C0, const float* in1, int C1, const float* w, const float* bias, float* out, int N,
                                    int H, int W, int Cout, int lrelu, void* ws, size_t ws_bytes, void* stream) {
     if (N == 0) return 0;
+    AlgoScope scope(-1);
     if (!in0 || !w || !bias || !out || (C0 + C1) % 16 || C0 % 16 || Cout % 32) return ELD_EINVAL;
     float *pack, *part;
     RC(layer_ws(ws, ws_bytes, N, H, W, C0 + C1, Cout, &pack, &part));
@@ -669,6 +670,7 @@ extern "C" int eld_conv3x3_forward(const float* in0, int C0, const float* in1, i
 extern "C" int eld_conv3x3_backward_data(const float* g, const float* w, float* din0, float* din1, int split, const float* act0, const float* act1,
                                          int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
     if (N == 0) return 0;
+    AlgoScope scope(-1);
     if (!g || !w || !din0 || Cin % 32 || Cout % 16 || split % 32 || split > Cin || (split < Cin && !din1)) return ELD_EINVAL;
     float *pack, *part;
     RC(layer_ws(ws, ws_bytes, N, H, W, Cin, Cout, &pack, &part));
@@ -683,6 +685,7 @@ extern "C" int eld_conv3x3_backward_data(const float* g, const float* w, float* 
 extern "C" int eld_conv3x3_backward_weight(const float* g, const float* x0, int C0, const float* x1, int C1, float* dw, float* db, int N, int H,
                                            int W, int Cout, void* ws, size_t ws_bytes, void* stream) {
     if (N == 0) return 0;
+    AlgoScope scope(-1);
     if (!g || !x0 || !dw || Cout % 32 || C0 % 4 || C1 % 4) return ELD_EINVAL;
     float *pack, *part;
     RC(layer_ws(ws, ws_bytes, N, H, W, C0 + C1, Cout, &pack, &part));
@@ -695,6 +698,7 @@ extern "C" int eld_conv3x3_backward_weight(const float* g, const float* x0, int 
 extern "C" int eld_convt2x2_forward(const float* in, const float* w, const float* bias, float* out, int N, int H, int W, int Cin, int Cout,
                                     void* ws, size_t ws_bytes, void* stream) {
     if (N == 0) return 0;
+    AlgoScope scope(-1);
     if (!in || !w || !bias || !out || Cin % 16 || Cout % 8) return ELD_EINVAL;
     float *pack, *part;
     RC(layer_ws(ws, ws_bytes, N, H, W, Cin, Cout, &pack, &part));
@@ -709,6 +713,7 @@ extern "C" int eld_convt2x2_forward(const float* in, const float* w, const float
 extern "C" int eld_convt2x2_backward_data(const float* dout, const float* w, const float* act, float* din, int N, int H, int W, int Cin, int Cout,
                                           void* ws, size_t ws_bytes, void* stream) {
     if (N == 0) return 0;
+    AlgoScope scope(-1);
     if (!dout || !w || !din || Cin % 32 || Cout % 16) return ELD_EINVAL;
     float *pack, *part;
     RC(layer_ws(ws, ws_bytes, N, H, W, Cin, Cout, &pack, &part));
@@ -723,6 +728,7 @@ extern "C" int eld_convt2x2_backward_data(const float* dout, const float* w, con
 extern "C" int eld_convt2x2_backward_weight(const float* in, const float* dout, float* dw, float* db, int N, int H, int W, int Cin, int Cout,
                                             void* ws, size_t ws_bytes, void* stream) {
     if (N == 0) return 0;
+    AlgoScope scope(-1);
     if (!in || !dout || !dw || Cin % 32 || Cout % 4) return ELD_EINVAL;
     float *pack, *part;
     RC(layer_ws(ws, ws_bytes, N, H, W, Cin, Cout, &pack, &part));

@@ -1,0 +1,157 @@
+"""Dataset-side plugins: drop-ins for the three dataset classes on the training path of train_syn.py, re-cut so that the
+per-pixel work happens on the MI355X and the DataLoader workers (train_syn.py:78-80, default --nThreads 8, forked) do what
+they are good at -- I/O and a handful of NumPy scalar draws:
+
+    LMDBDataset       dataset/lmdb_dataset.py:7-47    returns the stored uint16 codes UNDECODED (2 B/pixel over PCIe instead
+                                                      of 4; the decode clip(u16/65535) is fused into the HIP sampler / augment)
+    SynDataset        dataset/sid_dataset.py:248-284  draws the per-sample noise parameters exactly where the reference does
+                                                      (noise_maker._sample_params(), same NumPy draws in the same order, once per
+                                                      burst) and DEFERS the per-pixel synthesis: returns a `Deferred` sample
+    ELDTrainDataset   dataset/sid_dataset.py:322-367  pairs input and target (i % N, i // N), draws the three augmentation bits
+                                                      exactly as the reference does (np.random.randint(2, size=1)[0], three
+                                                      times) and returns them instead of flipping host arrays
+
+What reaches the model plugin (eld_amd.model.ELDModel.set_input) after torch's default collate is
+    {'target': int16 view of the uint16 codes (B,C,H,W) | float32, 'params': uint8 (B,64) EldNoiseParams records,
+     'aug': int64 (B,), 'burst': int64 (B,)}
+and the model runs decode -> sampler (+clip, burst concat) -> augmentation of input and target on the device.
+Samples whose input dataset is an ordinary array dataset (offline-noise LMDBs, train_syn.py:66-70) take the reference's host
+path below unchanged (index maps and a clip -- the same arithmetic as sid_dataset.py:344-356).
+"""
+import pickle
+from os.path import join
+
+import numpy as np
+import torch.utils.data as tdata
+
+from . import _lib as L
+from .noise import NoiseParams
+
+
+class LMDBDataset(tdata.Dataset):
+    """dataset/lmdb_dataset.py:7-47 with `decode=False` by default: uint16 records stay uint16 (tagged by dtype), everything
+    else (float32 sRGB databases) is returned as stored, like the reference."""
+
+    def __init__(self, db_path, size=None, repeat=1, decode=False):
+        import lmdb
+        self.db_path = db_path
+        self.env = lmdb.open(db_path, max_readers=1, readonly=True, lock=False, readahead=False, meminit=False)
+        with self.env.begin(write=False) as txn:
+            length = txn.stat()['entries']
+        self.length = size or length
+        self.repeat = repeat
+        with open(join(db_path, 'meta_info.pkl'), 'rb') as f:
+            self.meta = pickle.load(f)
+        self.shape = self.meta['shape']
+        self.dtype = self.meta['dtype']
+        self.decode = decode
+
+    def __getitem__(self, index):
+        index = index % self.length
+        with self.env.begin(write=False) as txn:
+            raw_data = txn.get('{:08}'.format(index).encode('ascii'))
+        x = np.frombuffer(raw_data, self.dtype).reshape(*self.shape)
+        if self.dtype == np.uint16 and self.decode:          # the reference's host decode (lmdb_dataset.py:38-39)
+            x = np.clip(x / 65535, 0, 1).astype(np.float32)
+        return x
+
+    def __len__(self):
+        return int(self.length * self.repeat)
+
+    def __repr__(self):
+        return self.__class__.__name__ + ' (' + self.db_path + ')'
+
+
+class Deferred(object):
+    """A noisy sample whose pixels do not exist yet: the clean data, the parameter record of its noise and the burst count."""
+    __slots__ = ('clean', 'params', 'burst')
+
+    def __init__(self, clean, params, burst):
+        self.clean, self.params, self.burst = clean, params, burst
+
+
+class SynDataset(tdata.Dataset):
+    """dataset/sid_dataset.py:248-284.  Same constructor.  The RNG draws the reference makes per sample before touching pixels
+    -- `_sample_params()` once per call, or once per BURST when num_burst > 1 (:267-272) -- happen here, in the worker, from the
+    worker's own NumPy stream (worker_init_fn, :17-18); the pixels are synthesised later, batched, on the device."""
+
+    def __init__(self, dataset, size=None, flag=None, noise_maker=None, repeat=1, cfa='bayer', num_burst=1):
+        super(SynDataset, self).__init__()
+        self.size = size
+        self.dataset = dataset
+        self.flag = flag
+        self.repeat = repeat
+        self.noise_maker = noise_maker
+        self.cfa = cfa
+        self.num_burst = num_burst
+
+    def __getitem__(self, i):
+        i = i % self.size if self.size is not None else i % len(self.dataset)
+        data = self.dataset[i]
+        params = NoiseParams.coerce(self.noise_maker._sample_params())
+        return Deferred(data, params, max(1, int(self.num_burst)))
+
+    def __len__(self):
+        size = self.size or len(self.dataset)
+        return int(size * self.repeat)
+
+
+def _as_wire(x):
+    """uint16 codes travel as an int16 view (torch's default collate stacks int16; uint16 support is partial)."""
+    x = np.ascontiguousarray(x)
+    return x.view(np.int16) if x.dtype == np.uint16 else x
+
+
+class ELDTrainDataset(tdata.Dataset):
+    """dataset/sid_dataset.py:322-367.  Same constructor, same pairing (i % N, i // N), same three augmentation draws."""
+
+    def __init__(self, target_dataset, input_datasets, size=None, flag=None, augment=True, cfa='bayer'):
+        super(ELDTrainDataset, self).__init__()
+        self.size = size
+        self.target_dataset = target_dataset
+        self.input_datasets = input_datasets
+        self.flag = flag
+        self.augment = augment
+        self.cfa = cfa
+
+    def __getitem__(self, i):
+        N = len(self.input_datasets)
+        inp = self.input_datasets[i % N][i // N]
+        target = self.target_dataset[i // N]
+        bits = 0
+        if self.augment:                                     # sid_dataset.py:344-352: flip H, flip W, transpose
+            for b in (1, 2, 4):
+                if np.random.randint(2, size=1)[0] == 1:
+                    bits |= b
+        if isinstance(inp, Deferred):
+            dic = {'target': _as_wire(target), 'params': inp.params.record(0).reshape(1).view(np.uint8).copy(),
+                   'aug': bits, 'burst': inp.burst}
+        else:                                                # pre-synthesised input (offline-noise LMDB): the reference's host path
+            if getattr(inp, 'dtype', None) == np.uint16:
+                inp = np.clip(inp / 65535, 0, 1).astype(np.float32)
+            if getattr(target, 'dtype', None) == np.uint16:
+                target = np.clip(target / 65535, 0, 1).astype(np.float32)
+            if bits & 1:
+                target, inp = np.flip(target, axis=1), np.flip(inp, axis=1)
+            if bits & 2:
+                target, inp = np.flip(target, axis=2), np.flip(inp, axis=2)
+            if bits & 4:
+                target, inp = np.transpose(target, (0, 2, 1)), np.transpose(inp, (0, 2, 1))
+            inp = np.maximum(np.minimum(inp, 1.0), 0)
+            dic = {'input': np.ascontiguousarray(inp), 'target': np.ascontiguousarray(target)}
+        if self.flag is not None:
+            dic.update(self.flag)
+        return dic
+
+    def __len__(self):
+        return self.size or len(self.target_dataset) * len(self.input_datasets)
+
+
+def worker_init_fn(worker_id):                               # dataset/sid_dataset.py:17-18
+    np.random.seed(np.random.get_state()[1][0] + worker_id)
+
+
+def records_from_batch(params_u8):
+    """(B,64) uint8 tensor/array of a collated batch -> structured NumPy records (a copy the caller may edit)."""
+    a = np.ascontiguousarray(np.asarray(params_u8, dtype=np.uint8)).reshape(-1, 64)
+    return a.view(L.NOISE_PARAMS_DTYPE).reshape(-1).copy()

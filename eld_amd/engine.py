@@ -73,6 +73,13 @@ class Engine(object):
             self.model.save(label='best_{}_{}'.format(loss_key, dataset_name))
         return avg_meters
 
+    def test(self, test_loader, savedir=None, **kwargs):                                   # engine.py:101-107
+        outs = []
+        with torch.no_grad():
+            for data in test_loader:
+                outs.append(self.model.test(data, savedir=savedir, **kwargs))
+        return outs
+
     def set_learning_rate(self, lr):                 # engine.py:109-112
         for optimizer in self.model.optimizers:
             if D.rank() == 0:

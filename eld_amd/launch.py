@@ -8,10 +8,19 @@ What it does (nothing in the reference tree is edited or written to):
      rawpy / exifread / tensorboardX / torchinterp1d / skimage / skvideo / cv2 / colour that are only touched when real
      SID data is opened, `torch._utils._accumulate`, a TTY-less `stty size`, and -- when no LMDB is present -- an
      in-memory synthetic stand-in for the `lmdb` module so `LMDBDataset` (dataset/lmdb_dataset.py) works;
-  2. installs the plugins at the reference's three registries:
+  2. installs the plugins at the reference's registries:
        noise : sys.modules['noise']            = eld_amd.noise        (resolved by `import noise`, train_syn.py:10)
        arch  : models.arch.__dict__['unet']    = eld_amd.unet.unet     (looked up at models/ELD_model.py:391)
-       model : models.__dict__['eld_model']    = eld_amd.model.eld_model  (engine.py:26; the fully fused step)
+       model : models.__dict__['eld_model']    = eld_amd.model.eld_model  (engine.py:26; the fully fused step).  The model
+               attaches the NoiseModel instance the script built (train_syn.py:38) by itself.
+       data  : dataset.lmdb_dataset.LMDBDataset, dataset.sid_dataset.{SynDataset, ELDTrainDataset, worker_init_fn}
+               = eld_amd.data's deferred-synthesis classes (needs `model`): DataLoader workers (default --nThreads 8) draw the
+               per-sample parameters and augmentation bits, the pixels are synthesised on the device in set_input.
+               The shipped train_syn.py reads OFFLINE pre-synthesised noise (train_syn.py:66-70; the on-the-fly SynDataset
+               lines 61-64 are commented out, although scripts/train.sh:2-4 says the released models were trained on-the-fly):
+               with --online-noise (default when the offline database directory does not exist) opening
+               `SID_Sony_syn_Raw_<camera>.db` yields SynDataset(LMDBDataset(SID_Sony_Raw.db), noise_maker=<that NoiseModel>),
+               i.e. exactly the commented lines, without editing the script.
   3. runs `<ref>/train_syn.py` with runpy from a scratch CWD that symlinks the data tables the script opens relatively.
 With `--plugins none` the reference runs on its own code (used by the CPU test of the harness itself).
 """
@@ -86,10 +95,36 @@ def install_shims(synthetic_lmdb=True, patches=16, patch_hw=(512, 512)):
             mod('lmdb', open=_open)
 
 
-def install_plugins(which):
+def install_plugins(which, online_noise=None, num_burst=1):
+    if 'data' in which and 'model' not in which:
+        raise SystemExit("--plugins data needs model: deferred samples are synthesised by eld_amd.model.ELDModel.set_input")
     if 'noise' in which:
         import eld_amd.noise as plug
         sys.modules['noise'] = plug
+    if 'data' in which:
+        import dataset.lmdb_dataset as ref_lmdb               # the reference modules (on sys.path); train_syn.py resolves the
+        import dataset.sid_dataset as ref_sid                 # classes through these module objects at call time
+        import eld_amd.data as D
+        import eld_amd.noise as N
+
+        class _LMDBDataset(D.LMDBDataset):
+            """Redirects the offline-noise database of train_syn.py:66-70 to on-the-fly synthesis (train_syn.py:61-64)."""
+            def __new__(cls, db_path, size=None, repeat=1, **kw):
+                base = os.path.basename(os.path.normpath(db_path))
+                offline = base.startswith('SID_Sony_syn_Raw_') and base.endswith('.db')
+                want = online_noise if online_noise is not None else not os.path.exists(os.path.join(db_path, 'meta_info.pkl'))
+                if offline and want:
+                    nm = N.NoiseModel.last_instance
+                    if nm is None:
+                        raise RuntimeError('--online-noise: no NoiseModel has been constructed yet (needs the noise plugin)')
+                    clean = D.LMDBDataset(os.path.join(os.path.dirname(os.path.normpath(db_path)), 'SID_Sony_Raw.db'), size=size, repeat=repeat)
+                    print('[i] eld_amd: %s -> on-device synthesis from SID_Sony_Raw.db with noise model %r' % (base, nm.model))
+                    return D.SynDataset(clean, noise_maker=nm, num_burst=num_burst, size=size, repeat=repeat)
+                return super().__new__(cls)
+        ref_lmdb.LMDBDataset = _LMDBDataset
+        ref_sid.SynDataset = D.SynDataset
+        ref_sid.ELDTrainDataset = D.ELDTrainDataset
+        ref_sid.worker_init_fn = D.worker_init_fn
     if 'arch' in which or 'model' in which:
         import models                                        # the reference package (on sys.path)
         if 'arch' in which:
@@ -117,9 +152,14 @@ def prepare_cwd(ref, cwd):
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--ref', required=True, help='path of the (unmodified) reference checkout')
-    ap.add_argument('--plugins', default='noise,arch', help='comma list of noise,arch,model or "none"')
+    ap.add_argument('--plugins', default='noise,arch', help='comma list of noise,arch,model,data or "none"')
+    ap.add_argument('--online-noise', dest='online_noise', action='store_true', default=None, help='data plugin: synthesise the input on the fly even if an offline-noise LMDB exists')
+    ap.add_argument('--offline-noise', dest='online_noise', action='store_false', help='data plugin: read the offline-noise LMDB (train_syn.py as shipped)')
+    ap.add_argument('--num-burst', type=int, default=1, help='data plugin: burst frames per sample (sid_dataset.py:267-273)')
     ap.add_argument('--script', default='train_syn.py')
     ap.add_argument('--cwd', default=None, help='scratch working directory (default: $TMPDIR/eld_amd_run)')
+    ap.add_argument('--stop-after-epochs', type=int, default=0, help='harness: leave the script cleanly after this many Engine.train calls (train_syn.py:100 loops to epoch 200)')
+    ap.add_argument('--max-iters-per-epoch', type=int, default=0, help='harness: truncate every epoch to this many batches (an epoch of train_syn.py is always 1288 samples)')
     ap.add_argument('rest', nargs=argparse.REMAINDER)
     args = ap.parse_args(argv)
     ref = os.path.abspath(args.ref)
@@ -129,7 +169,31 @@ def main(argv=None):
     sys.path.insert(0, ref)
     install_shims()
     which = [] if args.plugins == 'none' else [p.strip() for p in args.plugins.split(',') if p.strip()]
-    install_plugins(which)
+    install_plugins(which, online_noise=args.online_noise, num_burst=args.num_burst)
+    if args.stop_after_epochs > 0 or args.max_iters_per_epoch > 0:
+        import engine as ref_engine                        # the reference's engine.py: train_syn.py does `from engine import Engine`
+        _train, left = ref_engine.Engine.train, [args.stop_after_epochs]
+
+        class _Head(object):                                # the first K batches of a loader
+            def __init__(self, loader, k):
+                self.loader, self.k = loader, k
+
+            def __len__(self):
+                return min(self.k, len(self.loader))
+
+            def __iter__(self):
+                return itertools.islice(iter(self.loader), self.k)
+
+        def train(self, loader, *a, **k):
+            if args.max_iters_per_epoch > 0:
+                loader = _Head(loader, args.max_iters_per_epoch)
+            r = _train(self, loader, *a, **k)
+            left[0] -= 1
+            if args.stop_after_epochs > 0 and left[0] <= 0:
+                print('[i] eld_amd.launch: stopping after %d epoch(s)' % args.stop_after_epochs)
+                raise SystemExit(0)
+            return r
+        ref_engine.Engine.train = train
     rest = args.rest[1:] if args.rest and args.rest[0] == '--' else args.rest
     sys.argv = [os.path.join(ref, args.script)] + rest
     runpy.run_path(sys.argv[0], run_name='__main__')

@@ -1,43 +1,19 @@
 """Evaluation metrics on device: what the reference's eval path computes with scikit-image on the host
 (util/index.py:76-81 `quality_assess`: PSNR and multichannel SSIM with data_range=255 on the x255-clipped float
-images of `tensor2im`, models/ELD_model.py:23-38).  `quality_assess_frames` / `illuminance_correct` run the HIP kernels of
-csrc/eval.hip (one pass over the frames, double accumulation, no host round trip); `psnr` / `ssim` below are the same
-formulas in torch ops for tensors that are not on the GPU.
+images of `tensor2im`, models/ELD_model.py:23-38).  Everything here runs the HIP kernels of csrc/eval.hip (one pass over the
+frames, double accumulation, no host round trip); CPU tensors raise -- there is no second implementation in the product.
 scikit-image is absent from this stack, so SSIM restates skimage.metrics.structural_similarity's defaults
 (7x7 uniform window, K1=0.01, K2=0.03, sample covariance, border of 3 cropped, mean over channels) -- the oracle
 statement is oracle/metrics_ref.py (NumPy + scipy.ndimage)."""
 import torch
-import torch.nn.functional as F
-
-
-def psnr(x, y, data_range=255.0):
-    """x, y: (C,H,W) or (N,C,H,W) tensors already on the [0, data_range] scale.  10*log10(R^2 / MSE) over all elements."""
-    mse = torch.mean((x.double() - y.double()) ** 2)
-    return 10.0 * torch.log10(torch.as_tensor(float(data_range) ** 2, dtype=torch.float64, device=x.device) / mse)
-
-
-def ssim(x, y, data_range=255.0, win_size=7, K1=0.01, K2=0.03):
-    """Mean SSIM of a (C,H,W) image pair, channels treated independently then averaged (multichannel=True)."""
-    if x.dim() == 3:
-        x, y = x[None], y[None]
-    x, y = x.double(), y.double()
-    NP = win_size * win_size
-    cov_norm = NP / (NP - 1.0)                       # use_sample_covariance=True
-    def box(t):                                      # valid-region uniform filter == skimage's filter followed by crop(pad)
-        return F.avg_pool2d(t, win_size, stride=1)
-    ux, uy = box(x), box(y)
-    uxx, uyy, uxy = box(x * x), box(y * y), box(x * y)
-    vx = cov_norm * (uxx - ux * ux)
-    vy = cov_norm * (uyy - uy * uy)
-    vxy = cov_norm * (uxy - ux * uy)
-    C1, C2 = (K1 * data_range) ** 2, (K2 * data_range) ** 2
-    S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux * ux + uy * uy + C1) * (vx + vy + C2))
-    return S.mean()
 
 
 def quality_assess(X, Y, data_range=255.0):
-    """util/index.py:76-81 for one image (C,H,W on device): Y correct, X estimate."""
-    return {'PSNR': float(psnr(Y, X, data_range)), 'SSIM': float(ssim(Y, X, data_range))}
+    """util/index.py:76-81 for one image pair already on the [0, data_range] scale (what tensor2im returns): CUDA (C,H,W)."""
+    if not (X.is_cuda and Y.is_cuda):
+        raise RuntimeError('eld_amd.metrics runs on the GPU only (no CPU fallback)')
+    q = quality_assess_frames((X.float() / data_range)[None], (Y.float() / data_range)[None], data_range)[0].tolist()
+    return {'PSNR': q[0], 'SSIM': q[1]}
 
 
 def quality_assess_frames(est, ref, data_range=255.0):

@@ -22,7 +22,8 @@ import torch
 from . import _lib as L
 from . import dist as D
 from . import unet as arch_unet
-from .noise import NoiseModel, sample_noise, model_flags
+from .data import records_from_batch
+from .noise import (NoiseModel, augment, decode_augment_u16, make_records, model_flags, sample_noise_records, set_sample_ids)
 
 ARCH = {'unet': arch_unet.unet}          # the `arch.__dict__[opt.netG]` registry (ELD_model.py:391)
 
@@ -100,7 +101,8 @@ class ELDModel:
         if getattr(opt, 'stage_in', 'raw') != 'raw' or getattr(opt, 'stage_out', 'raw') != 'raw':
             raise NotImplementedError('sRGB stages are outside the MI355X hot path (raw->raw only)')
         ch = getattr(opt, 'channels', 4)
-        self.netG = ARCH[getattr(opt, 'netG', 'unet')](ch, ch).to(self.device)
+        cin = getattr(opt, 'in_channels', None) or ch        # burst input (sid_dataset.py:267-273): num_burst * channels planes in
+        self.netG = ARCH[getattr(opt, 'netG', 'unet')](cin, ch).to(self.device)
         prec = getattr(opt, 'precision', os.environ.get('ELD_AMD_PRECISION', 'fp32'))      # 'bf16' = BASELINE config 3
         self.netG.train_precision = self.netG.inference_precision = prec
         self.world, self.rank = D.world_size(), D.rank()
@@ -120,8 +122,10 @@ class ELDModel:
             self.schedulers = []
         self._l1_ws = torch.empty(L.lib().eld_l1_workspace_bytes(), dtype=torch.uint8, device=self.device)
         self._loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
-        self.noise_model = None
+        self.noise_model = NoiseModel.last_instance      # the plugin instance the entry script built (train_syn.py:38); may be None
         self._sample_counter = 0
+        # Philox key: the run's --seed (base_option.py:22) unless overridden; per-image counters are global sample indices
+        self.seed = int(os.environ.get('ELD_AMD_SEED', getattr(opt, 'seed', None) if getattr(opt, 'seed', None) is not None else 2018))
         if getattr(opt, 'resume', False):
             self.load(self, getattr(opt, 'resume_epoch', None))
 
@@ -131,6 +135,11 @@ class ELDModel:
 
     # ---- ELD_model.py:173-200 -----------------------------------------------------------------------------
     def set_input(self, data, mode='train'):
+        """Same contract as the reference (picks 'input'/'target' by mode, moves them to the device).  Additionally, a TRAIN batch
+        without 'input' is a batch of DEFERRED samples (eld_amd.data: clean 'target' codes + 'params' records + 'aug' bits +
+        'burst'): what SynDataset / ELDTrainDataset.__getitem__ do per sample on the CPU (sid_dataset.py:259-280, 332-363) then
+        happens here, batched, on the device: decode -> sampler + clip (burst frames concatenated on the channel axis) ->
+        flips / transpose of input AND target -> clip."""
         mode = mode.lower()
         if mode not in ('train', 'eval', 'test'):
             raise NotImplementedError('Mode [%s] is not implemented' % mode)
@@ -140,33 +149,60 @@ class ELDModel:
             target = target.to(device=self.device, non_blocking=True)
         if inp is not None:
             inp = inp.to(device=self.device, non_blocking=True)
+            if target is not None and target.element_size() == 2:
+                target = decode_augment_u16(target)
         elif mode == 'train':
-            inp = self.synthesize(target, data.get('params'), data.get('sample_ids'))
+            if target is None:
+                raise KeyError('target')
+            inp = self.synthesize(target, data.get('params'), data.get('sample_ids'), burst=_burst_of(data))
         else:
             raise KeyError('input')
-        if data.get('aug') is not None and mode == 'train':
+        aug = data.get('aug')
+        if aug is not None and mode == 'train':
             # ELDTrainDataset augmentation (sid_dataset.py:344-354) AFTER synthesis, as the reference does, so that
             # row banding follows the sensor rows of the un-augmented frame: same flips/transpose on input and target.
-            from .noise import augment
-            inp = augment(inp, data['aug'], clip=True)
-            target = augment(target, data['aug'], clip=False)
+            bits = [int(b) for b in (aug.tolist() if hasattr(aug, 'tolist') else aug)]
+            inp = augment(inp, bits, clip=True)
+            target = decode_augment_u16(target, bits) if target.element_size() == 2 else augment(target, bits, clip=False)
+        elif target is not None and target.element_size() == 2:
+            target = decode_augment_u16(target)
         self.input, self.target = inp, target
         self.data_name = data.get('fn')
+        self.rawpath = data.get('rawpath')
 
-    def synthesize(self, clean, params=None, sample_ids=None):
-        """noisy = clip(noise_model(clean)) on device, one Philox sample id per image (global index:
-        rank-strided so that a given global batch gets the same noise for every world size)."""
+    def synthesize(self, clean, params=None, sample_ids=None, burst=1):
+        """noisy = clip(noise_model(clean)) on device, one Philox sample id per synthesised frame (global index: rank-strided so
+        that a given global batch gets the same noise for every world size).  clean: CUDA float32 (N,C,H,W) or the LMDB uint16
+        codes (int16 view) -- decoded inside the sampler.  params: None (drawn here with _sample_params, once per image as
+        sid_dataset.py:269 does for a burst), a list of N tuples, or the (N,64) record bytes of a collated deferred batch.
+        burst > 1: `burst` frames per image share the image's parameters and are concatenated on the channel axis
+        (sid_dataset.py:267-273)."""
         nm = self.noise_model
         if nm is None:
             raise RuntimeError('no noise model attached (set_noise_model) and the batch has no "input"')
         N = clean.shape[0]
         if params is None:
-            params = [nm._sample_params() for _ in range(N)]
+            recs = make_records([nm._sample_params() for _ in range(N)], [0] * N)
+        elif hasattr(params, 'dtype') and not isinstance(params, (list, tuple)):
+            recs = records_from_batch(params.cpu().numpy() if hasattr(params, 'cpu') else params)
+        else:
+            recs = make_records(list(params), [0] * N)
+        burst = max(1, int(burst))
         if sample_ids is None:
             base = self._sample_counter * self.world
-            sample_ids = [base + self.rank + self.world * i for i in range(N)]
-            self._sample_counter += N
-        return sample_noise(clean.contiguous().float(), params, model_flags(nm.model) | L.CLIP, nm.seed, sample_ids)
+            sample_ids = [base + self.rank + self.world * i for i in range(N * burst)]
+            self._sample_counter += N * burst
+        sample_ids = [int(v) for v in sample_ids]
+        if len(sample_ids) != N * burst:
+            raise ValueError('need %d sample ids (N x burst), got %d' % (N * burst, len(sample_ids)))
+        in_u16 = clean.element_size() == 2
+        clean = clean.contiguous() if in_u16 else clean.contiguous().float()
+        flags = model_flags(nm.model) | L.CLIP
+        out = None
+        for k in range(burst):                   # frame k of image i carries id sample_ids[i*burst + k]
+            out = sample_noise_records(clean, set_sample_ids(recs, sample_ids[k::burst]), flags, self.seed, in_u16=in_u16, out=out,
+                                       burst_index=k, burst=burst)
+        return out
 
     # ---- ELD_model.py:422-432 -------------------------------------------------------------------------------
     def forward(self):
@@ -202,8 +238,11 @@ class ELDModel:
         out, key, _ = net._engine_forward(x, save=True, bf16=net.train_precision == 'bf16')      # forward()
         self.output = out
         dout = torch.empty_like(out)
+        tgt = self.target.contiguous().float()            # a float64 / half target (custom datasets) must not reach the float4 loads
+        if tgt.shape != out.shape:
+            raise RuntimeError('target shape %s does not match the network output %s' % (tuple(tgt.shape), tuple(out.shape)))
         loss_fn = L.lib().eld_mse_loss if self.loss_name == 'l2' else L.lib().eld_l1_loss
-        L.check(loss_fn(L.dptr(out), L.dptr(self.target.contiguous()), L.dptr(dout), L.dptr(self._loss_buf), L.dptr(self._l1_ws),
+        L.check(loss_fn(L.dptr(out), L.dptr(tgt), L.dptr(dout), L.dptr(self._loss_buf), L.dptr(self._l1_ws),
                         out.numel(), 1.0, L.cur_stream()), 'eld_%s_loss' % self.loss_name)      # backward_G(): loss + its gradient
         if self.world > 1 and opt.grads.is_cuda:                              # data-parallel exchange (new):
             if self._buckets is None:                                         # buckets all-reduced under the rest of the backward
@@ -245,9 +284,33 @@ class ELDModel:
         psnr, ssim = q[0].tolist()                               # + util/index.py:76-81, fused on the device
         return {'PSNR': psnr, 'SSIM': ssim}
 
+    @torch.no_grad()
+    def test(self, data, savedir=None, video_mode=False):
+        """ELD_model.py:309-350: forward on data['input'] (no target), returns the output tensor.  The reference then renders
+        JPEGs through the author's customised rawpy (postprocess_bayer, ELD_model.py:41-60) when the sample carries a raw path;
+        that renderer is outside the hot path: with `savedir` the raw network output is stored as
+        <savedir>/<name>/<opt.name>.npy instead (same skip-if-present rule, ELD_model.py:321-324)."""
+        self.set_input(data, 'test')
+        name = None
+        if self.data_name is not None and savedir is not None:
+            fn = self.data_name[0] if isinstance(self.data_name, (list, tuple)) else self.data_name
+            name = os.path.splitext(os.path.basename(fn))[0]
+            d = os.path.join(savedir, self.opt.name) if video_mode else os.path.join(savedir, name)
+            os.makedirs(d, exist_ok=True)
+            path = os.path.join(d, ('%s.npy' % name) if video_mode else ('%s.npy' % self.opt.name))
+            if not video_mode and os.path.exists(path):
+                return None
+        output = self.forward()
+        if name is not None:
+            np.save(path, output[0].cpu().numpy())
+        return output
+
     # ---- checkpoints (base_model.py:55-66, ELD_model.py:492-523) -----------------------------------------------
     def state_dict(self):
-        return {'netG': self.netG.state_dict(), 'opt_g': self.optimizer_G.state_dict(), 'epoch': self.epoch, 'iterations': self.iterations}
+        # the reference's four keys (ELD_model.py:516-523) + the sampler's position, so that --resume continues the noise stream
+        # instead of replaying sample ids from 0 (the reference loads with plain dict indexing: an extra key is harmless there)
+        return {'netG': self.netG.state_dict(), 'opt_g': self.optimizer_G.state_dict(), 'epoch': self.epoch, 'iterations': self.iterations,
+                'eld_amd': {'sample_counter': self._sample_counter, 'seed': self.seed}}
 
     def save(self, label=None):
         if self.rank != 0:
@@ -265,10 +328,24 @@ class ELDModel:
         sd = torch.load(path, map_location='cpu')
         model.netG.load_state_dict(sd['netG'])
         model.epoch, model.iterations = sd['epoch'], sd['iterations']
+        extra = sd.get('eld_amd') or {}
+        model._sample_counter = int(extra.get('sample_counter', 0))
+        if 'seed' in extra and 'ELD_AMD_SEED' not in os.environ:
+            model.seed = int(extra['seed'])
         if model.isTrain:
             model.optimizer_G.load_state_dict(sd['opt_g'])
         print('Resume from epoch %d, iteration %d' % (model.epoch, model.iterations))
         return sd
+
+
+def _burst_of(data):
+    b = data.get('burst')
+    if b is None:
+        return 1
+    vals = set(int(v) for v in (b.tolist() if hasattr(b, 'tolist') else ([b] if isinstance(b, int) else b)))
+    if len(vals) != 1:
+        raise ValueError('mixed burst counts in one batch: %r' % (sorted(vals),))
+    return vals.pop()
 
 
 def illuminance_correct(predict, source):

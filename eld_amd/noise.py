@@ -101,21 +101,98 @@ def load_camera_params(camera, param_dir=None):
     return out
 
 
-def sample_noise(y, params, flags, seed, sample_ids, in_u16=False, inject=None, dump=None, out=None):
-    """Device-side batched sampler call.  y: CUDA tensor (N,C,H,W) float32 (or uint16 codes viewed as
-    int16 when in_u16); params: list of N NoiseParams; returns CUDA float32 tensor (N,C,H,W)."""
+_PINNED = {}
+
+
+def _upload(arr, device):
+    """Small host array -> device through a PINNED staging ring, asynchronously on the current stream (a pageable H2D copy is
+    a blocking call in front of every step).  A slot is reused only after the copy issued from it has completed."""
+    import torch
+    raw = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
+    n = raw.size
+    ring = _PINNED.setdefault(device, {'slots': [], 'next': 0})
+    if not ring['slots']:
+        ring['slots'] = [[torch.empty(4096, dtype=torch.uint8).pin_memory(), None] for _ in range(8)]
+    slot = ring['slots'][ring['next'] % len(ring['slots'])]
+    ring['next'] += 1
+    if slot[0].numel() < n:
+        slot[0] = torch.empty(max(n, 2 * slot[0].numel()), dtype=torch.uint8).pin_memory()
+    if slot[1] is not None:
+        slot[1].synchronize()           # the copy that last used this slot (8 uploads ago) has long finished
+    slot[0][:n].copy_(torch.from_numpy(raw))
+    dev = slot[0][:n].to(device, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    slot[1] = ev
+    return dev                          # uint8 view of the bytes; callers pass its device pointer through the C ABI
+
+
+def make_records(params, sample_ids):
+    """list of parameter tuples + global sample ids -> structured EldNoiseParams records."""
+    if len(params) == 0:
+        return np.zeros((0,), L.NOISE_PARAMS_DTYPE)
+    return np.stack([NoiseParams.coerce(p).record(int(s)) for p, s in zip(params, sample_ids)])
+
+
+def set_sample_ids(recs, sample_ids):
+    ids = np.asarray(sample_ids, dtype=np.uint64)
+    recs['sample_id_lo'] = (ids & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    recs['sample_id_hi'] = (ids >> np.uint64(32)).astype(np.uint32)
+    return recs
+
+
+def sample_noise_records(y, recs, flags, seed, in_u16=False, inject=None, dump=None, out=None, burst_index=0, burst=1):
+    """The C-ABI sampler call.  y: CUDA (N,C,H,W) float32, or int16/uint16 LMDB codes when in_u16; recs: N structured records
+    (host); out: CUDA float32 (N, burst*C, H, W) -- this call fills channels [burst_index*C, (burst_index+1)*C) of every image
+    (burst == 1: the whole tensor)."""
     import torch
     assert y.is_cuda and y.is_contiguous() and y.dim() == 4
     N, C, H, W = y.shape
-    recs = np.stack([NoiseParams.coerce(p).record(int(s)) for p, s in zip(params, sample_ids)]) if N else \
-        np.zeros((0,), L.NOISE_PARAMS_DTYPE)
-    prm = torch.from_numpy(recs.view(np.uint8).reshape(-1).copy()).to(y.device, non_blocking=True)
+    assert len(recs) == N
+    if in_u16:
+        assert y.element_size() == 2
+    else:
+        assert y.dtype == torch.float32
+    prm = _upload(np.ascontiguousarray(recs).view(np.uint8).reshape(-1), y.device)
     if out is None:
-        out = torch.empty((N, C, H, W), dtype=torch.float32, device=y.device)
-    rc = L.lib().eld_noise_forward(L.dptr(y), L.IN_U16 if in_u16 else L.IN_F32, L.dptr(out), L.dptr(prm),
-                                   N, C, H, W, int(flags), int(seed) & (2 ** 64 - 1), L.dptr(inject), L.dptr(dump),
-                                   L.cur_stream())
-    L.check(rc, 'eld_noise_forward')
+        out = torch.empty((N, burst * C, H, W), dtype=torch.float32, device=y.device)
+    assert out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (N, burst * C, H, W)
+    chw = C * H * W
+    optr = None if out.numel() == 0 else C_void(out.data_ptr() + 4 * burst_index * chw)
+    rc = L.lib().eld_noise_forward_strided(L.dptr(y), L.IN_U16 if in_u16 else L.IN_F32, chw, optr, burst * chw, L.dptr(prm),
+                                           N, C, H, W, int(flags), int(seed) & (2 ** 64 - 1), L.dptr(inject), L.dptr(dump), L.cur_stream())
+    L.check(rc, 'eld_noise_forward_strided')
+    return out
+
+
+def C_void(addr):
+    import ctypes
+    return ctypes.c_void_p(addr)
+
+
+def sample_noise(y, params, flags, seed, sample_ids, in_u16=False, inject=None, dump=None, out=None):
+    """Device-side batched sampler call.  y: CUDA tensor (N,C,H,W) float32 (or uint16 codes viewed as
+    int16 when in_u16); params: list of N NoiseParams; returns CUDA float32 tensor (N,C,H,W)."""
+    return sample_noise_records(y, make_records(params, sample_ids), flags, seed, in_u16=in_u16, inject=inject, dump=dump, out=out)
+
+
+def decode_augment_u16(codes, bits=None):
+    """CUDA int16/uint16 LMDB codes (N,C,H,W) -> float32 clip(u16/65535) (lmdb_dataset.py:38-39), optionally through the
+    ELDTrainDataset index maps (sid_dataset.py:344-352); one HIP pass."""
+    import torch
+    assert codes.is_cuda and codes.element_size() == 2 and codes.dim() == 4
+    codes = codes.contiguous()
+    N, C, H, W = codes.shape
+    out = torch.empty((N, C, H, W), dtype=torch.float32, device=codes.device)
+    b, flags = None, 0
+    if bits is not None:
+        bits = [int(v) for v in bits]
+        if H != W:
+            if any(v & 4 for v in bits):
+                raise ValueError('augment: transpose bit set on a batch of non-square %dx%d images' % (H, W))
+            flags |= L.AUG_NOTRANSPOSE
+        b = _upload(np.asarray(bits, dtype=np.int32), codes.device)
+    L.check(L.lib().eld_augment_u16(L.dptr(codes), L.dptr(out), L.dptr(b), N, C, H, W, flags, L.cur_stream()), 'eld_augment_u16')
     return out
 
 
@@ -126,8 +203,14 @@ def augment(x, bits, clip=False):
     x = x.contiguous().float()
     N, C, H, W = x.shape
     out = torch.empty_like(x)
-    b = torch.as_tensor(list(bits), dtype=torch.int32, device=x.device)
-    L.check(L.lib().eld_augment(L.dptr(x), L.dptr(out), L.dptr(b), N, C, H, W, L.CLIP if clip else 0, L.cur_stream()), 'eld_augment')
+    bits = [int(v) for v in bits]
+    flags = L.CLIP if clip else 0
+    if H != W:                          # the reference transposes single (C,H,W) samples; a batched tensor cannot hold both shapes
+        if any(v & 4 for v in bits):
+            raise ValueError('augment: transpose bit set on a batch of non-square %dx%d images' % (H, W))
+        flags |= L.AUG_NOTRANSPOSE
+    b = _upload(np.asarray(bits, dtype=np.int32), x.device)
+    L.check(L.lib().eld_augment(L.dptr(x), L.dptr(out), L.dptr(b), N, C, H, W, flags, L.cur_stream()), 'eld_augment')
     return out
 
 
@@ -215,6 +298,8 @@ class NoiseModelBase:  # same name / role as noise.py:148
 
 
 class NoiseModel(NoiseModelBase):
+    last_instance = None
+
     def __init__(self, model='g', cameras=None, include=None, exclude=None, cfa='bayer'):
         super().__init__()
         assert cfa in ['bayer', 'xtrans']                   # noise.py:177
@@ -235,6 +320,10 @@ class NoiseModel(NoiseModelBase):
         self.model = model
         self.raw_packer = RawPacker(cfa)                    # noise.py:199
         self._counter = 0
+        # noise.py:209-210 reads the calibrated Kmin/Kmax and then samples log K from the hard-coded [0.1, 30] (:215); the
+        # calibrated range is the paper's.  Default = the reference's behaviour; ELD_AMD_CALIBRATED_K=1 or this attribute opts in.
+        self.use_calibrated_K = os.environ.get('ELD_AMD_CALIBRATED_K', '0') == '1'
+        NoiseModel.last_instance = self                     # eld_amd.model attaches the most recent instance (train_syn.py:38 -> :89)
 
     def _sample_params(self):
         """noise.py:201-225, same five draws from the global NumPy RandomState in the same order.
@@ -246,7 +335,10 @@ class NoiseModel(NoiseModelBase):
         camera_params = self.camera_params[camera]
         profile = np.random.choice(profiles)
         prof = camera_params[profile]
-        log_K = np.random.uniform(low=np.log(1e-1), high=np.log(30))
+        if self.use_calibrated_K:
+            log_K = np.random.uniform(low=np.log(camera_params['Kmin']), high=np.log(camera_params['Kmax']))
+        else:
+            log_K = np.random.uniform(low=np.log(1e-1), high=np.log(30))
         log_g_scale = np.random.standard_normal() * prof['g_scale']['sigma'] * 1 + \
             prof['g_scale']['slope'] * log_K + prof['g_scale']['bias']
         K = np.exp(log_K)

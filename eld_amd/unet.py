@@ -31,12 +31,13 @@ class _Workspace:
     def __init__(self):
         self.bufs = {}
         self.gen = {}
+        self.algo = {}       # fp32 product scheme the forward that filled the buffer ran with
 
     def get(self, key, nbytes, device):
         b = self.bufs.get(key)
         if b is None or b.numel() < nbytes or b.device != device:
             if len(self.bufs) > 4:          # shapes changed (e.g. chop tiles): drop old scratch
-                self.bufs.clear(); self.gen.clear()
+                self.bufs.clear(); self.gen.clear(); self.algo.clear()
             b = torch.empty(nbytes, dtype=torch.uint8, device=device)
             self.bufs[key] = b
             self.gen[key] = 0
@@ -116,6 +117,7 @@ class UNetSeeInDark(nn.Module):
 
     # ---- engine calls ----------------------------------------------------------------------------------
     inference_precision = 'fp32'          # 'bf16': no-grad forwards run eld_unet_forward_bf16 (BASELINE config 3 precision)
+    fp32_products = None                  # None: process default (eld_conv_fp32_algo / env ELD_FP32_CONV); 0 / 1 / 2 pins the scheme for this module
     train_precision = 'fp32'              # 'bf16': training forwards/backwards run the bf16 engine (fp32 master weights/grads)
 
     def _engine_forward(self, x, save, bf16=False):
@@ -132,9 +134,12 @@ class UNetSeeInDark(nn.Module):
         ws = self._ws.get(key, nbytes, x.device)
         self._ws.gen[key] += 1
         out = torch.empty((N, self.out_channels, H, W), dtype=torch.float32, device=x.device)
-        fn = L.lib().eld_unet_forward_bf16 if bf16 else L.lib().eld_unet_forward
-        L.check(fn(L.dptr(x), L.dptr(self.flat_params), L.dptr(out), L.dptr(ws), ws.numel(),
-                   N, H, W, self.in_channels, self.out_channels, L.cur_stream()), 'eld_unet_forward')
+        # the fp32 product scheme is named per call and remembered with the saved activations: the backward of THIS forward
+        # runs the same scheme even if the process default (eld_conv_fp32_algo) is changed in between
+        algo = self.fp32_products if self.fp32_products is not None else L.lib().eld_conv_fp32_algo(-1)
+        self._ws.algo[key] = algo
+        L.check(L.lib().eld_unet_forward_ex(L.dptr(x), L.dptr(self.flat_params), L.dptr(out), L.dptr(ws), ws.numel(),
+                                            N, H, W, self.in_channels, self.out_channels, 1 if bf16 else 0, algo, L.cur_stream()), 'eld_unet_forward_ex')
         return out, key, self._ws.gen[key]
 
     def _engine_backward(self, dout, key, shape, grads=None, buckets=None):
@@ -143,14 +148,10 @@ class UNetSeeInDark(nn.Module):
         ws = self._ws.bufs[key]
         if grads is None:
             grads = torch.empty(self._offsets[-1], dtype=torch.float32, device=dout.device)
-        if buckets is not None:
-            L.check(L.lib().eld_unet_backward_buckets(L.dptr(dout), L.dptr(self.flat_params), L.dptr(grads), L.dptr(ws), ws.numel(), N, H, W,
-                                                      self.in_channels, self.out_channels, 1 if key[0] == 'train_bf16' else 0,
-                                                      buckets.starts_c, buckets.events_c, buckets.n, L.cur_stream()), 'eld_unet_backward_buckets')
-            return grads
-        fn = L.lib().eld_unet_backward_bf16 if key[0] == 'train_bf16' else L.lib().eld_unet_backward
-        L.check(fn(L.dptr(dout), L.dptr(self.flat_params), L.dptr(grads), L.dptr(ws), ws.numel(),
-                   N, H, W, self.in_channels, self.out_channels, L.cur_stream()), 'eld_unet_backward')
+        starts, events, nb = (buckets.starts_c, buckets.events_c, buckets.n) if buckets is not None else (None, None, 0)
+        L.check(L.lib().eld_unet_backward_ex(L.dptr(dout), L.dptr(self.flat_params), L.dptr(grads), L.dptr(ws), ws.numel(), N, H, W,
+                                             self.in_channels, self.out_channels, 1 if key[0] == 'train_bf16' else 0, self._ws.algo[key],
+                                             starts, events, nb, L.cur_stream()), 'eld_unet_backward_ex')
         return grads
 
     def forward(self, x):

@@ -11,7 +11,11 @@
  *   - asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
  *     no hipMalloc / hipFree / hipDeviceSynchronize inside, so calls are hipGraph-capturable;
  *   - return value is a hipError_t as int (0 = success) or a negative ELD_E* code; nothing throws;
- *   - re-entrant per stream; no global mutable state.
+ *   - re-entrant per stream.  Process-wide state is limited to (a) immutable per-device caches (compute-unit count,
+ *     per-kernel LDS attribute set once per device) and (b) the DEFAULT fp32 product scheme of eld_conv_fp32_algo(), which
+ *     only the entry points that do not take a scheme argument consult; eld_unet_forward_ex / eld_unet_backward_ex name the
+ *     scheme per call and never read it.  Developer switches (ELD_CONV_DBG, ELD_NOISE_DBG, eld_debug_conv_prof) exist only in
+ *     builds made with -DELD_DEV_TOOLS=1; the default build ignores them.
  */
 #ifndef ELD_AMD_H
 #define ELD_AMD_H
@@ -39,6 +43,7 @@ extern "C" {
 #define ELD_QUANT        32u   /* 'U'  uniform quantisation noise  follows the ELD paper and    */
 #define ELD_CBIAS        64u   /* 'B'  per-channel colour bias     camera_params/release/ npy tables] */
 #define ELD_CLIP        128u   /* fuse the caller's clip to [0,1]       dataset/sid_dataset.py:277 */
+#define ELD_AUG_NOTRANSPOSE 256u /* eld_augment only: no image of the batch has its transpose bit set (then H != W is fine) */
 
 /* input element types */
 #define ELD_IN_F32  0   /* float32 in [0,1]                                                      */
@@ -87,6 +92,14 @@ int eld_noise_forward(const void* in, int in_dtype, float* out, const EldNoisePa
                       int N, int C, int H, int W, uint32_t flags, uint64_t seed,
                       const float* inject, float* dump, void* stream);
 
+/* The same sampler with explicit image strides (in ELEMENTS): image n is read at in + n*in_image_stride and written at
+ * out + n*out_image_stride.  Burst synthesis (SynDataset, dataset/sid_dataset.py:267-273: num_burst noisy frames of ONE clean
+ * image with ONE parameter draw, concatenated on the channel axis) is num_burst launches with out_image_stride =
+ * num_burst*C*H*W and out advanced by k*C*H*W, each with its own sample ids; in_image_stride 0 re-reads one clean image. */
+int eld_noise_forward_strided(const void* in, int in_dtype, size_t in_image_stride, float* out, size_t out_image_stride,
+                              const EldNoiseParams* params, int N, int C, int H, int W, uint32_t flags, uint64_t seed,
+                              const float* inject, float* dump, void* stream);
+
 /* Raw Philox4x32-10 words of the sampler's counter layout, for bit-exact RNG tests:
  * out[i*4..i*4+3] = philox(ctr=(index0+i, sample_id, stream|iter<<8), key=seed). */
 int eld_philox_words(uint32_t* out, uint32_t n, uint32_t index0, uint64_t sample_id,
@@ -100,9 +113,13 @@ int eld_unpack_bayer(const float* packed, float* mosaic, int N, int h, int w, vo
 
 /* Training-pair augmentation of ELDTrainDataset.__getitem__ (dataset/sid_dataset.py:344-352), batched on device:
  * per image n, bits of aug[n]: 1 = flip H (axis 1), 2 = flip W (axis 2), 4 = transpose (0,2,1), applied in that order;
- * ELD_CLIP in `flags` fuses the clip to [0,1] of sid_dataset.py:354.  A transposed image needs H == W (batched tensor).
+ * ELD_CLIP in `flags` fuses the clip to [0,1] of sid_dataset.py:354.  A transposed image needs H == W (batched tensor): with
+ * H != W the call returns ELD_ENOTSUP unless ELD_AUG_NOTRANSPOSE is set, which makes the kernel ignore bit 4.
  * in/out: float32 [N,C,H,W]; aug: device int32[N].  Pure index map: bit-exact. */
 int eld_augment(const float* in, float* out, const int32_t* aug, int N, int C, int H, int W, uint32_t flags, void* stream);
+/* The same on uint16 LMDB codes: out = augment(clip(u16/65535, 0, 1)) -- LMDBDataset.__getitem__'s decode (dataset/lmdb_dataset.py:
+ * 35-39, true fp32 division: bit-exact for all 65536 codes) fused in front; aug == NULL is the plain decode. */
+int eld_augment_u16(const uint16_t* in, float* out, const int32_t* aug, int N, int C, int H, int W, uint32_t flags, void* stream);
 
 /* ====================================================================================================
  * U-Net ("See-in-the-Dark", 5 scales) -- replaces UNetSeeInDark.forward (models/arch/Unet.py:48-91) and
@@ -147,8 +164,15 @@ int eld_unet_backward_buckets(const float* dout, const float* params, float* gra
                               int N, int H, int W, int in_ch, int out_ch, int precision,
                               const int64_t* bucket_start, void* const* bucket_event, int n_buckets, void* stream);
 
-/* mean |out-target| (nn.L1Loss, models/losses.py:32) and, if dout != NULL, its gradient times grad_scale.
- * ws: eld_l1_workspace_bytes() bytes.  loss: one device float. */
+/* The same two calls with everything per call: precision 0 = fp32 / 1 = bf16 activations; fp32_algo names the fp32 product
+ * scheme (see eld_conv_fp32_algo below; < 0 = the process default); n_buckets may be 0.  A backward must name the scheme its
+ * forward ran with: scheme 2 leaves operand bounds in the workspace that only a scheme-2 backward reads. */
+int eld_unet_forward_ex(const float* x, const float* params, float* out, void* ws, size_t ws_bytes,
+                        int N, int H, int W, int in_ch, int out_ch, int precision, int fp32_algo, void* stream);
+int eld_unet_backward_ex(const float* dout, const float* params, float* grads, void* ws, size_t ws_bytes,
+                         int N, int H, int W, int in_ch, int out_ch, int precision, int fp32_algo,
+                         const int64_t* bucket_start, void* const* bucket_event, int n_buckets, void* stream);
+
 /* How the fp32 3x3 convolutions of eld_unet_forward/backward and eld_conv3x3_* form their products:
  *   0  v_mfma_f32_32x32x2_f32 (fp32 operands);
  *   1  every fp32 operand cut exactly into three bf16 pieces, six v_mfma_f32_32x32x16_bf16 per k-block, fp32 accumulate
@@ -156,9 +180,12 @@ int eld_unet_backward_buckets(const float* dout, const float* params, float* gra
  *   2  every fp32 operand scaled by a per-tensor power of two and cut into two fp16 pieces (22 significant bits), three
  *      v_mfma_f32_32x32x16_f16 per k-block, fp32 accumulate: each product is good to 2^-22 instead of 2^-24, which stays
  *      inside the fp32 dot-product error bound for every contraction length >= 4 (csrc/conv_igemm.hip, H2).
- * algo < 0 only queries.  Process-wide; returns the value in force before the call.  Initial value: env ELD_FP32_CONV. */
+ * algo < 0 only queries.  Process-wide DEFAULT for the entry points without a scheme argument; returns the value in force
+ * before the call.  Initial value: env ELD_FP32_CONV. */
 int eld_conv_fp32_algo(int algo);
 
+/* mean |out-target| (nn.L1Loss, models/losses.py:32) and, if dout != NULL, its gradient times grad_scale.
+ * ws: eld_l1_workspace_bytes() bytes.  loss: one device float. */
 size_t eld_l1_workspace_bytes(void);
 int eld_l1_loss(const float* out, const float* target, float* dout, float* loss, void* ws, size_t n, float grad_scale, void* stream);
 /* --loss l2: nn.MSELoss (models/losses.py:34), same contract and workspace as eld_l1_loss. */
@@ -189,7 +216,7 @@ int eld_illuminance_correct(const float* predict, const float* source, float* ou
 int eld_isp_process(const float* bayer, const float* wbs, const float* ccms, float* out, int N, int H, int W, float gamma,
                     const float* crf_E, const float* crf_f, int crf_n, void* stream);
 
-/* Dev tool (tools/conv_phase_profile.py): device buffer of 8 x 4 x 128 x 6 uint64 that conv_x3_kernel fills with s_memtime
+/* Dev tool (tools/conv_phase_profile.py; a no-op unless built with -DELD_DEV_TOOLS=1): device buffer of 8 x 4 x 128 x 6 uint64 that conv_x3_kernel fills with s_memtime
  * stamps of its stage phases (first 8 workgroups, first 128 stages); NULL switches it off (default). */
 void eld_debug_conv_prof(void* buf);
 
