@@ -23,3 +23,18 @@ def eld_lib():
     """The HIP library must be the thing under test on a GPU box: no fallback, fail loudly."""
     import eld_amd
     return eld_amd.load_library()
+
+
+@pytest.fixture(autouse=True)
+def _restore_torch_threads():
+    """Some tests raise torch's CPU thread count for the oracle; reductions (e.g. the weight checksums compared bit-for-bit
+    with tests/golden/unet.npz) depend on it, so every test starts from the same setting."""
+    try:
+        import torch
+    except Exception:
+        yield
+        return
+    n = torch.get_num_threads()
+    yield
+    if torch.get_num_threads() != n:
+        torch.set_num_threads(n)
