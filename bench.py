@@ -66,42 +66,63 @@ def timed_events(fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
+def _cpu_sampler_worker(args):
+    """One forked DataLoader-style worker: the NumPy sampler port on one image (its own NumPy stream, like worker_init_fn)."""
+    y, model, seed = args
+    from oracle import noise_ref as O
+    rs = np.random.RandomState(seed)
+    p = O.Params(K=2.288, g_scale=6.451, ratio=208.98, tl_lambda=-0.14285714, tl_scale=3.3, row_scale=0.9)
+    t0 = time.time()
+    O.noise_numpy_full(y, p, O.model_flags(model) | O.CLIP, rng=rs)
+    return time.time() - t0
+
+
 def cpu_baseline(h, w, seed=2018):
-    """Reference-style CPU path timed on this box's host cores (bounded sample, ~10-20 s of CPU work): the NumPy sampler
-    port on full 4x1424x2128 images (single-threaded NumPy, like noise.py) + torch-CPU U-Net training steps
-    (forward + L1 + backward + Adam, up to 32 threads) on a 4x1024x1024 crop; combined per pixel."""
+    """The reference-style CPU path timed on THIS box's host cores, bounded to ~20-30 s of CPU work (kind "port": the oracle's
+    NumPy / torch-CPU restatement -- /root/reference does not exist on the GPU box):
+      * sampler: NumPy port, single thread like noise.py (np.random is single-threaded), on ONE full 4 x h x w image, for the
+        full model 'PGRU' and for the reference's own 'Pg' (noise.py:158-166); plus the reference's real deployment, 8 forked
+        DataLoader workers (--nThreads 8, base_option.py:26), one 'Pg' image each, as an aggregate rate;
+      * U-Net: one torch-CPU fp32 training step (forward + L1 + backward + Adam, up to 32 threads) on ONE full 4 x h x w frame
+        (after a warm-up step on a 512 x 512 crop).
+    value = combined per-pixel rate of (PGRU sampler, 1 thread) + (U-Net step)."""
+    import multiprocessing as mp
     from oracle import noise_ref as O
     from oracle import unet_ref as U
     rs = np.random.RandomState(seed)
     y = (np.floor(65535.0 * rs.uniform(size=(4, h, w)) ** 2.2) / 65535.0).astype(np.float32)
-    p = O.Params(K=2.288, g_scale=6.451, ratio=208.98, tl_lambda=-0.14285714, tl_scale=3.3, row_scale=0.9)
-    flags = O.SHOT_POISSON | O.READ_TL | O.ROW | O.QUANT | O.CLIP
-    t_noise = 1e9
-    for _ in range(3):
-        t0 = time.time()
-        O.noise_numpy_full(y, p, flags, rng=rs)
-        t_noise = min(t_noise, time.time() - t0)
+    t_full = min(_cpu_sampler_worker((y, 'PGRU', seed + i)) for i in range(2))
+    t_pg = _cpu_sampler_worker((y, 'Pg', seed))
+    workers = 8
+    t0 = time.time()
+    with mp.get_context('fork').Pool(workers) as pool:
+        pool.map(_cpu_sampler_worker, [(y, 'Pg', seed + 100 + i) for i in range(workers)])
+    t_pool = time.time() - t0
     cores = min(os.cpu_count() or 1, 32)     # torch-CPU convs stop scaling (and oversubscribe) beyond a few dozen threads
     torch.set_num_threads(cores)
-    ch, cw = min(1024, h), min(1024, w)
     sd = U.seeded_state_dict(4, 4, seed=seed)
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     opt = torch.optim.Adam(list(params.values()), lr=1e-4)
-    x = torch.from_numpy(y[None, :, :ch, :cw].copy())
-    t_unet = 1e9
-    for it in range(3):                 # one warm-up, two timed (min)
+
+    def cpu_step(x):
         t0 = time.time()
         opt.zero_grad()
         loss = torch.nn.functional.l1_loss(U.unet_forward(params, x), x)
         loss.backward()
         opt.step()
-        if it:
-            t_unet = min(t_unet, time.time() - t0)
-    per_pix = t_noise / (4.0 * h * w) + t_unet / (4.0 * ch * cw)
+        loss.item()                      # the reference reads loss.item() every iteration (ELD_model.py:480)
+        return time.time() - t0
+    cpu_step(torch.from_numpy(y[None, :, :min(512, h), :min(512, w)].copy()))      # warm-up (thread pool, oneDNN primitives)
+    t_unet = cpu_step(torch.from_numpy(y[None].copy()))
+    npx = 4.0 * h * w
+    per_pix = t_full / npx + t_unet / npx
     return {'value': round(1e-6 / per_pix, 4), 'unit': 'raw MPix/s', 'cores': cores, 'kind': 'port',
-            'sample': 'NumPy sampler port (1 thread) on one 4x%dx%d image: %.2f s (min of 3); torch-CPU fp32 U-Net step (%d threads) on one '
-                      '4x%dx%d crop: %.2f s (min of 2 warm); combined per pixel' % (h, w, t_noise, cores, ch, cw, t_unet),
-            'sampler_mpix_s': round(4.0 * h * w / t_noise / 1e6, 3), 'unet_step_mpix_s': round(4.0 * ch * cw / t_unet / 1e6, 4)}
+            'sample': 'one 4x%dx%d frame: NumPy sampler port PGRU %.2f s (1 thread, min of 2), Pg %.2f s (1 thread), 8 forked workers x 1 Pg image '
+                      '%.2f s wall; torch-CPU fp32 U-Net train step (fwd, L1, bwd, Adam, loss.item()) on the full frame %.2f s (%d threads, after a '
+                      '512x512 warm-up step); value = PGRU sampler + U-Net step per pixel' % (h, w, t_full, t_pg, t_pool, t_unet, cores),
+            'sampler_mpix_s': round(npx / t_full / 1e6, 3), 'sampler_Pg_mpix_s': round(npx / t_pg / 1e6, 3),
+            'sampler_Pg_8workers_mpix_s': round(workers * npx / t_pool / 1e6, 3), 'unet_step_mpix_s': round(npx / t_unet / 1e6, 4),
+            'os_cpu_count': os.cpu_count()}
 
 
 def main():
@@ -150,6 +171,7 @@ def main():
         ids = [(i * world * B) + rank + world * k for k in range(B)]      # global sample indices
         model.set_input({'target': clean, 'params': plists[i % len(plists)], 'sample_ids': ids}, 'train')
         model.optimize_parameters()
+        return model.get_current_errors()['Pixel']           # loss.item(): the reference's per-iteration device sync (ELD_model.py:480)
 
     for i in range(args.warmup):
         step(i)
@@ -158,16 +180,36 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.warmup, total_steps):
-        step(i)
+        loss = step(i)
     torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0
     if world > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
+    per_rank, exchange = None, None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
-    loss = model.get_current_errors().get('Pixel')
+        allr = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        torch.distributed.all_gather(allr, torch.tensor([dt_local / args.steps * 1e3], dtype=torch.float64, device=dev))
+        per_rank = [round(float(v.item()), 3) for v in allr]
+        # exposed cost of the gradient exchange: the same steps with the all-reduce switched off (replicas diverge: done last)
+        model.exchange = False
+        step(total_steps); torch.cuda.synchronize(); torch.distributed.barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step(total_steps + 1 + i)
+        torch.cuda.synchronize()
+        t_noex = torch.tensor([(time.perf_counter() - t1) / args.steps * 1e3], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t_noex, op=torch.distributed.ReduceOp.MAX)
+        model.exchange = True
+        nbytes = 4 * model.optimizer_G.grads.numel()
+        exchange = {'bytes': nbytes, 'buckets': (model._buckets.n if model._buckets is not None else 1), 'ms_per_step_without_exchange': round(float(t_noex.item()), 3),
+                    'exposed_ms': round(max(0.0, dt / args.steps * 1e3 - float(t_noex.item())), 3),
+                    'ring_floor_ms': round(2.0 * (world - 1) / world * nbytes / 153e9 * 1e3, 3),
+                    'note': 'exposed = step time with the bucketed RCCL all-reduce (overlapped with the backward) minus the same step without it; '
+                            'ring_floor = 2(N-1)/N x bytes over one ~153 GB/s xGMI link'}
 
     pix_per_step = world * B * 4.0 * Hh * Ww
     res = {
@@ -177,13 +219,16 @@ def main():
         'dtype': 'f32' if args.precision == 'fp32' else 'bf16', 'data': 'synthetic',
         'config': {'workload': 'BASELINE.json configs[%d]: full ELD noise model (%s, SonyA7S2 params) on 4x%dx%d packed raw + U-Net %s '
                                'train step (fwd, L1, bwd, Adam), %d frames per GPU' % (1 if args.precision == 'fp32' else 2, args.noise, Hh, Ww, args.precision, B),
-                   'images_per_gpu': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world, 'final_loss': loss,
+                   'images_per_gpu': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world, 'final_loss': loss, 'loss_item_sync_per_step': True,
                    'fp32_products': (None if args.precision != 'fp32' else
                                      {0: 'v_mfma_f32_32x32x2_f32', 1: 'fp32 operands cut exactly into 3 bf16 pieces, 6 bf16 MFMA products per k-block, fp32 accumulate '
                                       '(each product exact to below fp32 rounding; eld_conv_fp32_algo 1)', 2: '2 fp16 pieces per operand (22-bit products), fp32 accumulate'}
                                      [eld_amd.load_library().eld_conv_fp32_algo(-1)])},
     }
 
+    if per_rank is not None:
+        res['per_rank_ms_per_step'] = per_rank
+        res['allreduce'] = exchange
     if rank == 0:
         # ---- roofline of the dominant kernels, measured live with HIP events on the launch stream ----------------------
         net = model.netG

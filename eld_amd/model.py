@@ -106,6 +106,7 @@ class ELDModel:
         prec = getattr(opt, 'precision', os.environ.get('ELD_AMD_PRECISION', 'fp32'))      # 'bf16' = BASELINE config 3
         self.netG.train_precision = self.netG.inference_precision = prec
         self.world, self.rank = D.world_size(), D.rank()
+        self.exchange = True                                 # False: skip the gradient all-reduce (bench.py measures its exposed cost)
         self._buckets = None
         if self.world > 1:
             D.broadcast_(self.netG.flat_params, 0)          # identical replicas
@@ -244,7 +245,10 @@ class ELDModel:
         loss_fn = L.lib().eld_mse_loss if self.loss_name == 'l2' else L.lib().eld_l1_loss
         L.check(loss_fn(L.dptr(out), L.dptr(tgt), L.dptr(dout), L.dptr(self._loss_buf), L.dptr(self._l1_ws),
                         out.numel(), 1.0, L.cur_stream()), 'eld_%s_loss' % self.loss_name)      # backward_G(): loss + its gradient
-        if self.world > 1 and opt.grads.is_cuda:                              # data-parallel exchange (new):
+        if not self.exchange:
+            net._engine_backward(dout, key, tuple(x.shape), grads=opt.grads)
+            w = 1
+        elif self.world > 1 and opt.grads.is_cuda:                            # data-parallel exchange (new):
             if self._buckets is None:                                         # buckets all-reduced under the rest of the backward
                 self._buckets = D.GradBuckets(opt.grads.numel(), opt.grads.device)
             net._engine_backward(dout, key, tuple(x.shape), grads=opt.grads, buckets=self._buckets)      # loss.backward()
