@@ -88,6 +88,11 @@ int launch_conv(const ConvArgs& a, int mode, hipStream_t st);
 int conv_fp32_algo(int set);
 inline int resolve_algo(int algo) { return (algo >= 0 && algo <= 2) ? algo : conv_fp32_algo(-1); }
 int launch_conv_x3(const ConvArgs& a, hipStream_t st);
+// three-piece scheme: 3x3 layers whose GEMM N (Nout) is a multiple of 64 take their weights PRE-SPLIT in the slab layout of
+// conv_x3d_kernel (conv_x3.hip); returns the slab's channel-block width BN (64 or 128), or 0 for layers that keep fp32 packed weights
+int x3_slab_bn(int Nout);
+// bytes of one packed layer in slab layout: 9 taps x Nout x K/16 rows of 112 B
+inline size_t x3_slab_bytes(int Nout, int K) { return (size_t)9 * Nout * ((K + 15) / 16) * 112; }
 void conv_x3_set_prof(unsigned long long* buf);      // dev tool: 8 workgroups x 4 waves x 128 stages x 6 stamps
 int launch_conv_x3_gemm(const ConvArgs& a, int mode, hipStream_t st);      // transposed-conv directions; ELD_ENOTSUP if not covered
 

@@ -134,7 +134,6 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
     };
 
     int t = blockIdx.x;
-    int pstage = 0;
     if (t >= total_tiles) return;
     setup_load(t);
     load_A(0);
@@ -160,18 +159,11 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
 #pragma unroll 1
             for (int ky = 0; ky < 3; ++ky) {
                 __builtin_amdgcn_s_setprio(3);   // the short staging section goes ahead of the co-resident workgroup's MFMA stream
-                unsigned long long* pf = nullptr;
-                if (ELD_PROF(a) && blockIdx.x < 8 && lane == 0 && pstage < 128) pf = ELD_PROF(a) + (((size_t)blockIdx.x * 4 + wave) * 128 + pstage) * 6;
-                ++pstage;
-                if (pf) pf[0] = __builtin_amdgcn_s_memtime();
                 __syncthreads();                 // every wave is done with the previous stage's operands
-                if (pf) pf[1] = __builtin_amdgcn_s_memtime();
-                if (ky == 0 && !(ELD_DBG(a) & 16)) store_A();
-                if (!(ELD_DBG(a) & 8)) store_B();
-                if (pf) { __builtin_amdgcn_s_waitcnt(0xC07F); pf[2] = __builtin_amdgcn_s_memtime(); }
+                if (ky == 0) store_A();
+                store_B();
                 __syncthreads();
-                if (pf) pf[3] = __builtin_amdgcn_s_memtime();
-                if (!(ELD_DBG(a) & 4)) {
+                {
                     if (ky == 0) {               // the halo tile of the next chunk / next tile has three stages to arrive
                         if (!last_chunk) load_A(c0 + CK);
                         else if (t_next < total_tiles) { setup_load(t_next); load_A(0); }
@@ -200,7 +192,6 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
                 constexpr int XI[6] = {2, 1, 0, 1, 0, 0};
                 if constexpr (DB) {
                     read_tap(0, fx[0], fw[0]);
-                    if (pf) { __builtin_amdgcn_s_waitcnt(0xC07F); pf[4] = __builtin_amdgcn_s_memtime(); }
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         const int cur = kx & 1;
@@ -221,7 +212,6 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
                                                                                              __builtin_bit_cast(bf16x8, fx[cur][j][r]), acc[r][tt], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (pf) pf[5] = __builtin_amdgcn_s_memtime();
                 } else {                         // register budget: one fragment set, the compiler interleaves reads and MFMAs
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
@@ -246,7 +236,272 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
                 const int y = y0 + wave * RPW + r;
-                if (y >= a.H || (ELD_DBG(a) & 1) || !xok) continue;
+                if (y >= a.H || !xok) continue;
+                const size_t pix = (size_t)(img * a.H + y) * a.W + x;
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) {
+                    const int nbase = nb * BN + tt * 32 + 4 * hi;
+                    float4 v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = make_float4(acc[r][tt][4 * q], acc[r][tt][4 * q + 1], acc[r][tt][4 * q + 2], acc[r][tt][4 * q + 3]);
+                    float* dst[4];
+                    if (a.epi == EPI_FWD) {
+                        float4 bs[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) bs[q] = *reinterpret_cast<const float4*>(a.bias + nbase + 8 * q);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            v[q].x += bs[q].x; v[q].y += bs[q].y; v[q].z += bs[q].z; v[q].w += bs[q].w;
+                            if (a.lrelu) {
+                                v[q].x = fmaxf(0.2f * v[q].x, v[q].x); v[q].y = fmaxf(0.2f * v[q].y, v[q].y);
+                                v[q].z = fmaxf(0.2f * v[q].z, v[q].z); v[q].w = fmaxf(0.2f * v[q].w, v[q].w);
+                            }
+                            dst[q] = static_cast<float*>(a.out0) + pix * a.Nout + nbase + 8 * q;
+                        }
+                    } else {
+                        float4 s[4];
+                        bool has[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int n = nbase + 8 * q;
+                            const bool lo = n < a.split;
+                            const int C = lo ? a.split : a.Nout - a.split;
+                            const size_t idx = pix * C + (lo ? n : n - a.split);
+                            dst[q] = static_cast<float*>(lo ? a.out0 : a.out1) + idx;
+                            const float* act = static_cast<const float*>(lo ? a.act0 : a.act1);
+                            has[q] = act != nullptr;
+                            s[q] = make_float4(1.f, 1.f, 1.f, 1.f);
+                            if (has[q]) s[q] = *reinterpret_cast<const float4*>(act + idx);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (has[q]) {
+                                v[q].x *= lrelu_slope(s[q].x); v[q].y *= lrelu_slope(s[q].y);
+                                v[q].z *= lrelu_slope(s[q].z); v[q].w *= lrelu_slope(s[q].w);
+                            }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(v[q].x), "+v"(v[q].y), "+v"(v[q].z), "+v"(v[q].w));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(dst[q]) = v[q];
+                }
+            }
+        }
+        if (t_next >= total_tiles) break;
+        t = t_next;
+    }
+}
+
+// =============================================================================================================================
+// conv_x3d_kernel: the same convolution with the WEIGHT operand pre-split once per step (pack kernels, unet_misc.hip) and laid out
+// in global memory as the exact LDS image of a stage's slab, so that a stage's weights travel L2 -> LDS by LDS-DMA
+// (buffer_load_dwordx4 ... lds: no VGPRs, no split VALU, no ds_write) into a double buffer, one stage ahead of their use.
+// Only the activation halo tile still goes through registers (it is fp32 in HBM and must be cut into pieces on the way in),
+// once per 16-channel chunk = once per three stages.
+//
+//   packed weights:  slab(ky, chunk, nb) = [kx 0..2][n 0..BN)[3 pieces][16 bf16] + 16 B pad per row  (3*BN rows x 112 B, 1 KiB-multiple)
+//                    at byte offset ((ky * (K/16) + chunk) * (Nout/BN) + nb) * 3*BN*112          (x3_store in unet_misc.hip)
+//   stage s:         barrier [slab s landed (each wave drained its own DMA pieces before arriving) / everybody done with stage s-1]
+//                    ky == 0:  cut the halo registers into LDS, barrier
+//                    issue DMA of slab s+1 into the other buffer; ky == 0: issue the next chunk's halo loads into registers
+//                    3 taps x 6 piece products x RPW x NT MFMAs out of LDS
+// Barriers per chunk: 4 (was 6); VALU per MFMA: the activation cut only.  WAVES = 4 (two workgroups per CU) or 8 (one).
+// One 1 KiB LDS-DMA piece: lane l copies the 16 bytes at buffer offset voff (per lane) + soff (wave-uniform) to LDS byte address
+// lds_dst + 16 l (lds_dst wave-uniform).  Issued through inline asm ON PURPOSE: hipcc orders every later ds_read behind an LDS-DMA it
+// knows about (s_waitcnt vmcnt(0) in front of the stage's first fragment read, which would serialise the prefetch and drain the halo
+// loads with it).  The kernel waits for its own pieces explicitly (dma_wait) before the barrier that publishes the slab.
+// s_nop 4: SALU-written soffset / descriptor -> VMEM read wait states; s_nop 0: M0 write -> LDS-DMA; M0 is saved and restored.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void bdma16(i32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <int BN, int RPW, int WAVES, bool DB>
+__global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN == 64) ? 2 : (WAVES == 8 ? 2 : 1)) void conv_x3d_kernel(const ConvArgs a) {
+    constexpr int CK = 16, THREADS = 64 * WAVES;
+    constexpr int TH = WAVES * RPW, NT = BN / 32, A_PIX = (TH + 2) * (TW + 2);
+    constexpr int A_WORDS = A_PIX * PX, B_ROWS = 3 * BN, B_WORDS = B_ROWS * PX;
+    constexpr int B_PIECES = B_WORDS * 4 / 1024;                      // 1 KiB per wave-instruction
+    static_assert(B_WORDS * 4 % 1024 == 0, "slab must be a whole number of 1 KiB DMA pieces");
+    constexpr int DMA_IT = (B_PIECES + WAVES - 1) / WAVES;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* ldsB = lds;                                                // two slabs first: the DMA destinations stay at low LDS addresses
+    float* ldsA = lds + 2 * B_WORDS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31, hi = lane >> 5;
+    const int NB = a.Nout / BN;
+    const int Cin = a.C0 + a.C1, NCH = Cin / CK;
+    const int total_tiles = a.tiles_x * a.tiles_y * a.N * NB;
+    const int Cs0 = a.C0;
+
+    constexpr int A_UNITS = A_PIX * 4;
+    constexpr int A_IT = (A_UNITS + THREADS - 1) / THREADS;
+    float4 ra[A_IT];
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    unsigned a_voff[A_IT];
+    int l_img = 0;
+    const unsigned ldsB_addr = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(__attribute__((address_space(3))) float*)ldsB);
+    const unsigned long long wbase = (unsigned long long)a.wp;
+    const i32x4 rsrc_w = {(int)(unsigned)wbase, (int)((unsigned)(wbase >> 32) & 0xFFFFu), (int)((size_t)9 * a.Nout * NCH * 112), 0x00020000};
+    const unsigned dma_voff = (unsigned)lane * 16u;
+
+    auto decode = [&](int t, int& nb, int& img, int& y0, int& x0) {
+        nb = t % NB;
+        int r = t / NB;
+        const int tx = r % a.tiles_x;
+        r /= a.tiles_x;
+        const int ty = r % a.tiles_y;
+        img = r / a.tiles_y;
+        y0 = ty * TH; x0 = tx * TW;
+    };
+    auto setup_load = [&](int t) {
+        int nb, y0, x0;
+        decode(t, nb, l_img, y0, x0);
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int u = tid + it * THREADS;
+            const int hp = u >> 2, part = u & 3;
+            const int hy = hp / (TW + 2), hx = hp - hy * (TW + 2);
+            const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+            const bool ok = u < A_UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            a_voff[it] = ok ? (unsigned)(gy * a.W + gx) * (unsigned)(Cs0 * 4) + (unsigned)part * 16u : OOB;
+        }
+    };
+    auto load_A = [&](int c0) {
+        const char* src = static_cast<const char*>(c0 < a.C0 ? a.in0 : a.in1);
+        const int cs = c0 < a.C0 ? c0 : c0 - a.C0;
+        const size_t img_bytes = (size_t)a.H * a.W * Cs0 * 4;
+        const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)l_img * img_bytes), 0, (int)img_bytes, 0x00020000);
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it)
+            ra[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)a_voff[it], cs * 4, 0));
+    };
+    auto store_A = [&]() {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int u = tid + it * THREADS;
+            if (u < A_UNITS) split_store(ldsA + (u >> 2) * PX + (u & 3) * 2, ra[it]);
+        }
+    };
+    // slab (nb, chunk, ky) -> LDS buffer `buf`: wave w moves pieces w, w + WAVES, ...
+    auto dma_B = [&](int buf, int nb, int chunk, int ky) {
+        const unsigned soff = (unsigned)(((ky * NCH + chunk) * NB + nb) * (B_WORDS * 4));
+#pragma unroll
+        for (int it = 0; it < DMA_IT; ++it) {
+            const int piece = wave + it * WAVES;             // wave-uniform
+            if (piece < B_PIECES) bdma16(rsrc_w, dma_voff, soff + (unsigned)(piece * 1024), ldsB_addr + (unsigned)(buf * B_WORDS * 4 + piece * 1024));
+        }
+    };
+
+    int t = blockIdx.x;
+    if (t >= total_tiles) return;
+    setup_load(t);
+    load_A(0);
+    int buf = 0;
+    {
+        int nb0, i0, y00, x00;
+        decode(t, nb0, i0, y00, x00);
+        dma_B(0, nb0, 0, 0);
+    }
+    for (;;) {
+        int nb, img, y0, x0;
+        decode(t, nb, img, y0, x0);
+        const int t_next = t + gridDim.x;
+        f32x16 acc[RPW][NT];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[r][tt][i] = 0.f;
+
+        for (int chunk = 0; chunk < NCH; ++chunk) {
+            const bool last_chunk = chunk + 1 >= NCH;
+#pragma unroll 1
+            for (int ky = 0; ky < 3; ++ky) {
+                __builtin_amdgcn_s_setprio(3);   // the short staging section goes ahead of co-resident waves' MFMA streams
+                dma_wait();                      // this wave's pieces of the stage's slab (issued one stage ago) have landed
+                __syncthreads();                 // ... and so have everybody else's; the previous stage's fragment reads are done
+                if (ky == 0) {
+                    store_A();
+                    __syncthreads();
+                }
+                if (ky < 2) dma_B(buf ^ 1, nb, chunk, ky + 1);
+                else if (!last_chunk) dma_B(buf ^ 1, nb, chunk + 1, 0);
+                else if (t_next < total_tiles) dma_B(buf ^ 1, t_next % NB, 0, 0);
+                if (ky == 0) {                   // the halo tile of the next chunk / next tile has three stages to arrive
+                    if (!last_chunk) load_A((chunk + 1) * CK);
+                    else if (t_next < total_tiles) { setup_load(t_next); load_A(0); }
+                }
+                __builtin_amdgcn_s_setprio(0);
+                const float* lb = ldsB + buf * B_WORDS;
+                uint4 fx[DB ? 2 : 1][3][RPW], fw[DB ? 2 : 1][3][NT];
+                auto read_tap = [&](int kx, uint4 (&X)[3][RPW], uint4 (&Wt)[3][NT]) {
+#pragma unroll
+                    for (int r = 0; r < RPW; ++r) {
+                        const float* p = ldsA + ((wave * RPW + r + ky) * (TW + 2) + m + kx) * PX + hi * 4;
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc) X[pc][r] = *reinterpret_cast<const uint4*>(p + pc * 8);
+                    }
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt) {
+                        const float* p = lb + (kx * BN + tt * 32 + m) * PX + hi * 4;
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc) Wt[pc][tt] = *reinterpret_cast<const uint4*>(p + pc * 8);
+                    }
+                };
+                constexpr int WI[6] = {0, 1, 2, 0, 1, 0};
+                constexpr int XI[6] = {2, 1, 0, 1, 0, 0};
+                if constexpr (DB) {
+                    read_tap(0, fx[0], fw[0]);
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int cur = kx & 1;
+                        if (kx + 1 < 3) read_tap(kx + 1, fx[cur ^ 1], fw[cur ^ 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                            for (int j = 2; j >= 0; --j)
+#pragma unroll
+                                for (int i = 0; i + j <= 2; ++i)
+#pragma unroll
+                                    for (int tt = 0; tt < NT; ++tt)
+                                        acc[r][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[cur][i][tt]),
+                                                                                             __builtin_bit_cast(bf16x8, fx[cur][j][r]), acc[r][tt], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        read_tap(kx, fx[0], fw[0]);
+#pragma unroll
+                        for (int q = 0; q < 6; ++q)
+#pragma unroll
+                            for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                                for (int tt = 0; tt < NT; ++tt)
+                                    acc[r][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[0][WI[q]][tt]),
+                                                                                         __builtin_bit_cast(bf16x8, fx[0][XI[q]][r]), acc[r][tt], 0, 0, 0);
+                    }
+                }
+                buf ^= 1;
+            }
+        }
+
+        // ---- epilogue: lane (m, hi) owns pixel x0+m and channels 8q+4hi..+3 of each 32-block (as conv_x3_kernel) ----
+        {
+            const int x = x0 + m;
+            const bool xok = x < a.W;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int y = y0 + wave * RPW + r;
+                if (y >= a.H || !xok) continue;
                 const size_t pix = (size_t)(img * a.H + y) * a.W + x;
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) {
@@ -503,10 +758,31 @@ int launch_x3(ConvArgs a, hipStream_t st) {
     int per_cu = (int)((160 * 1024) / lds_bytes);
     if (per_cu > 2) per_cu = 2;
     if (per_cu < 1) per_cu = 1;
-    if (ELD_DBG(a) & 64) per_cu = 1;
-    long long grid = (long long)eld_num_cus() * per_cu * ((ELD_DBG(a) & 128) ? 2 : 1);
+    long long grid = (long long)eld_num_cus() * per_cu;
     if (grid > tiles) grid = tiles;
     ELD_LAUNCH(kern, dim3((unsigned)grid), dim3(256), lds_bytes, st, a);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int BN, int RPW, int WAVES, bool DB>
+int launch_x3d(ConvArgs a, hipStream_t st) {
+    constexpr int TH = WAVES * RPW;
+    a.tiles_x = (a.W + TW - 1) / TW;
+    a.tiles_y = (a.H + TH - 1) / TH;
+    const size_t lds_bytes = (size_t)((TH + 2) * (TW + 2) + 2 * 3 * BN) * PX * sizeof(float);
+    const long long tiles = (long long)a.tiles_x * a.tiles_y * a.N * (a.Nout / BN);
+    if (tiles <= 0) return 0;
+    if (tiles > 0x7fffffffLL) return ELD_ENOTSUP;
+    auto kern = conv_x3d_kernel<BN, RPW, WAVES, DB>;
+    static EldAttrOnce once;
+    { const int rc = once.ensure(kern, lds_bytes); if (rc) return rc; }
+    int per_cu = (int)((160 * 1024) / lds_bytes);
+    if (per_cu > 2) per_cu = 2;
+    if (per_cu < 1) per_cu = 1;
+    long long grid = (long long)eld_num_cus() * per_cu;
+    if (grid > tiles) grid = tiles;
+    ELD_LAUNCH(kern, dim3((unsigned)grid), dim3(64 * WAVES), lds_bytes, st, a);
     ELD_LAUNCH_CHECK();
     return 0;
 }
@@ -531,22 +807,33 @@ int launch_x3_gemm(ConvArgs a, hipStream_t st) {
 
 }  // namespace
 
-#if ELD_DEV_TOOLS
-static unsigned long long* g_prof = nullptr;
-void conv_x3_set_prof(unsigned long long* buf) { g_prof = buf; }
-#else
-void conv_x3_set_prof(unsigned long long*) {}
-#endif
+void conv_x3_set_prof(unsigned long long*) {}       // the s_memtime stage profiler of round 1 is gone with the kernel it instrumented
+
+static int x3d_variant() {                       // dev knob (read once): ELD_X3D_VARIANT = 0 | 1 | 2, see launch_conv_x3
+    static int variant = -1;
+    if (variant < 0) { const char* e = getenv("ELD_X3D_VARIANT"); variant = e ? atoi(e) : 2; }
+    return variant;
+}
+
+int x3_slab_bn(int Nout) {
+    if (Nout % 64) return 0;
+    return (x3d_variant() >= 1 && Nout % 128 == 0) ? 128 : 64;
+}
 
 // a: fp32 CONV_3X3 arguments already validated by launch_conv
 int launch_conv_x3(const ConvArgs& a_in, hipStream_t st) {
     ConvArgs a = a_in;
     a.prof = nullptr;
-#if ELD_DEV_TOOLS
-    a.prof = g_prof;
-#endif
     if ((size_t)a.H * a.W * a.C0 * 4 >= 0xFFFFFFF0ull) return ELD_ENOTSUP;
-    return a.Nout % 64 == 0 ? launch_x3<64, 2, true>(a, st) : launch_x3<32, 4, false>(a, st);
+    if (a.Nout % 64 == 0) {                      // weights pre-split in slab layout (x3_slab_bn): LDS-DMA kernel
+        // ELD_X3D_VARIANT: 0 = 64 channels x 8 rows, 2 WG/CU; 1 = 128-channel tiles, 4 waves, 1 WG/CU; 2 = 128-channel tiles x 16 rows, 8 waves
+        if (x3_slab_bn(a.Nout) == 128) {
+            if (x3d_variant() == 2) return launch_x3d<128, 2, 8, false>(a, st);
+            return launch_x3d<128, 2, 4, true>(a, st);
+        }
+        return launch_x3d<64, 2, 4, true>(a, st);
+    }
+    return launch_x3<32, 4, false>(a, st);
 }
 
 // transposed-conv directions (CONV_1X1 + EPI_CONVT_FWD, CONV_GATHER2X2 + EPI_GRAD); returns ELD_ENOTSUP for shapes the GEMM

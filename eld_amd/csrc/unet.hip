@@ -175,8 +175,8 @@ int make_plan(Plan& P, int N, int H, int W, int in_ch, int out_ch) {
         const LayerDef& d = P.L[i];
         if (d.kind == 0) {
             const int cinp = (d.cin + 15) / 16 * 16;
-            P.wp_fwd[i] = take((size_t)9 * d.cout * cinp);
-            P.wp_bwd[i] = (i == L_E0A) ? 0 : take((size_t)9 * d.cin * d.cout);
+            P.wp_fwd[i] = take((size_t)9 * d.cout * cinp * 2);          // fp32 [tap][n][c] or the pre-split slab layout (7 B per element)
+            P.wp_bwd[i] = (i == L_E0A) ? 0 : take((size_t)9 * d.cin * d.cout * 2);
         } else if (d.kind == 1) {
             P.wp_fwd[i] = take((size_t)4 * d.cout * d.cin);
             P.wp_bwd[i] = take((size_t)4 * d.cin * d.cout);
@@ -235,6 +235,8 @@ int pack_weights(const Plan& P, const float* params, float* ws, bool for_backwar
         }
         J.bf16 = bf16 ? 1 : 0;
         J.amax_slot = S_W + i;
+        // three-piece scheme: 3x3 layers with GEMM N % 64 == 0 get pre-split slabs (N = Cout forward, Cin backward-data)
+        J.x3bn = (!bf16 && g_algo == 1 && d.kind == 0) ? x3_slab_bn(for_backward ? d.cin : d.cout) : 0;
         jobs.job[jobs.n++] = J;
     }
     return launch_pack_all(jobs, params, ws, st, amax);
@@ -621,7 +623,7 @@ extern "C" int eld_adam_step(float* params, const float* grads, float* exp_avg, 
 extern "C" size_t eld_layer_workspace_bytes(int N, int H, int W, int Cin, int Cout) {
     if (N < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return 0;
     const int cinp = (Cin + 15) / 16 * 16;
-    size_t f = (size_t)9 * Cout * cinp + 64;                                // one packed weight set
+    size_t f = (size_t)9 * Cout * cinp * 2 + 64;                            // one packed weight set (fp32 or pre-split slabs)
     size_t p = 0, q;
     if (Cout % 32 == 0) { q = wgrad_geom(CONV_3X3, Cout, Cin, N, H, W).floats; p = q > p ? q : p; }
     if (Cin % 32 == 0) { q = wgrad_geom(CONV_GATHER2X2, Cin, Cout, N, H, W).floats; p = q > p ? q : p; }
@@ -648,7 +650,7 @@ static int layer_ws(void* ws, size_t ws_bytes, int N, int H, int W, int Cin, int
     if (ws_bytes < need) return ELD_EWS;
     const int cinp = (Cin + 15) / 16 * 16;
     *pack = (float*)ws;
-    *part = (float*)ws + align_up((size_t)9 * Cout * cinp + 64, 64);
+    *part = (float*)ws + align_up((size_t)9 * Cout * cinp * 2 + 64, 64);
     return 0;
 }
 
@@ -660,7 +662,7 @@ extern "C" int eld_conv3x3_forward(const float* in0, int C0, const float* in1, i
     float *pack, *part;
     RC(layer_ws(ws, ws_bytes, N, H, W, C0 + C1, Cout, &pack, &part));
     hipStream_t st = as_stream(stream);
-    RC(launch_pack(w, pack, PACK_CONV_FWD, Cout, C0 + C1, C0 + C1, 9, st));
+    RC(launch_pack(w, pack, PACK_CONV_FWD, Cout, C0 + C1, C0 + C1, 9, st, g_algo == 1 ? x3_slab_bn(Cout) : 0));
     float* am;
     RC(layer_amax(ws, eld_layer_workspace_bytes(N, H, W, C0 + C1, Cout), st, in0, (size_t)N * H * W * C0, in1, (size_t)N * H * W * C1, pack, (size_t)9 * Cout * (C0 + C1), &am));
     if (am) { g_am.in0 = am; g_am.in1 = in1 ? am + 1 : nullptr; g_am.w = am + 2; g_am.out0 = am + 3; }
@@ -675,7 +677,7 @@ extern "C" int eld_conv3x3_backward_data(const float* g, const float* w, float* 
     float *pack, *part;
     RC(layer_ws(ws, ws_bytes, N, H, W, Cin, Cout, &pack, &part));
     hipStream_t st = as_stream(stream);
-    RC(launch_pack(w, pack, PACK_CONV_BWD, Cout, Cin, Cin, 9, st));
+    RC(launch_pack(w, pack, PACK_CONV_BWD, Cout, Cin, Cin, 9, st, g_algo == 1 ? x3_slab_bn(Cin) : 0));
     float* am;
     RC(layer_amax(ws, eld_layer_workspace_bytes(N, H, W, Cin, Cout), st, g, (size_t)N * H * W * Cout, nullptr, 0, pack, (size_t)9 * Cout * Cin, &am));
     if (am) { g_am.in0 = am; g_am.w = am + 2; g_am.out0 = am + 3; g_am.out1 = am + 4; }

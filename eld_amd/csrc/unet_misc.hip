@@ -314,17 +314,34 @@ int launch_colsum(const float* x, float* out, float* part, size_t P, int C, hipS
 //   PACK_CONVT_FWD: dst[tap*Cout+co][ci] = src[ci][co][tap]                              src (Cin,Cout,2,2)
 //   PACK_CONVT_BWD: dst[tap][ci][co]     = src[ci][co][tap]
 // ------------------------------------------------------------------------------------------------
-__global__ void pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int kind, int Cout, int Cin, int Cinp, int T) {
+// Pre-split slab layout of conv_x3d_kernel (conv_x3.hip): element (tap t, GEMM column n of N, k-channel c of K) of the logical packed
+// weight B[t][n][c] is cut EXACTLY into its three bf16 pieces (top 16 bits, top 16 bits of the exact remainder, exact rest -- the same
+// cut split_store makes) and stored at   slab(ky, c/16, n/BN) + row(kx, n%BN) * 112 B + piece * 32 B + (c%16) * 2 B.
+__device__ __forceinline__ void x3_store(float* dst, int t, int n, int c, int N, int K, int BN, float v) {
+    const int NCH = K >> 4, NB = N / BN;
+    const int ky = t / 3, kx = t - 3 * ky;
+    const size_t row = ((size_t)((ky * NCH + (c >> 4)) * NB + n / BN) * 3 + kx) * BN + (n % BN);
+    bf16_t* d = reinterpret_cast<bf16_t*>(dst) + row * 56 + (c & 15);
+    const unsigned x = __float_as_uint(v);
+    const float r = v - __uint_as_float(x & 0xFFFF0000u);
+    const unsigned y = __float_as_uint(r);
+    const float q = r - __uint_as_float(y & 0xFFFF0000u);
+    d[0] = (bf16_t)(x >> 16); d[16] = (bf16_t)(y >> 16); d[32] = (bf16_t)(__float_as_uint(q) >> 16);
+}
+
+__global__ void pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int kind, int Cout, int Cin, int Cinp, int T, int x3bn) {
     size_t total;
     if (kind == PACK_CONV_FWD) total = (size_t)T * Cout * Cinp; else total = (size_t)T * Cout * Cin;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     if (kind == PACK_CONV_FWD) {
         const int ci = (int)(i % Cinp); const int co = (int)((i / Cinp) % Cout); const int t = (int)(i / ((size_t)Cinp * Cout));
-        dst[i] = ci < Cin ? src[((size_t)co * Cin + ci) * T + t] : 0.f;
+        const float v = ci < Cin ? src[((size_t)co * Cin + ci) * T + t] : 0.f;
+        if (x3bn) x3_store(dst, t, co, ci, Cout, Cinp, x3bn, v); else dst[i] = v;
     } else if (kind == PACK_CONV_BWD) {
         const int co = (int)(i % Cout); const int ci = (int)((i / Cout) % Cin); const int t = (int)(i / ((size_t)Cout * Cin));
-        dst[i] = src[((size_t)co * Cin + ci) * T + (T - 1 - t)];
+        const float v = src[((size_t)co * Cin + ci) * T + (T - 1 - t)];
+        if (x3bn) x3_store(dst, t, ci, co, Cin, Cout, x3bn, v); else dst[i] = v;
     } else if (kind == PACK_CONVT_FWD) {
         const int ci = (int)(i % Cin); const int co = (int)((i / Cin) % Cout); const int t = (int)(i / ((size_t)Cin * Cout));
         dst[i] = src[((size_t)ci * Cout + co) * T + t];
@@ -334,9 +351,9 @@ __global__ void pack_kernel(const float* __restrict__ src, float* __restrict__ d
     }
 }
 
-int launch_pack(const float* src, float* dst, int kind, int Cout, int Cin, int Cinp, int T, hipStream_t st) {
+int launch_pack(const float* src, float* dst, int kind, int Cout, int Cin, int Cinp, int T, hipStream_t st, int x3bn) {
     const size_t total = (size_t)T * Cout * (kind == PACK_CONV_FWD ? Cinp : Cin);
-    ELD_LAUNCH(pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, dst, kind, Cout, Cin, Cinp, T);
+    ELD_LAUNCH(pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, dst, kind, Cout, Cin, Cinp, T, x3bn);
     ELD_LAUNCH_CHECK();
     return 0;
 }
@@ -390,6 +407,8 @@ __global__ void pack_all_kernel(const PackJobs jobs, const float* __restrict__ p
     }
     if (live) {
         if (J.bf16) reinterpret_cast<bf16_t*>(dst)[i] = f2bf(v);
+        else if (J.x3bn && J.kind == PACK_CONV_FWD) x3_store(dst, (int)(i / ((size_t)Cinp * Cout)), (int)((i / Cinp) % Cout), (int)(i % Cinp), Cout, Cinp, J.x3bn, v);
+        else if (J.x3bn && J.kind == PACK_CONV_BWD) x3_store(dst, (int)(i / ((size_t)Cout * Cin)), (int)((i / Cout) % Cin), (int)(i % Cout), Cin, Cout, J.x3bn, v);
         else dst[i] = v;
     }
     if (amax) amax_accumulate(amax + J.amax_slot, v);          // per-layer weight bound (all lanes take part)
