@@ -57,13 +57,26 @@ int choose_psplit(int groups, int ntiles) {
     return ps;
 }
 
-struct WgradGeom { int T, CA, CBp, groups, ntiles, psplit; size_t floats; };
+struct WgradGeom { int T, CA, CBp, groups, ntiles, psplit, w8; size_t floats; };
 
-WgradGeom wgrad_geom(int mode, int CA, int CB, int N, int H, int W) {
+// algo: the fp32 product scheme of the call (the three-piece scheme re-blocks 3x3 layers for wgrad8_kernel: one 8-wave workgroup per CU)
+WgradGeom wgrad_geom(int mode, int CA, int CB, int N, int H, int W, int algo) {
     WgradGeom g;
     g.T = mode == CONV_3X3 ? 9 : 4;
     g.CA = CA;
     g.CBp = (CB + 31) / 32 * 32;
+    g.w8 = 0;
+    int cob8, jb8, th8;
+    if (algo == 1 && mode == CONV_3X3 && CB % 32 == 0 && wgrad8_shape(CA, g.CBp, cob8, jb8, th8)) {
+        g.w8 = 1;
+        g.groups = (CA / cob8) * (g.CBp / jb8);
+        g.ntiles = ((W + 31) / 32) * ((H + th8 - 1) / th8) * N;
+        int ps = 256 / g.groups;
+        if (ps > g.ntiles) ps = g.ntiles;
+        g.psplit = ps < 1 ? 1 : ps;
+        g.floats = (size_t)g.psplit * ((size_t)g.T * CA * g.CBp + CA);
+        return g;
+    }
     const int COB = (CA % 64 == 0) ? 64 : 32;
     const int TH = mode == CONV_3X3 ? 4 : 2;
     g.groups = (CA / COB) * (g.CBp / 32);
@@ -106,11 +119,12 @@ int conv_bwd_data(const float* g, const float* wb, float* out0, float* out1, int
 
 int conv_wgrad(const float* g, int Cout, const float* x0, int C0, const float* x1, int C1, int Cin_real, float* dw, float* db, float* part,
                int N, int H, int W, hipStream_t st) {
-    const WgradGeom q = wgrad_geom(CONV_3X3, Cout, C0 + C1, N, H, W);
+    const WgradGeom q = wgrad_geom(CONV_3X3, Cout, C0 + C1, N, H, W, (C0 % 32 || C1 % 32) ? 0 : g_algo);
     WgradArgs a = {};
     a.g = g; a.CA = Cout; a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.N = N; a.H = H; a.W = W;
     a.part = part; a.bpart = db ? part + (size_t)q.psplit * q.T * q.CA * q.CBp : nullptr; a.CBp = q.CBp; a.psplit = q.psplit;
     take_amax(a);
+    a.wgrad8 = q.w8;
     int rc = launch_wgrad(a, CONV_3X3, st);
     if (rc) return rc;
     return launch_wgrad_reduce(part, a.bpart, dw, db, q.psplit, q.T, q.CA, q.CBp, Cin_real, st);
@@ -136,7 +150,7 @@ int convt_bwd_data(const float* dout, const float* wb, const float* act, float* 
 
 // dw[ci][co][tap] = sum in[p][ci] * dout[gather(p,tap)][co];  db[co] = column sums of dout
 int convt_wgrad(const float* in, const float* dout, float* dw, float* db, float* part, int N, int H, int W, int Cin, int Cout, hipStream_t st) {
-    const WgradGeom q = wgrad_geom(CONV_GATHER2X2, Cin, Cout, N, H, W);
+    const WgradGeom q = wgrad_geom(CONV_GATHER2X2, Cin, Cout, N, H, W, 0);
     WgradArgs a = {};
     a.g = in; a.CA = Cin; a.x0 = dout; a.C0 = Cout; a.N = N; a.H = H; a.W = W;
     a.part = part; a.bpart = nullptr; a.CBp = q.CBp; a.psplit = q.psplit;
@@ -204,8 +218,11 @@ int make_plan(Plan& P, int N, int H, int W, int in_ch, int out_ch) {
         int lev;
         if (i <= L_E4B) lev = i / 2; else if (i < L_HEAD) lev = 3 - (i - L_UP3) / 3; else lev = 0;
         size_t f = 0;
-        if (d.kind == 0) f = wgrad_geom(CONV_3X3, d.cout, i == L_E0A ? 16 : d.cin, N, P.Hl[lev], P.Wl[lev]).floats;
-        else if (d.kind == 1) f = wgrad_geom(CONV_GATHER2X2, d.cin, d.cout, N, P.Hl[lev + 1], P.Wl[lev + 1]).floats;
+        if (d.kind == 0) {
+            f = wgrad_geom(CONV_3X3, d.cout, i == L_E0A ? 16 : d.cin, N, P.Hl[lev], P.Wl[lev], 0).floats;
+            const size_t f1 = wgrad_geom(CONV_3X3, d.cout, i == L_E0A ? 16 : d.cin, N, P.Hl[lev], P.Wl[lev], 1).floats;
+            f = f1 > f ? f1 : f;
+        } else if (d.kind == 1) f = wgrad_geom(CONV_GATHER2X2, d.cin, d.cout, N, P.Hl[lev + 1], P.Wl[lev + 1], 0).floats;
         pmax = f > pmax ? f : pmax;
     }
     P.part = take(pmax);
@@ -447,7 +464,7 @@ int conv_bwd_data_bf16(const bf16_t* g, const bf16_t* wb, bf16_t* out0, bf16_t* 
 
 int conv_wgrad_bf16(const bf16_t* g, int Cout, const bf16_t* x0, int C0, const bf16_t* x1, int C1, float* dw, float* db, float* part,
                     int N, int H, int W, hipStream_t st) {
-    const WgradGeom q = wgrad_geom(CONV_3X3, Cout, C0 + C1, N, H, W);
+    const WgradGeom q = wgrad_geom(CONV_3X3, Cout, C0 + C1, N, H, W, 0);
     WgradArgs a = {};
     a.g = g; a.CA = Cout; a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.N = N; a.H = H; a.W = W; a.dtype = DT_BF16;
     a.part = part; a.bpart = db ? part + (size_t)q.psplit * q.T * q.CA * q.CBp : nullptr; a.CBp = q.CBp; a.psplit = q.psplit;
@@ -479,7 +496,7 @@ int unet_backward_bf16(const Plan& P, const float* dout, const float* prm, float
         const bf16_t* src = l == 3 ? B(P.eb[4]) : B(P.db[l + 1]);
         {   // transposed conv: weight gradient (gather mode), bias gradient (column sums of d_up), backward data
             const int Hi = P.Hl[l + 1], Wi = P.Wl[l + 1];
-            const WgradGeom q = wgrad_geom(CONV_GATHER2X2, 2 * C, C, N, Hi, Wi);
+            const WgradGeom q = wgrad_geom(CONV_GATHER2X2, 2 * C, C, N, Hi, Wi, 0);
             WgradArgs a = {};
             a.g = src; a.CA = 2 * C; a.x0 = cur; a.C0 = C; a.N = N; a.H = Hi; a.W = Wi; a.dtype = DT_BF16;
             a.part = part; a.bpart = nullptr; a.CBp = q.CBp; a.psplit = q.psplit;
@@ -625,8 +642,8 @@ extern "C" size_t eld_layer_workspace_bytes(int N, int H, int W, int Cin, int Co
     const int cinp = (Cin + 15) / 16 * 16;
     size_t f = (size_t)9 * Cout * cinp * 2 + 64;                            // one packed weight set (fp32 or pre-split slabs)
     size_t p = 0, q;
-    if (Cout % 32 == 0) { q = wgrad_geom(CONV_3X3, Cout, Cin, N, H, W).floats; p = q > p ? q : p; }
-    if (Cin % 32 == 0) { q = wgrad_geom(CONV_GATHER2X2, Cin, Cout, N, H, W).floats; p = q > p ? q : p; }
+    if (Cout % 32 == 0) { q = wgrad_geom(CONV_3X3, Cout, Cin, N, H, W, 0).floats; p = q > p ? q : p; q = wgrad_geom(CONV_3X3, Cout, Cin, N, H, W, 1).floats; p = q > p ? q : p; }
+    if (Cin % 32 == 0) { q = wgrad_geom(CONV_GATHER2X2, Cin, Cout, N, H, W, 0).floats; p = q > p ? q : p; }
     q = colsum_ws_floats(Cout > Cin ? Cout : Cin); p = q > p ? q : p;
     return (align_up(f, 64) + align_up(p, 64) + 64) * sizeof(float);      // + 64 operand-bound slots (conv_fp32_algo 2)
 }
