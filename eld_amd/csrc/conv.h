@@ -92,7 +92,7 @@ int launch_conv_x3(const ConvArgs& a, hipStream_t st);
 // conv_x3d_kernel (conv_x3.hip); returns the slab's channel-block width BN (64 or 128), or 0 for layers that keep fp32 packed weights
 int x3_slab_bn(int Nout);
 // bytes of one packed layer in slab layout: 9 taps x Nout x K/16 rows of 112 B
-inline size_t x3_slab_bytes(int Nout, int K) { return (size_t)9 * Nout * ((K + 15) / 16) * 112; }
+__host__ __device__ inline size_t x3_slab_stride(int BN) { return (size_t)(3 * BN * 112 + 1023) / 1024 * 1024; }      // bytes of one (ky, chunk, channel-block) slab
 void conv_x3_set_prof(unsigned long long* buf);      // dev tool: 8 workgroups x 4 waves x 128 stages x 6 stamps
 int launch_conv_x3_gemm(const ConvArgs& a, int mode, hipStream_t st);      // transposed-conv directions; ELD_ENOTSUP if not covered
 

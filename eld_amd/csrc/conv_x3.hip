@@ -320,12 +320,12 @@ __device__ __forceinline__ void bdma16(i32x4 rsrc, unsigned voff, unsigned soff,
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <int BN, int RPW, int WAVES, bool DB>
-__global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN == 64) ? 2 : (WAVES == 8 ? 2 : 1)) void conv_x3d_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES == 8 ? 2 : 1)) void conv_x3d_kernel(const ConvArgs a) {
     constexpr int CK = 16, THREADS = 64 * WAVES;
     constexpr int TH = WAVES * RPW, NT = BN / 32, A_PIX = (TH + 2) * (TW + 2);
-    constexpr int A_WORDS = A_PIX * PX, B_ROWS = 3 * BN, B_WORDS = B_ROWS * PX;
+    constexpr int A_WORDS = A_PIX * PX, B_ROWS = 3 * BN;
+    constexpr int B_WORDS = (B_ROWS * PX * 4 + 1023) / 1024 * 256;     // slab stride (global and LDS): rows padded to whole 1 KiB DMA pieces
     constexpr int B_PIECES = B_WORDS * 4 / 1024;                      // 1 KiB per wave-instruction
-    static_assert(B_WORDS * 4 % 1024 == 0, "slab must be a whole number of 1 KiB DMA pieces");
     constexpr int DMA_IT = (B_PIECES + WAVES - 1) / WAVES;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* ldsB = lds;                                                // two slabs first: the DMA destinations stay at low LDS addresses
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN == 64) ? 2 : (WAVES =
     int l_img = 0;
     const unsigned ldsB_addr = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(__attribute__((address_space(3))) float*)ldsB);
     const unsigned long long wbase = (unsigned long long)a.wp;
-    const i32x4 rsrc_w = {(int)(unsigned)wbase, (int)((unsigned)(wbase >> 32) & 0xFFFFu), (int)((size_t)9 * a.Nout * NCH * 112), 0x00020000};
+    const i32x4 rsrc_w = {(int)(unsigned)wbase, (int)((unsigned)(wbase >> 32) & 0xFFFFu), (int)((size_t)3 * NCH * NB * B_WORDS * 4), 0x00020000};
     const unsigned dma_voff = (unsigned)lane * 16u;
 
     auto decode = [&](int t, int& nb, int& img, int& y0, int& x0) {
@@ -770,7 +770,7 @@ int launch_x3d(ConvArgs a, hipStream_t st) {
     constexpr int TH = WAVES * RPW;
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + TH - 1) / TH;
-    const size_t lds_bytes = (size_t)((TH + 2) * (TW + 2) + 2 * 3 * BN) * PX * sizeof(float);
+    const size_t lds_bytes = (size_t)(TH + 2) * (TW + 2) * PX * sizeof(float) + 2 * (size_t)((3 * BN * PX * 4 + 1023) / 1024 * 1024);
     const long long tiles = (long long)a.tiles_x * a.tiles_y * a.N * (a.Nout / BN);
     if (tiles <= 0) return 0;
     if (tiles > 0x7fffffffLL) return ELD_ENOTSUP;
@@ -809,15 +809,13 @@ int launch_x3_gemm(ConvArgs a, hipStream_t st) {
 
 void conv_x3_set_prof(unsigned long long*) {}       // the s_memtime stage profiler of round 1 is gone with the kernel it instrumented
 
-static int x3d_variant() {                       // dev knob (read once): ELD_X3D_VARIANT = 0 | 1 | 2, see launch_conv_x3
-    static int variant = -1;
-    if (variant < 0) { const char* e = getenv("ELD_X3D_VARIANT"); variant = e ? atoi(e) : 2; }
-    return variant;
-}
-
+// Tile shapes of the LDS-DMA kernel (measured, profiles/r02_*): 16-row tiles with ONE 8-wave workgroup per CU; 128 output channels per
+// tile where the layer has them (half the halo cuts per MFMA), else 64.  Layers with 32 output channels stay on the register-staged
+// conv_x3_kernel<32, 4> with two workgroups per CU: their K loop is 2-4 chunks long and a lone workgroup cannot hide its epilogue
+// (DMA variants with 32-channel slabs measured 0-2 % slower).
 int x3_slab_bn(int Nout) {
     if (Nout % 64) return 0;
-    return (x3d_variant() >= 1 && Nout % 128 == 0) ? 128 : 64;
+    return Nout % 128 == 0 ? 128 : 64;
 }
 
 // a: fp32 CONV_3X3 arguments already validated by launch_conv
@@ -825,14 +823,8 @@ int launch_conv_x3(const ConvArgs& a_in, hipStream_t st) {
     ConvArgs a = a_in;
     a.prof = nullptr;
     if ((size_t)a.H * a.W * a.C0 * 4 >= 0xFFFFFFF0ull) return ELD_ENOTSUP;
-    if (a.Nout % 64 == 0) {                      // weights pre-split in slab layout (x3_slab_bn): LDS-DMA kernel
-        // ELD_X3D_VARIANT: 0 = 64 channels x 8 rows, 2 WG/CU; 1 = 128-channel tiles, 4 waves, 1 WG/CU; 2 = 128-channel tiles x 16 rows, 8 waves
-        if (x3_slab_bn(a.Nout) == 128) {
-            if (x3d_variant() == 2) return launch_x3d<128, 2, 8, false>(a, st);
-            return launch_x3d<128, 2, 4, true>(a, st);
-        }
-        return launch_x3d<64, 2, 4, true>(a, st);
-    }
+    if (x3_slab_bn(a.Nout) == 128) return launch_x3d<128, 2, 8, false>(a, st);      // weights pre-split in slab layout: LDS-DMA kernel
+    if (x3_slab_bn(a.Nout) == 64) return launch_x3d<64, 2, 8, false>(a, st);
     return launch_x3<32, 4, false>(a, st);
 }
 

@@ -320,8 +320,8 @@ int launch_colsum(const float* x, float* out, float* part, size_t P, int C, hipS
 __device__ __forceinline__ void x3_store(float* dst, int t, int n, int c, int N, int K, int BN, float v) {
     const int NCH = K >> 4, NB = N / BN;
     const int ky = t / 3, kx = t - 3 * ky;
-    const size_t row = ((size_t)((ky * NCH + (c >> 4)) * NB + n / BN) * 3 + kx) * BN + (n % BN);
-    bf16_t* d = reinterpret_cast<bf16_t*>(dst) + row * 56 + (c & 15);
+    const size_t slab = (size_t)(ky * NCH + (c >> 4)) * NB + n / BN;
+    bf16_t* d = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(dst) + slab * x3_slab_stride(BN)) + (size_t)(kx * BN + (n % BN)) * 56 + (c & 15);
     const unsigned x = __float_as_uint(v);
     const float r = v - __uint_as_float(x & 0xFFFF0000u);
     const unsigned y = __float_as_uint(r);
