@@ -35,6 +35,7 @@ SIGNATURES = {
     'eld_philox_words': (_i, [_vp, _u32, _u32, _u64, _u32, _u32, _u64, _vp]),
     'eld_pack_bayer': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'eld_unpack_bayer': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'eld_pack_raw_bayer_u16': (_i, [_vp, _vp, _i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_float), _f, _vp]),
     'eld_augment': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _u32, _vp]),
     'eld_unet_param_offsets': (_i, [_i, _i, _vp]),
     'eld_unet_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),

@@ -152,8 +152,10 @@ __global__ __launch_bounds__(256) void illum_scale_kernel(const float* __restric
 // ---- raw -> sRGB ISP: util/process.py:52-68 `process`, one pass: 16 B read + 12 B written per RGBG position.
 //      gains (15-19) -> clamp -> binning R, (G1+G2)/2, B (42-49) -> 3x3 CCM with j ascending (22-31) -> clamp -> gamma
 //      compression max(x,1e-8)^(1/gamma) (34-39) or piecewise-linear camera response (71-83) -> truncating 8-bit quantiser.
-//      The power is evaluated in double and rounded once (the correctly rounded float result): the reference's vectorised
-//      powf is within 1 ulp of it, which the truncating quantiser can turn into a +-1 code difference on isolated pixels.
+//      gamma == 2.2 (the only value the reference passes): power + quantiser are ONE exact step function of the clamped input,
+//      tabulated from torch's own float32 evaluation over every float32 in [0, 1] (gamma22_table.h, oracle/gen_gamma_table.py):
+//      bit-exact 8-bit codes.  Other gammas: the power in double, rounded once (then +-1 code on isolated pixels is possible).
+#include "gamma22_table.h"
 __device__ __forceinline__ float isp_quant(float v) {
     int q = (int)(v * 255.0f);                                     // .int(): truncation toward zero
     q = q < 0 ? 0 : (q > 255 ? 255 : q);
@@ -162,7 +164,10 @@ __device__ __forceinline__ float isp_quant(float v) {
 
 __global__ __launch_bounds__(256) void isp_kernel(const float* __restrict__ bayer, const float* __restrict__ wbs, const float* __restrict__ ccms,
                                                   float* __restrict__ out, size_t hw, float inv_gamma, const float* __restrict__ crf_E,
-                                                  const float* __restrict__ crf_f, int crf_n) {
+                                                  const float* __restrict__ crf_f, int crf_n, int gtab) {
+    __shared__ unsigned s_t[256];
+    if (gtab) s_t[threadIdx.x] = ELD_GAMMA22_T[threadIdx.x];
+    __syncthreads();
     const int n = blockIdx.y;
     const float* wb = wbs + 4 * n;
     const float* cm = ccms + 9 * n;
@@ -191,6 +196,15 @@ __global__ __launch_bounds__(256) void isp_kernel(const float* __restrict__ baye
                 ind = ind < 0 ? 0 : (ind > crf_n - 2 ? crf_n - 2 : ind);
                 const float slope = (crf_f[ind + 1] - crf_f[ind]) / (crf_E[ind + 1] - crf_E[ind]);
                 o = crf_f[ind] + slope * (v - crf_E[ind]);
+            } else if (gtab) {                                      // exact: code = #{c : bits(max(v,1e-8)) >= T[c]}, found from a hardware-pow guess
+                const float vm = fmaxf(v, 1e-8f);
+                const unsigned vb = __float_as_uint(vm);
+                int q = (int)(__builtin_amdgcn_exp2f(__builtin_amdgcn_logf(vm) * inv_gamma) * 255.0f);
+                q = q < 0 ? 0 : (q > 255 ? 255 : q);
+                while (q < 255 && vb >= s_t[q + 1]) ++q;
+                while (q > 0 && vb < s_t[q]) --q;
+                dst[c * hw + i] = (float)q / 255.0f;
+                continue;
             } else {
                 o = (float)pow((double)fmaxf(v, 1e-8f), ig);
             }
@@ -253,7 +267,8 @@ extern "C" int eld_isp_process(const float* bayer, const float* wbs, const float
     if (crf_n != 0 && (crf_n < 2 || !crf_E || !crf_f)) return ELD_EINVAL;
     const size_t hw = (size_t)H * W;
     const unsigned bx = (unsigned)((hw + 255) / 256 < 2048 ? (hw + 255) / 256 : 2048);
-    ELD_LAUNCH(isp_kernel, dim3(bx, N), dim3(256), 0, as_stream(stream), bayer, wbs, ccms, out, hw, (float)(1.0 / (double)gamma), crf_E, crf_f, crf_n);
+    const int gtab = (crf_n == 0 && gamma == 2.2f) ? 1 : 0;
+    ELD_LAUNCH(isp_kernel, dim3(bx, N), dim3(256), 0, as_stream(stream), bayer, wbs, ccms, out, hw, (float)(1.0 / (double)gamma), crf_E, crf_f, crf_n, gtab);
     ELD_LAUNCH_CHECK();
     return 0;
 }

@@ -588,6 +588,64 @@ extern "C" int eld_unpack_bayer(const float* packed, float* mosaic, int N, int h
 }
 
 // ---------------------------------------------------------------------------------------------
+// Sensor mosaic -> packed, normalised raw (pack_raw_bayer, dataset/sid_dataset.py:172-196), one pass:
+//   out[k][y][x] = clip((float(im[2y+oy_k][2x+ox_k]) - black[k]) / (white - black[k]), 0, 1),  k = R, G1, B, G2 = raw_pattern codes 0..3
+// float32 throughout as NumPy evaluates it (uint16 -> float32 exact, one rounding per op, true division).  2 B read + 4 B written
+// per sensor pixel.  A lane handles two horizontally adjacent packed positions of all four channels: one 8-byte read per mosaic row.
+// ---------------------------------------------------------------------------------------------
+struct PackRawArgs { int oy[4], ox[4]; float black[4], denom[4]; };
+
+__global__ __launch_bounds__(256) void pack_raw_kernel(const uint16_t* __restrict__ im, float* __restrict__ out, int h, int w, PackRawArgs p) {
+    const int n = blockIdx.y;
+    const size_t hw = (size_t)h * w, W2 = 2 * (size_t)w;
+    const uint16_t* src = im + (size_t)n * 4 * hw;
+    float* dst = out + (size_t)n * 4 * hw;
+    const int wp = (w + 1) / 2;                                     // position pairs per packed row
+    const size_t total = (size_t)h * wp;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int y = (int)(i / wp), x = 2 * (int)(i - (size_t)y * wp);
+        const bool two = x + 1 < w;
+        uint16_t q[2][4];                                           // q[row][col] of the 2 x 4 mosaic block
+        const uint16_t* r0 = src + (size_t)(2 * y) * W2 + 2 * x;
+        if (two && ((W2 & 3) == 0)) {
+            const ushort4 a = *reinterpret_cast<const ushort4*>(r0), b = *reinterpret_cast<const ushort4*>(r0 + W2);
+            q[0][0] = a.x; q[0][1] = a.y; q[0][2] = a.z; q[0][3] = a.w; q[1][0] = b.x; q[1][1] = b.y; q[1][2] = b.z; q[1][3] = b.w;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const bool ok = c < 2 || two; q[0][c] = ok ? r0[c] : 0; q[1][c] = ok ? r0[W2 + c] : 0; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float v0 = ((float)q[p.oy[k]][p.ox[k]] - p.black[k]) / p.denom[k];
+            const float v1 = ((float)q[p.oy[k]][2 + p.ox[k]] - p.black[k]) / p.denom[k];
+            float* o = dst + (size_t)k * hw + (size_t)y * w + x;
+            o[0] = fminf(fmaxf(v0, 0.f), 1.f);
+            if (two) o[1] = fminf(fmaxf(v1, 0.f), 1.f);
+        }
+    }
+}
+
+extern "C" int eld_pack_raw_bayer_u16(const uint16_t* mosaic, float* packed, int N, int h, int w, const int* raw_pattern, const float* black_level,
+                                      float white_point, void* stream) {
+    if (N < 0 || h < 0 || w < 0 || !raw_pattern || !black_level) return ELD_EINVAL;
+    if (N == 0 || h == 0 || w == 0) return 0;
+    if (!mosaic || !packed) return ELD_EINVAL;
+    PackRawArgs p;
+    bool seen[4] = {false, false, false, false};
+    for (int i = 0; i < 4; ++i) {                                    // np.where(raw_pattern == k): position of colour code k in the 2x2 cell
+        const int k = raw_pattern[i];
+        if (k < 0 || k > 3 || seen[k]) return ELD_EINVAL;
+        seen[k] = true; p.oy[k] = i >> 1; p.ox[k] = i & 1;
+    }
+    for (int k = 0; k < 4; ++k) { p.black[k] = black_level[k]; p.denom[k] = white_point - black_level[k]; }
+    const size_t total = (size_t)h * ((w + 1) / 2);
+    dim3 grid((unsigned)min((total + 255) / 256, (size_t)4096), N);
+    ELD_LAUNCH(pack_raw_kernel, grid, dim3(256), 0, as_stream(stream), mosaic, packed, h, w, p);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Augmentation (sid_dataset.py:344-352): out = transpose?(flipW?(flipH?(x))) per image, optional clip (:354).
 //   no transpose: out[c][i][j] = x[c][fh(i)][fw(j)]      transpose: out[c][i][j] = x[c][fh(j)][fw(i)]
 // ---------------------------------------------------------------------------------------------

@@ -64,10 +64,10 @@ class LMDBDataset(tdata.Dataset):
 
 class Deferred(object):
     """A noisy sample whose pixels do not exist yet: the clean data, the parameter record of its noise and the burst count."""
-    __slots__ = ('clean', 'params', 'burst')
+    __slots__ = ('clean', 'params', 'burst', 'isp')
 
-    def __init__(self, clean, params, burst):
-        self.clean, self.params, self.burst = clean, params, burst
+    def __init__(self, clean, params, burst, isp=None):
+        self.clean, self.params, self.burst, self.isp = clean, params, burst, isp      # isp: (wb[4], ccm[3,3]) -> raw2rgb after the noise
 
 
 class SynDataset(tdata.Dataset):
@@ -94,6 +94,29 @@ class SynDataset(tdata.Dataset):
     def __len__(self):
         size = self.size or len(self.dataset)
         return int(size * self.repeat)
+
+
+class ISPDataset(tdata.Dataset):
+    """dataset/sid_dataset.py:287-319 (the --stage_in srgb input, train_syn.py:55-58): noise on the raw patch, clip, raw -> sRGB
+    with the patch's white balance and colour matrix (meta_info[i] = (wb, ccm), util/process.py:107-112), clip.  Deferred like
+    SynDataset: the worker draws the parameters, the device runs sampler + ISP (eld_amd.isp.process)."""
+
+    def __init__(self, dataset, noise_maker=None, cfa='bayer', meta_info=None, CRF=None):
+        super(ISPDataset, self).__init__()
+        self.dataset = dataset
+        self.noise_maker = noise_maker
+        self.cfa = cfa
+        self.meta_info = dataset.meta if meta_info is None else meta_info
+        self.CRF = CRF
+
+    def __getitem__(self, i):
+        data = self.dataset[i]
+        wb, ccm = self.meta_info[i]
+        params = NoiseParams.coerce(self.noise_maker._sample_params()) if self.noise_maker is not None else None
+        return Deferred(data, params, 1, isp=(np.asarray(wb, np.float32).reshape(4), np.asarray(ccm, np.float32).reshape(3, 3)))
+
+    def __len__(self):
+        return len(self.dataset)
 
 
 def _as_wire(x):
@@ -124,8 +147,13 @@ class ELDTrainDataset(tdata.Dataset):
                 if np.random.randint(2, size=1)[0] == 1:
                     bits |= b
         if isinstance(inp, Deferred):
-            dic = {'target': _as_wire(target), 'params': inp.params.record(0).reshape(1).view(np.uint8).copy(),
-                   'aug': bits, 'burst': inp.burst}
+            if inp.isp is not None:                          # sRGB input stage: the raw patch to degrade travels beside the sRGB target
+                dic = {'clean': _as_wire(inp.clean), 'target': _as_wire(target), 'wb': inp.isp[0], 'ccm': inp.isp[1], 'aug': bits, 'burst': 1}
+                if inp.params is not None:
+                    dic['params'] = inp.params.record(0).reshape(1).view(np.uint8).copy()
+            else:
+                dic = {'target': _as_wire(target), 'params': inp.params.record(0).reshape(1).view(np.uint8).copy(),
+                       'aug': bits, 'burst': inp.burst}
         else:                                                # pre-synthesised input (offline-noise LMDB): the reference's host path
             if getattr(inp, 'dtype', None) == np.uint16:
                 inp = np.clip(inp / 65535, 0, 1).astype(np.float32)

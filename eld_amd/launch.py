@@ -123,6 +123,7 @@ def install_plugins(which, online_noise=None, num_burst=1):
                 return super().__new__(cls)
         ref_lmdb.LMDBDataset = _LMDBDataset
         ref_sid.SynDataset = D.SynDataset
+        ref_sid.ISPDataset = D.ISPDataset                     # --stage_in srgb (train_syn.py:55-58)
         ref_sid.ELDTrainDataset = D.ELDTrainDataset
         ref_sid.worker_init_fn = D.worker_init_fn
     if 'arch' in which or 'model' in which:

@@ -98,11 +98,15 @@ class ELDModel:
             raise RuntimeError('eld_amd.model.ELDModel needs a GPU (gpu_ids=%r): there is no CPU fallback' % (self.gpu_ids,))
         self.device = torch.device('cuda', self.gpu_ids[0] if isinstance(self.gpu_ids, (list, tuple)) else int(self.gpu_ids))
         torch.cuda.set_device(self.device)
-        if getattr(opt, 'stage_in', 'raw') != 'raw' or getattr(opt, 'stage_out', 'raw') != 'raw':
-            raise NotImplementedError('sRGB stages are outside the MI355X hot path (raw->raw only)')
+        self.stage_in, self.stage_out = getattr(opt, 'stage_in', 'raw'), getattr(opt, 'stage_out', 'raw')
+        for st in (self.stage_in, self.stage_out):           # ELD_model.py:377-389
+            if st not in ('raw', 'srgb'):
+                raise NotImplementedError('Invalid Stage: {}'.format(st))
         ch = getattr(opt, 'channels', 4)
-        cin = getattr(opt, 'in_channels', None) or ch        # burst input (sid_dataset.py:267-273): num_burst * channels planes in
-        self.netG = ARCH[getattr(opt, 'netG', 'unet')](cin, ch).to(self.device)
+        cin = 3 if self.stage_in == 'srgb' else (getattr(opt, 'in_channels', None) or ch)      # burst input (sid_dataset.py:267-273): num_burst * channels planes in
+        cout = 3 if self.stage_out == 'srgb' else ch
+        self.CRF = getattr(opt, 'crf_tables', None)          # (E, fs) of process.load_CRF (EMoR tables are outside this package); None = gamma 2.2
+        self.netG = ARCH[getattr(opt, 'netG', 'unet')](cin, cout).to(self.device)
         prec = getattr(opt, 'precision', os.environ.get('ELD_AMD_PRECISION', 'fp32'))      # 'bf16' = BASELINE config 3
         self.netG.train_precision = self.netG.inference_precision = prec
         self.world, self.rank = D.world_size(), D.rank()
@@ -152,6 +156,15 @@ class ELDModel:
             inp = inp.to(device=self.device, non_blocking=True)
             if target is not None and target.element_size() == 2:
                 target = decode_augment_u16(target)
+        elif mode == 'train' and data.get('wb') is not None:
+            # --stage_in srgb (ISPDataset.__getitem__, sid_dataset.py:301-316): noise on the raw patch, clip, raw -> sRGB, clip
+            clean = data['clean'].to(device=self.device, non_blocking=True)
+            if data.get('params') is not None:
+                inp = self.synthesize(clean, data.get('params'), data.get('sample_ids'))
+            else:
+                inp = decode_augment_u16(clean) if clean.element_size() == 2 else clean.float().clamp(0, 1)
+            from .isp import process
+            inp = process(inp, data['wb'], data['ccm'], CRF=self.CRF)          # quantised to k/255 in [0,1]: the second clip is the identity
         elif mode == 'train':
             if target is None:
                 raise KeyError('target')

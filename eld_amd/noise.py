@@ -254,6 +254,30 @@ class RawPacker:
         raise NotImplementedError
 
 
+def pack_raw_bayer(raw_image_visible, raw_pattern, black_level_per_channel, white_point=16383):
+    """dataset/sid_dataset.py:172-196 on the device: uint16 sensor mosaic (2h,2w) or (N,2h,2w) [ndarray or CUDA int16/uint16
+    tensor] -> packed, black-level-normalised float32 (4,h,w) / (N,4,h,w) in R, G1, B, G2 order.  Takes what the reference
+    reads off a rawpy object: raw.raw_image_visible, raw.raw_pattern, raw.black_level_per_channel."""
+    import ctypes
+    import torch
+    as_np = isinstance(raw_image_visible, np.ndarray)
+    t = torch.from_numpy(np.ascontiguousarray(raw_image_visible, dtype=np.uint16).view(np.int16)).cuda() if as_np else raw_image_visible.contiguous()
+    assert t.is_cuda and t.element_size() == 2
+    single = t.dim() == 2
+    if single:
+        t = t.unsqueeze(0)
+    N, H2, W2 = t.shape
+    if H2 % 2 or W2 % 2:
+        raise ValueError('mosaic sides must be even, got %dx%d' % (H2, W2))
+    out = torch.empty((N, 4, H2 // 2, W2 // 2), dtype=torch.float32, device=t.device)
+    pat = (ctypes.c_int * 4)(*[int(v) for v in np.asarray(raw_pattern).reshape(-1)])
+    blk = (ctypes.c_float * 4)(*[float(np.float32(v)) for v in black_level_per_channel])
+    L.check(L.lib().eld_pack_raw_bayer_u16(L.dptr(t), L.dptr(out), N, H2 // 2, W2 // 2, pat, blk, float(white_point), L.cur_stream()), 'eld_pack_raw_bayer_u16')
+    if single:
+        out = out[0]
+    return out.cpu().numpy() if as_np else out
+
+
 class NoiseModelBase:  # same name / role as noise.py:148
     seed = int(os.environ.get('ELD_AMD_SEED', '2018'))      # Philox key (reference --seed default, base_option.py:22)
     sample_base = 0                                         # first global sample index handed out by this instance

@@ -109,6 +109,12 @@ int eld_philox_words(uint32_t* out, uint32_t n, uint32_t index0, uint64_t sample
  * batched: mosaic float32 [N,2h,2w] <-> packed float32 [N,4,h,w]. */
 int eld_pack_bayer(const float* mosaic, float* packed, int N, int h, int w, void* stream);
 int eld_unpack_bayer(const float* packed, float* mosaic, int N, int h, int w, void* stream);
+/* pack_raw_bayer (dataset/sid_dataset.py:172-196): uint16 sensor mosaic [N,2h,2w] (raw.raw_image_visible) -> packed float32
+ * [N,4,h,w] in the order R, G1, B, G2 given by the 2x2 `raw_pattern` (row-major colour codes 0..3, HOST array of 4 ints),
+ * normalised per channel: clip((x - black_level[k]) / (white_point - black_level[k]), 0, 1), float32 arithmetic as NumPy's
+ * (black_level: HOST array of 4 floats = raw.black_level_per_channel; white_point 16383 in the reference).  Bit-exact. */
+int eld_pack_raw_bayer_u16(const uint16_t* mosaic, float* packed, int N, int h, int w, const int* raw_pattern,
+                           const float* black_level, float white_point, void* stream);
 
 
 /* Training-pair augmentation of ELDTrainDataset.__getitem__ (dataset/sid_dataset.py:344-352), batched on device:

@@ -33,11 +33,23 @@ def quantise(x):                                               # clamp((x*255).i
     return q.astype(np.float32) / np.float32(255)
 
 
+_T22 = None
+
+
 def gamma_compression(images, gamma=2.2):                      # process.py:34-39
-    # torch evaluates x ** (1/gamma) on float32 tensors with the exponent rounded to float32 and a <= 1 ulp vectorised powf;
-    # NumPy's float32 power is several ulp off on ~18 % of inputs, so the power is taken in float64 and rounded once
-    # (agrees with torch on 99 % of values and on every 8-bit code of the fixtures and of a 2x3x356x532 frame).
-    outs = np.power(np.maximum(images, np.float32(1e-8)).astype(np.float64), np.float64(np.float32(1.0 / gamma))).astype(np.float32)
+    """clamp((clamp(x, 1e-8) ** (1/gamma) * 255).int(), 0, 255) / 255 as torch evaluates it on float32 tensors.  For gamma = 2.2
+    (the only value the reference uses) that composition is a monotone step function of x with 255 thresholds, minted
+    exhaustively from torch itself by oracle/gen_gamma_table.py (tests/golden/gamma22_thresholds.npy): exact codes.  Other
+    gammas: the power in float64, rounded once (torch's vectorised powf is within 1 ulp of that)."""
+    global _T22
+    x = np.maximum(images, np.float32(1e-8)).astype(np.float32)
+    if np.float32(gamma) == np.float32(2.2):
+        if _T22 is None:
+            import os
+            _T22 = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'gamma22_thresholds.npy'))
+        q = np.searchsorted(_T22[1:], x.view(np.uint32), side='right')
+        return q.astype(np.float32) / np.float32(255)
+    outs = np.power(x.astype(np.float64), np.float64(np.float32(1.0 / gamma))).astype(np.float32)
     return quantise(outs)
 
 

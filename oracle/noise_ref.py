@@ -419,6 +419,22 @@ def unpack_raw_bayer(img4c):
     return out
 
 
+def pack_raw_sid(im, raw_pattern, black_level, white_point=16383):
+    """dataset/sid_dataset.py:172-196 pack_raw_bayer: mosaic (H,W) -> (4,H/2,W/2) in R, G1, B, G2 order (positions of colour codes
+    0..3 in the 2x2 raw_pattern), (x - black) / (white_point - black) per channel in float32, clipped to [0,1]."""
+    im = np.asarray(im).astype(F32)
+    pat = np.asarray(raw_pattern)
+    H, W = im.shape
+    chans = []
+    for k in range(4):
+        oy, ox = np.where(pat == k)
+        chans.append(im[oy[0]:H:2, ox[0]:W:2])
+    out = np.stack(chans, axis=0).astype(F32)
+    black = np.asarray(black_level, F32)[:, None, None]
+    out = (out - black) / (F32(white_point) - black)
+    return np.clip(out, 0, 1).astype(F32)
+
+
 def lmdb_decode_u16(x):
     """uint16 -> float32 in [0,1]: clip(x/65535, 0, 1) evaluated in float64 then cast
     (dataset/lmdb_dataset.py:38-39).  An fp32 true division float(u16)/65535.0f gives the

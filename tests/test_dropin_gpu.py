@@ -209,3 +209,56 @@ def test_checkpoint_keeps_the_noise_stream_position(eld_lib, tmp_path):
     assert e2.model._sample_counter == 2 and e2.model.seed == 99
     sd = torch.load(os.path.join(str(tmp_path), 't', 'model_latest.pt'), map_location='cpu')
     assert {'netG', 'opt_g', 'epoch', 'iterations'} <= set(sd)      # the reference's keys (ELD_model.py:516-523) are all there
+
+
+def test_srgb_input_stage_on_device(eld_lib, lmdb_stub, tmp_path):
+    """--stage_in srgb / --stage_out srgb (train_syn.py:48-58, sid_dataset.py:287-319): noise on the raw patch -> clip -> raw2rgb
+    (util/process.py:52-68) -> clip, all on the device, equals the oracle chain bit for bit; a 3 -> 3 U-Net trains on it."""
+    import eld_amd.noise as noise
+    from eld_amd import _lib as L
+    from eld_amd import data as datasets
+    from eld_amd.data import records_from_batch
+    from eld_amd.engine import Engine
+    from eld_amd.noise import model_flags, sample_noise_records, set_sample_ids
+    from oracle import isp_ref as I
+    np.random.seed(4)
+    torch.manual_seed(4)
+    with contextlib.redirect_stdout(io.StringIO()):
+        nm = noise.NoiseModel(model='Pg', include=4)
+    raw_db = datasets.LMDBDataset('data/Train/SID_Sony_Raw.db')
+    rng = np.random.default_rng(0)
+    meta = [(np.array([2.0 + 0.1 * i, 1.0, 1.5, 1.0], np.float32), (np.eye(3) * (1.3 + 0.05 * i) - 0.1).astype(np.float32)) for i in range(4)]
+    srgb_targets = [rng.uniform(0, 1, (3, 512, 512)).astype(np.float32) for _ in range(4)]
+
+    class ListDS(object):
+        def __getitem__(self, i):
+            return srgb_targets[i % 4]
+
+        def __len__(self):
+            return 4
+    input_data = datasets.ISPDataset(raw_db, noise_maker=nm, meta_info=meta)                              # train_syn.py:55-58
+    ds = datasets.ELDTrainDataset(target_dataset=ListDS(), input_datasets=[input_data])
+    batch = next(iter(torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False, num_workers=0)))
+    assert set(batch) == {'clean', 'target', 'wb', 'ccm', 'aug', 'burst', 'params'}
+    engine = Engine(make_opt(tmp_path, stage_in='srgb', stage_out='srgb'))
+    m = engine.model
+    m.set_input(batch, 'train')
+    assert tuple(m.input.shape) == (2, 3, 512, 512) and tuple(m.target.shape) == (2, 3, 512, 512)
+    # oracle chain
+    codes = batch['clean'].numpy().view(np.uint16)
+    clean = O.lmdb_decode_u16(codes)
+    recs = set_sample_ids(records_from_batch(batch['params'].numpy()), [0, 1])
+    flags = model_flags('Pg') | L.CLIP
+    dump = torch.zeros(L.NPLANES, clean.size, device='cuda')
+    sample_noise_records(batch['clean'].cuda(), recs, flags, m.seed, in_u16=True, dump=dump)
+    dv = dump.cpu().numpy()
+    noisy = np.stack([O.noise_arith(clean[i], oracle_params(recs[i]), flags, **{n: dv[j].reshape(clean.shape)[i] for n, j in L.PLANE.items()})
+                      for i in range(2)])
+    rgb = I.process(noisy, batch['wb'].numpy(), batch['ccm'].numpy())
+    for i in range(2):
+        b = int(batch['aug'][i])
+        assert np.array_equal(m.input[i].cpu().numpy(), np.clip(O.augment(rgb[i], b & 1, b & 2, b & 4), 0, 1))
+        assert np.array_equal(m.target[i].cpu().numpy(), O.augment(batch['target'][i].numpy(), b & 1, b & 2, b & 4))
+    m.optimize_parameters()
+    assert m.netG.state_dict()['conv1_1.weight'].shape == (32, 3, 3, 3) and m.netG.state_dict()['conv10_1.weight'].shape == (3, 32, 1, 1)
+    assert 0 < m.get_current_errors()['Pixel'] < 1

@@ -157,3 +157,10 @@ def test_philox_normals_and_rows():
     assert np.all(nr == nr[:, :, :1])                        # constant along a row
     assert np.array_equal(nr[0], nr[1]) and np.array_equal(nr[2], nr[3])     # channel pairs share the sensor row
     assert not np.array_equal(nr[0], nr[2])
+
+
+def test_pack_raw_sid_matches_reference_golden(golden_dir):
+    """pack_raw_bayer (dataset/sid_dataset.py:172-196): oracle restatement vs the reference's output, four CFA patterns."""
+    d = np.load(os.path.join(golden_dir, 'pack_raw.npz'))
+    for n in ('rggb', 'grbg', 'bggr', 'gbrg'):
+        assert np.array_equal(O.pack_raw_sid(d[n + '_im'], d[n + '_pattern'], d[n + '_black']), d[n + '_out'])
