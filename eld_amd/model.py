@@ -11,7 +11,8 @@ for the raw->raw path, with the whole training iteration on the MI355X:
                      torch-Adam-shaped 'opt_g' (ELD_model.py:492-523, base_model.py:55-66)
 
 `eld_model()` is the factory `models.__dict__[opt.model]()` resolves (engine.py:26, models/__init__.py:3-4).
-The sRGB stages (--stage_in/out srgb, util/process.py) are outside the hot path and raise.
+The sRGB stages (--stage_in/out srgb, util/process.py) run through eld_isp_process (3-channel ends); an unknown stage raises
+NotImplementedError('Invalid Stage') like ELD_model.py:377-389.
 """
 import os
 from collections import OrderedDict

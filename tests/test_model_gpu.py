@@ -233,8 +233,11 @@ def test_model_requires_gpu_and_raw_stage(eld_lib, tmp_path):
     from eld_amd.model import ELDModel
     with pytest.raises(RuntimeError):
         ELDModel().initialize(make_opt(tmp_path, gpu_ids=[]))
-    with pytest.raises(NotImplementedError):
-        ELDModel().initialize(make_opt(tmp_path, stage_in='srgb'))
+    with pytest.raises(NotImplementedError):                          # ELD_model.py:377-389: 'Invalid Stage'
+        ELDModel().initialize(make_opt(tmp_path, stage_in='xyz'))
+    m = ELDModel()
+    m.initialize(make_opt(tmp_path, stage_in='srgb'))                 # wired since n4: 3-channel input net
+    assert m.netG.conv1_1.weight.shape[1] == 3
 
 
 def test_bf16_training_tracks_fp32(eld_lib, tmp_path):

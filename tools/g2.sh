@@ -1,0 +1,5 @@
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+( time timeout 1800 python -m pytest tests -m gpu -q ) > gpurun_out/pytest.log 2>&1
+tail -8 gpurun_out/pytest.log
