@@ -29,6 +29,8 @@ struct ConvArgs {
     int lrelu;          // EPI_FWD: apply max(0.2v, v)
     void* out0;         // EPI_FWD/CONVT: destination.  EPI_GRAD: channels [0, split)
     void* out1;         // EPI_GRAD: channels [split, Nout)
+    void* pool_out;     // EPI_FWD, optional: also write the 2x2/stride-2 max-pool of the output ([N, H/2, W/2, Nout]; H, W even) -- honoured by the
+                        // three-piece 3x3 kernels (conv_x3.hip) only; other launchers return ELD_ENOTSUP when it is set
     int split;
     const void* act0;   // EPI_GRAD: saved post-activation tensor (layout of out0) -> multiply by lrelu slope; may be null
     const void* act1;
@@ -106,6 +108,8 @@ struct WgradArgs {
     int N, H, W;         // pixel domain of g
     float* part;         // partials [psplit][taps][CA][CBp]
     float* bpart;        // optional bias partials [psplit][CA] (sum over pixels of g); null to skip
+    float* xbpart;       // CONV_GATHER2X2, fp32 inputs, optional: partials [psplit][CBp] of the column sums of the gathered operand (every pixel
+                         // of x0 is staged exactly once per block column) = the transposed conv's bias gradient; null to skip
     int CBp;             // padded CB (multiple of 32)
     int psplit;
     int tiles_x, tiles_y;

@@ -116,7 +116,7 @@ int launch_conv_first_fwd_bf16(const float* x, const float* w, const float* bias
 // that pixel (j < K; two 32-wide j tiles cover K <= 36).  Each wave owns 64 pixels of the 256-pixel tile; the workgroup
 // walks tiles persistently, reduces its 4 waves through LDS and writes one partial [2][32][32] (+ 32 bias sums).
 // ------------------------------------------------------------------------------------------------------------------
-#define FW_BLOCKS 512
+#define FW_BLOCKS 1024
 template <int CIN, typename TG>
 __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const TG* __restrict__ g, const float* __restrict__ x, float* __restrict__ part,
                                                                int N, int H, int W) {

@@ -86,6 +86,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     float bsum = 0.f;
+    // column sums of the gathered operand (transposed-conv bias gradient): a thread always stages the same channel quad (256 % 8 == 0)
+    constexpr bool XSUM = MODE == CONV_GATHER2X2 && ES == 4;
+    const bool xsum_on = XSUM && a.xbpart != nullptr && ib == 0;
+    float4 xs = make_float4(0.f, 0.f, 0.f, 0.f);
 
     const int tiles_per_img = a.tiles_x * a.tiles_y;
     const int ntiles = tiles_per_img * a.N;
@@ -180,6 +184,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
         for (int it = 0; it < X_IT; ++it) {
             const int u = tid + it * 256;
             if (u < X_UNITS) put(ldsX, u, rx[it], XPL, u * EPU);
+        }
+        if constexpr (XSUM) {
+            if (xsum_on) {
+#pragma unroll
+                for (int it = 0; it < X_IT; ++it) { xs.x += rx[it].x; xs.y += rx[it].y; xs.z += rx[it].z; xs.w += rx[it].w; }      // out-of-image units load zeros
+            }
         }
     };
 
@@ -327,6 +337,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
             float s = 0.f;
             for (int wp = 0; wp < WPIX; ++wp) s += red[(wp * WCO + wc) * 64 + mm] + red[(wp * WCO + wc) * 64 + 32 + mm];
             a.bpart[(size_t)ps * a.CA + i0 + tid] = H2 ? s * (1.0f / sc_g) : s;
+        }
+    }
+    if constexpr (XSUM) {
+        if (xsum_on) {                                  // block-uniform: 32 threads hold each channel quad; fixed-order combine through LDS
+            __syncthreads();
+            float4* r4 = reinterpret_cast<float4*>(lds);
+            r4[tid] = xs;
+            __syncthreads();
+            if (tid < JB) {
+                const int part = tid >> 2, comp = tid & 3;
+                float s = 0.f;
+                for (int k = 0; k < 32; ++k) s += reinterpret_cast<const float*>(&r4[k * 8 + part])[comp];
+                a.xbpart[(size_t)ps * a.CBp + j0 + tid] = s;
+            }
         }
     }
 }

@@ -50,6 +50,54 @@ __device__ __forceinline__ void split_store(float* row, float4 v) {
     *reinterpret_cast<uint2*>(row + 16) = make_uint2(hi_pair(__float_as_uint(s0), __float_as_uint(s1)), hi_pair(__float_as_uint(s2), __float_as_uint(s3)));
 }
 
+
+// max over the horizontal neighbour pixel (lane ^ 1 holds pixel x ^ 1 of the same row and the same channels): quad_perm [1,0,3,2]
+__device__ __forceinline__ float hmax1(float f) {
+    return fmaxf(f, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(f), 0xB1, 0xF, 0xF, true)));
+}
+
+// Fused nn.MaxPool2d(2) of a forward tile (models/arch/Unet.py:51-63): a lane owns pixel column x0+m of RPW consecutive rows starting at an even
+// row, so the vertical pair is in its own registers and the horizontal one in lane ^ 1.  The finished values (bias, LeakyReLU) are formed again
+// from the accumulators -- the same operations as the full-resolution store, hence the same bits as pooling the stored tensor -- and the even
+// lanes write [N, H/2, W/2, Nout].  H and W are even (checked by the launcher), so a window is never split by the image border.
+template <int RPW, int NT, int BN>
+__device__ __forceinline__ void pool_epilogue(const ConvArgs& a, const f32x16 (&acc)[RPW][NT], int img, int nb, int yb /* first row of the lane */, int x, int hi) {
+    static_assert(RPW % 2 == 0, "row pairs per lane");
+    if (x >= a.W) return;
+    const int Hp = a.H >> 1, Wp = a.W >> 1;
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) {
+        const int nbase = nb * BN + tt * 32 + 4 * hi;
+        float4 bs[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bs[q] = *reinterpret_cast<const float4*>(a.bias + nbase + 8 * q);
+#pragma unroll
+        for (int rp = 0; rp < RPW / 2; ++rp) {
+            const int y = yb + 2 * rp;
+            if (y >= a.H) continue;
+            float4 pv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float u[4], d[4];
+                const float bq[4] = {bs[q].x, bs[q].y, bs[q].z, bs[q].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    u[j] = acc[2 * rp][tt][4 * q + j] + bq[j];
+                    d[j] = acc[2 * rp + 1][tt][4 * q + j] + bq[j];
+                    if (a.lrelu) { u[j] = fmaxf(0.2f * u[j], u[j]); d[j] = fmaxf(0.2f * d[j], d[j]); }
+                    u[j] = hmax1(fmaxf(u[j], d[j]));
+                }
+                pv[q] = make_float4(u[0], u[1], u[2], u[3]);
+            }
+            if (!(x & 1)) {
+                float* dst = static_cast<float*>(a.pool_out) + ((size_t)(img * Hp + (y >> 1)) * Wp + (x >> 1)) * a.Nout + nbase;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(dst + 8 * q) = pv[q];
+            }
+        }
+    }
+}
+
 template <int BN, int RPW, bool DB>
 __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
     constexpr int CK = 16;
@@ -287,6 +335,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
                 }
             }
         }
+        if (a.epi == EPI_FWD && a.pool_out != nullptr) pool_epilogue<RPW, NT, BN>(a, acc, img, nb, y0 + wave * RPW, x0 + m, hi);
         if (t_next >= total_tiles) break;
         t = t_next;
     }
@@ -552,6 +601,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
                 }
             }
         }
+        if (a.epi == EPI_FWD && a.pool_out != nullptr) pool_epilogue<RPW, NT, BN>(a, acc, img, nb, y0 + wave * RPW, x0 + m, hi);
         if (t_next >= total_tiles) break;
         t = t_next;
     }
@@ -823,6 +873,7 @@ int launch_conv_x3(const ConvArgs& a_in, hipStream_t st) {
     ConvArgs a = a_in;
     a.prof = nullptr;
     if ((size_t)a.H * a.W * a.C0 * 4 >= 0xFFFFFFF0ull) return ELD_ENOTSUP;
+    if (a.pool_out && (a.epi != EPI_FWD || (a.H & 1) || (a.W & 1))) return ELD_EINVAL;
     if (x3_slab_bn(a.Nout) == 128) return launch_x3d<128, 2, 8, false>(a, st);      // weights pre-split in slab layout: LDS-DMA kernel
     if (x3_slab_bn(a.Nout) == 64) return launch_x3d<64, 2, 8, false>(a, st);
     return launch_x3<32, 4, false>(a, st);

@@ -99,8 +99,9 @@ inline void take_amax(ConvArgs& a) { a.algo = g_algo; a.amax_in0 = g_am.in0; a.a
 inline void take_amax(WgradArgs& a) { a.algo = g_algo; a.amax_g = g_am.in0; a.amax_x0 = g_am.w; a.amax_x1 = g_am.in1; g_am = Amax(); }      // wgrad: in0 = G, w = X0, in1 = X1
 enum { S_W = 0, S_X = 23, S_EA = 24, S_EB = 29, S_UP = 34, S_DA = 38, S_DB = 42, S_GA = 46, S_GB = 47, S_SKIP = 48, S_COUNT = 64 };
 int conv_fwd(const float* in0, int C0, const float* in1, int C1, const float* wp, const float* bias, float* out, int N, int H, int W,
-             int Cout, int lrelu, hipStream_t st) {
+             int Cout, int lrelu, hipStream_t st, float* pool_out = nullptr) {
     ConvArgs a = {};
+    a.pool_out = pool_out;
     a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1; a.wp = wp; a.N = N; a.H = H; a.W = W; a.Nout = Cout;
     a.epi = EPI_FWD; a.bias = bias; a.lrelu = lrelu; a.out0 = out;
     take_amax(a);
@@ -154,11 +155,16 @@ int convt_wgrad(const float* in, const float* dout, float* dw, float* db, float*
     WgradArgs a = {};
     a.g = in; a.CA = Cin; a.x0 = dout; a.C0 = Cout; a.N = N; a.H = H; a.W = W;
     a.part = part; a.bpart = nullptr; a.CBp = q.CBp; a.psplit = q.psplit;
+    // bias gradient = column sums of dout: accumulated by the weight-gradient kernel from its staging registers (every dout pixel
+    // passes through exactly once per block column); the partials take the plan's bias slot (psplit * CA floats >= psplit * CBp)
+    const bool fused_bias = db != nullptr && q.CBp <= q.CA && Cout == q.CBp;
+    a.xbpart = fused_bias ? part + (size_t)q.psplit * q.T * q.CA * q.CBp : nullptr;
     take_amax(a);
     int rc = launch_wgrad(a, CONV_GATHER2X2, st);
     if (rc) return rc;
     rc = launch_wgrad_reduce(part, nullptr, dw, nullptr, q.psplit, q.T, q.CA, q.CBp, Cout, st);
     if (rc || !db) return rc;
+    if (fused_bias) return launch_colsum_reduce(a.xbpart, db, q.psplit, Cout, st);
     return launch_colsum(dout, db, part, (size_t)N * 4 * H * W, Cout, st);
 }
 
@@ -311,8 +317,11 @@ int unet_forward(const Plan& P, const float* x, const float* prm, float* out, fl
             RC(conv_fwd(src, cin, nullptr, 0, ws + P.wp_fwd[2 * l], prm + A.b_off, ws + P.ea[l], N, P.Hl[l], P.Wl[l], chan(l), 1, st));
         }
         AM(S_EA + l, -1, S_W + 2 * l + 1, S_EB + l);
-        RC(conv_fwd(ws + P.ea[l], chan(l), nullptr, 0, ws + P.wp_fwd[2 * l + 1], prm + B.b_off, ws + P.eb[l], N, P.Hl[l], P.Wl[l], chan(l), 1, st));
-        if (l < NLEV - 1) RC(launch_maxpool_fwd(ws + P.eb[l], ws + P.pool[l], N, P.Hl[l + 1], P.Wl[l + 1], chan(l), st));
+        // three-piece scheme: the conv's epilogue also writes the pooled tensor (no second pass over eb[l])
+        const bool fuse_pool = g_algo == 1 && l < NLEV - 1;
+        RC(conv_fwd(ws + P.ea[l], chan(l), nullptr, 0, ws + P.wp_fwd[2 * l + 1], prm + B.b_off, ws + P.eb[l], N, P.Hl[l], P.Wl[l], chan(l), 1, st,
+                    fuse_pool ? ws + P.pool[l] : nullptr));
+        if (l < NLEV - 1 && !fuse_pool) RC(launch_maxpool_fwd(ws + P.eb[l], ws + P.pool[l], N, P.Hl[l + 1], P.Wl[l + 1], chan(l), st));
     }
     for (int l = 3; l >= 0; --l) {
         const int iu = L_UP3 + 3 * (3 - l);

@@ -295,6 +295,14 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __rest
 
 size_t colsum_ws_floats(int C) { return (size_t)COLSUM_BLOCKS * C; }
 
+// out[c] = sum_b part[b][c]: second stage alone, for partials another kernel produced (wgrad_kernel's xbpart)
+int launch_colsum_reduce(const float* part, float* out, int nblocks, int C, hipStream_t st) {
+    if (nblocks <= 0 || C <= 0) return 0;
+    ELD_LAUNCH(colsum_reduce_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, part, out, nblocks, C);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_colsum(const float* x, float* out, float* part, size_t P, int C, hipStream_t st) {
     if (C % 4 || C > 512) return ELD_EINVAL;
     const int ppb = 256 / (C / 4);
