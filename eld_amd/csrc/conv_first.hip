@@ -12,16 +12,32 @@
 #define FTW 32
 #define FHP ((FTH + 2) * (FTW + 2))      // halo pixels per plane
 
-__device__ __forceinline__ void first_load_halo(float* halo, const float* __restrict__ x, int img, int y0, int x0, int H, int W, int CIN) {
-    for (int u = threadIdx.x; u < CIN * FHP; u += 256) {
-        const int c = u / FHP, hp = u - c * FHP;
-        const int hy = hp / (FTW + 2), hx = hp - hy * (FTW + 2);
-        const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-        float v = 0.f;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = x[((size_t)(img * CIN + c) * H + gy) * W + gx];
-        halo[u] = v;
+// The zero-padded halo [CIN][FTH+2][34] of a tile travels HBM -> registers -> LDS: all of a thread's loads are issued together, one tile
+// ahead (they are in flight during the previous tile's MFMA phase and epilogue), and go to LDS between the two barriers of the next step.
+// (A load -> ds_write loop costs one HBM round trip per iteration: 6 serialised latencies per tile were 3/4 of these kernels' time.)
+template <int CIN>
+struct FirstHalo {
+    static constexpr int IT = (CIN * FHP + 255) / 256;
+    float v[IT];
+    __device__ __forceinline__ void load(const float* __restrict__ x, int img, int y0, int x0, int H, int W) {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int u = threadIdx.x + it * 256;
+            const int c = u / FHP, hp = u - c * FHP;
+            const int hy = hp / (FTW + 2), hx = hp - hy * (FTW + 2);
+            const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+            v[it] = 0.f;
+            if (u < CIN * FHP && gy >= 0 && gy < H && gx >= 0 && gx < W) v[it] = x[((size_t)(img * CIN + c) * H + gy) * W + gx];
+        }
     }
-}
+    __device__ __forceinline__ void store(float* halo) const {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int u = threadIdx.x + it * 256;
+            if (u < CIN * FHP) halo[u] = v[it];
+        }
+    }
+};
 
 template <int CIN, typename TO>
 __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
@@ -47,12 +63,19 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
     }
     const float4 b0 = *reinterpret_cast<const float4*>(bias + 4 * hi), b1 = *reinterpret_cast<const float4*>(bias + 8 + 4 * hi),
                  b2 = *reinterpret_cast<const float4*>(bias + 16 + 4 * hi), b3 = *reinterpret_cast<const float4*>(bias + 24 + 4 * hi);
+    FirstHalo<CIN> hr;
+    auto prefetch = [&](int t) {
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, img = t / (tiles_x * tiles_y);
+        hr.load(x, img, ty * FTH, tx * FTW, H, W);
+    };
+    if ((int)blockIdx.x < total) prefetch(blockIdx.x);
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
         const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, img = t / (tiles_x * tiles_y);
         const int y0 = ty * FTH, x0 = tx * FTW;
         __syncthreads();
-        first_load_halo(halo, x, img, y0, x0, H, W, CIN);
+        hr.store(halo);
         __syncthreads();
+        if (t + (int)gridDim.x < total) prefetch(t + gridDim.x);
         f32x16 acc[2];
 #pragma unroll
         for (int r = 0; r < 2; ++r)
@@ -140,23 +163,33 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const TG* __restr
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[jt][i] = 0.f;
     float bsum = 0.f;
-    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+    FirstHalo<CIN> hr;
+    float4 gr[8];                                // this thread's 8 units of the 256-pixel x 32-channel gradient tile
+    auto prefetch = [&](int t) {
         const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, img = t / (tiles_x * tiles_y);
         const int y0 = ty * FTH, x0 = tx * FTW;
-        __syncthreads();
-        first_load_halo(halo, x, img, y0, x0, H, W, CIN);
-        for (int u = tid; u < FTH * FTW * 8; u += 256) {
+        hr.load(x, img, y0, x0, H, W);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int u = threadIdx.x + it * 256;
             const int lp = u >> 3, part4 = u & 7;
             const int gy = y0 + lp / FTW, gx = x0 + lp % FTW;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            gr[it] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gy < H && gx < W) {
                 const TG* gp = g + ((size_t)(img * H + gy) * W + gx) * 32 + part4 * 4;
-                if constexpr (sizeof(TG) == 4) v = *reinterpret_cast<const float4*>(gp);
-                else v = unpack_bf4(*reinterpret_cast<const uint2*>(gp));
+                if constexpr (sizeof(TG) == 4) gr[it] = *reinterpret_cast<const float4*>(gp);
+                else gr[it] = unpack_bf4(*reinterpret_cast<const uint2*>(gp));
             }
-            *reinterpret_cast<float4*>(gl + u * 4) = v;
         }
+    };
+    if ((int)blockIdx.x < total) prefetch(blockIdx.x);
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
         __syncthreads();
+        hr.store(halo);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) *reinterpret_cast<float4*>(gl + (tid + it * 256) * 4) = gr[it];
+        __syncthreads();
+        if (t + (int)gridDim.x < total) prefetch(t + gridDim.x);
 #pragma unroll 4
         for (int s = 0; s < 32; ++s) {
             const int lp = wave * 64 + s + hi * 32;          // rows 2*wave (hi=0) and 2*wave+1 (hi=1), column s

@@ -156,60 +156,80 @@ int launch_head_fwd(const float* in, const float* w, const float* b, float* out,
 
 // backward: g[p][c] = (sum_o W[o][c] d[o][p]) * slope(act[p][c]);  dW[o][c] = sum_p d[o][p] act[p][c];  db[o] = sum_p d[o][p]
 // per-block partials [nblocks][132] -> reduced by head_bwd_reduce_kernel in fixed order.
-#define HEAD_BLOCKS 512
+#define HEAD_BLOCKS 1024
+// Eight lanes per pixel, one channel quad each: a wave reads / writes 8 whole pixels = 1 KiB contiguous per instruction (the one-thread-per-
+// pixel layout touched 64 cache lines per load).  The pixel's four output gradients are read once (lane o of each quad of lanes reads plane o)
+// and handed round with quad-permute DPP moves.  A lane keeps dW[o][its 4 channels] (16 sums) and, in quad 0, db[o].
+__device__ __forceinline__ float quad_bcast(float v, int src) {
+    const int i = __float_as_int(v);
+    switch (src) {
+        case 0: return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0x00, 0xF, 0xF, true));
+        case 1: return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0x55, 0xF, 0xF, true));
+        case 2: return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0xAA, 0xF, 0xF, true));
+        default: return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0xFF, 0xF, 0xF, true));
+    }
+}
+
 __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ act, const float* __restrict__ w,
                                                        float* __restrict__ g, float* __restrict__ part, int N, size_t HW, int OC) {
-    __shared__ float sw[128];
     __shared__ float red[4][132];
-    for (int i = threadIdx.x; i < 128; i += 256) sw[i] = (i / 32 < OC) ? w[i] : 0.f;
-    __syncthreads();
-    float dw[4][32];
-    float db[4] = {0.f, 0.f, 0.f, 0.f};
+    const int tid = threadIdx.x, cq = tid & 7, o_ld = tid & 3;
+    float wq[4][4];                                   // w[o][4cq + j]
 #pragma unroll
     for (int o = 0; o < 4; ++o)
 #pragma unroll
-        for (int c = 0; c < 32; ++c) dw[o][c] = 0.f;
+        for (int j = 0; j < 4; ++j) wq[o][j] = o < OC ? w[o * 32 + 4 * cq + j] : 0.f;
+    float dw[4][4];
+    float db = 0.f;                                   // lanes with cq < 4 sum plane o_ld = cq
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dw[o][j] = 0.f;
     const size_t total = (size_t)N * HW;
-    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
-        const size_t n = p / HW, q = p - n * HW;
+    const size_t stride = (size_t)gridDim.x * 32;
+    size_t p = (size_t)blockIdx.x * 32 + (tid >> 3);
+    const size_t iters = (total + stride - 1) / stride;               // every lane of a quad runs the same trip count (DPP needs its quad mates)
+    for (size_t itn = 0; itn < iters; ++itn, p += stride) {
+        const bool ok = p < total;
+        const size_t pc = ok ? p : total - 1;
+        const size_t n = pc / HW, q = pc - n * HW;
+        float dl = 0.f;
+        if (ok && o_ld < OC) dl = dout[(n * OC + o_ld) * HW + q];
+        if (cq < 4) db += dl;
         float d[4];
 #pragma unroll
-        for (int o = 0; o < 4; ++o) { d[o] = o < OC ? dout[(n * OC + o) * HW + q] : 0.f; db[o] += d[o]; }
-        const float4* A = reinterpret_cast<const float4*>(act + p * 32);
-        float4* G = reinterpret_cast<float4*>(g + p * 32);
+        for (int o = 0; o < 4; ++o) d[o] = quad_bcast(dl, o);
+        if (!ok) continue;
+        const float4 a = reinterpret_cast<const float4*>(act + pc * 32)[cq];
+        const float av[4] = {a.x, a.y, a.z, a.w};
+        float gv[4];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float4 a = A[k];
-            const float av[4] = {a.x, a.y, a.z, a.w};
-            float gv[4];
+        for (int j = 0; j < 4; ++j) {
+            float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = 4 * k + j;
-                float s = 0.f;
-#pragma unroll
-                for (int o = 0; o < 4; ++o) { s = fmaf(sw[o * 32 + c], d[o], s); dw[o][c] = fmaf(d[o], av[j], dw[o][c]); }
-                gv[j] = s * lrelu_slope(av[j]);
-            }
-            G[k] = make_float4(gv[0], gv[1], gv[2], gv[3]);
+            for (int o = 0; o < 4; ++o) { s = fmaf(wq[o][j], d[o], s); dw[o][j] = fmaf(d[o], av[j], dw[o][j]); }
+            gv[j] = s * lrelu_slope(av[j]);
         }
+        reinterpret_cast<float4*>(g + pc * 32)[cq] = make_float4(gv[0], gv[1], gv[2], gv[3]);
     }
-    // block reduction: wave shuffle then across the 4 waves
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // block reduction in a fixed order: lanes sharing a channel quad (cq, cq+8, ...) by xor-shuffles, then the 4 waves through LDS
+    const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {
+    for (int o = 0; o < 4; ++o)
 #pragma unroll
-        for (int c = 0; c < 32; ++c) {
-            float v = dw[o][c];
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if (lane == 0) red[wave][o * 32 + c] = v;
+        for (int j = 0; j < 4; ++j) {
+            float v = dw[o][j];
+            for (int off = 8; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+            if (lane < 8) red[wave][o * 32 + 4 * lane + j] = v;
         }
-        float v = db[o];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0) red[wave][128 + o] = v;
+    {
+        float v = db;
+        for (int off = 8; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+        if (lane < 4) red[wave][128 + lane] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 132)
-        part[(size_t)blockIdx.x * 132 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (tid < 132)
+        part[(size_t)blockIdx.x * 132 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
 }
 
 // 132 outputs, 16 lanes each over the per-block partials; fixed shuffle tree
@@ -231,7 +251,7 @@ int launch_head_bwd(const float* dout, const float* act, const float* w, float* 
                     int N, int H, int W, int OC, hipStream_t st) {
     const size_t total = (size_t)N * H * W;
     if (!total) return 0;
-    const int nb = (int)min((total + 255) / 256, (size_t)HEAD_BLOCKS);
+    const int nb = (int)min((total + 31) / 32, (size_t)HEAD_BLOCKS);
     ELD_LAUNCH(head_bwd_kernel, dim3(nb), dim3(256), 0, st, dout, act, w, g, part, N, (size_t)H * W, OC);
     ELD_LAUNCH_CHECK();
     ELD_LAUNCH(head_bwd_reduce_kernel, dim3((132 + 15) / 16), dim3(256), 0, st, part, dw, db, nb, OC);
