@@ -16,6 +16,7 @@
 //     the reference's NumPy evaluation.
 #include <stdlib.h>
 #include "philox.h"
+#include "poisson_alias_table.h"
 
 #pragma clang fp contract(off)
 
@@ -25,9 +26,11 @@
 #define ELEMS_PER_BLOCK (GROUPS_PER_BLOCK * 4)
 #define MAX_LDS_ROWS 256
 #define RUNTIME_FLAGS 0xFFFFFFFFu
-#define INV_ITERS1 12          // inversion steps done in the dense first pass; leftovers go to the queue
-#define QP_CAP 1024            // PTRS rejections per 4096 pixels: 12-25 % of the PTRS draws (8 B entries)
-#define QI_CAP 256             // inversion leftovers (16 B entries); queue overflow is resolved in place
+#define POIS_TABLE_LAM 32.0f   // below: alias table of Poisson(floor(lam)) + inversion at the fractional rate; at or above: PTRS
+#define RES_STEPS 5            // branch-free inversion steps of the fractional-rate draw (P(more) < 6e-4 at a rate below 1)
+#define PTRS_DENSE_MIN 13      // lanes of a wave with lam >= 32 in one pixel slot: above -> PTRS inline, else -> queue
+#define QP_CAP 768             // open PTRS draws per 4096 pixels (16 B entries: 12 of 64 lanes at most take the queue route); overflow is resolved in place
+#define PASS_GROUPS 1           // 4-pixel groups a lane carries through one pass of phase 1 (1: 4 pixels -> <= 128 VGPRs, 4 workgroups per CU)
 
 struct NoiseArgs {
     const void* in;
@@ -45,15 +48,18 @@ struct NoiseArgs {
 };
 
 // ---------------------------------------------------------------------------------------------
-// Poisson(lam): CDF inversion (lam < 10) or PTRS transformed rejection (Hoermann 1993; the split and
-// the sampler NumPy's legacy RandomState.poisson uses, which is what noise.py:159 calls).  float32
-// throughout; the CPU statement of exactly this word usage is oracle/noise_ref.py::_poisson_philox.
-//
-// Divergence control: the exact draw has data-dependent loops (inversion: ~lam steps; PTRS: slow accept
-// test and retries for ~15-20 % of the draws).  A workgroup therefore makes ONE dense pass over its 4096
-// pixels that resolves the cheap majority (INV_ITERS1 inversion steps jointly over 8 pixels per lane;
-// PTRS attempt 0 with its squeeze test from a single 32-bit word), pushes the rest into two LDS queues,
-// and then drains the queues with every lane busy.  Counts meet the rest of the pipeline through LDS.
+// Poisson(lam), exact, float32 (replaces the internals of np.random.poisson that noise.py:159 calls; the CPU statement of
+// exactly this word usage is oracle/noise_ref.py::_poisson_philox):
+//   lam < 32   X = A_n(w0) + Inv(lam - n, u01(w1)),  n = floor(lam): the sum of independent Poisson(n) and Poisson(lam - n) draws.
+//              A_n = one lookup in Walker's alias table of Poisson(n) (LDS copy of POIS_ALIAS, oracle/gen_poisson_alias.py) with
+//              the whole word w0; Inv = CDF inversion at a rate below 1: RES_STEPS branch-free steps, the < 6e-4 leftovers and the
+//              table's tail outcome {A >= 63} (< 4e-7) finish in a rarely taken loop.  ~50 VALU per pixel, no divergence.
+//   lam >= 32  PTRS transformed rejection (Hoermann 1993, the large-rate sampler of NumPy's legacy RandomState): attempt 0 takes
+//              U = u01(w0), V = u01(w1); attempts 2c+1, 2c+2 the words of retry call c of the element (stream POIS_R).  Where
+//              most lanes of a wave are in this regime the attempt runs inline and only rejections are queued; where few are
+//              (an image whose rate peaks just above 32) the draws go to an LDS queue that is drained with dense lanes.  Both
+//              routes evaluate the same function of (lam, element): results do not depend on the route.
+// w0 / w1 = word (element % 4) of the group's STREAM_POIS_U / STREAM_POIS_V Philox calls.
 // ---------------------------------------------------------------------------------------------
 // The variate transforms below are NOT part of the reference's arithmetic (they replace NumPy's RNG internals), so they
 // may use FMA contraction and the hardware reciprocal / square root; only the op chain of noise.py:155-169 in phase 3
@@ -107,11 +113,17 @@ struct Ptrs {
     }
 };
 
-// finish a PTRS draw whose attempt 0 was rejected: attempts 2c+1, 2c+2 from retry call c of this element
-__device__ float ptrs_resolve(float lam, uint32_t elem, const SamplerRng& rng) {
+// finish a PTRS draw: `fresh` -> attempt 0 with (w0, w1) first; then attempts 2c+1, 2c+2 from retry call c of this element
+__device__ __noinline__ float ptrs_resolve(float lam, uint32_t elem, const SamplerRng& rng, bool fresh, uint32_t w0, uint32_t w1) {
     Ptrs P;
     P.init(lam);
     float k = 0.f;
+    if (fresh) {
+        float us;
+        k = P.k_of(lam, u01(w0), us);
+        const float V = u01(w1);
+        if ((us >= 0.07f && V <= P.vr) || P.slow_accept(lam, k, us, V)) return k;
+    }
     for (uint32_t call = 0; call < 64u; ++call) {
         const uint4 r = rng.words(elem, STREAM_POIS_R, call);
         float us;
@@ -125,17 +137,6 @@ __device__ float ptrs_resolve(float lam, uint32_t elem, const SamplerRng& rng) {
     return fmaxf(k, 0.f);
 }
 
-// finish an inversion draw after INV_ITERS1 steps (state p, r)
-__device__ float inv_resolve(float lam, float p, float r) {
-    int k = INV_ITERS1;
-    for (int it = INV_ITERS1 + 1; r > 0.f && it <= 96; ++it) {
-        ++k;
-        p = p * (lam * frcp((float)it));
-        r = r - p;
-    }
-    return (float)k;
-}
-
 // unit-scale Tukey-lambda quantile from one word: u = u01(w), 1-u = u01(~w) (exact complement); inv_lam = 1/lam (per image)
 __device__ __forceinline__ float tukey_lambda(uint32_t w, float lam, float inv_lam) {
     const float lu = __builtin_amdgcn_logf(u01(w)), lv = __builtin_amdgcn_logf(u01(~w));
@@ -143,6 +144,33 @@ __device__ __forceinline__ float tukey_lambda(uint32_t w, float lam, float inv_l
     return (__builtin_amdgcn_exp2f(lam * lu) - __builtin_amdgcn_exp2f(lam * lv)) * inv_lam;
 }
 #pragma clang fp contract(off)
+
+// rare tails of the small-rate draw.  k0 == 63: the alias table returned its tail outcome {X >= 63}: sample the conditional tail of
+// Poisson(n) by inversion from 63 with a fresh uniform (retry stream, call 64: never used by PTRS retries, which stop at 63).
+// r > 0: the fractional-rate inversion is not finished after RES_STEPS steps (state p, r): keep stepping.
+__device__ __noinline__ int pois_tail_alias(int n, uint32_t elem, const SamplerRng& rng) {
+    const uint4 w = rng.words(elem, STREAM_POIS_R, 64u);
+    float q = POIS_TAIL_Q0[n], t = u01(w.x) - q;
+    int k = 63;
+    while (t > 0.f && k < 255) {
+        ++k;
+        q = q * ((float)n / (float)k);
+        t = t - q;
+    }
+    return k;
+}
+__device__ __noinline__ int pois_tail_res(float d, float p, float r) {
+    int k = RES_STEPS;
+    for (int it = RES_STEPS + 1; r > 0.f && it <= 96; ++it) {
+        ++k;
+        p = p * (d * (1.0f / (float)it));
+        r = r - p;
+    }
+    return k;
+}
+
+// Poisson count and the 9 spare bits of the V word share an LDS word (counts stay far below 2^23: beyond that float32 PTRS has no integer resolution)
+__device__ __forceinline__ uint32_t pack_cnt(float k, uint32_t wv) { return ((uint32_t)fminf(k, 8388607.0f) << 9) | (wv & 511u); }
 
 __device__ __forceinline__ uint32_t pick(const uint4& w, int j) { return j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w; }
 
@@ -180,9 +208,9 @@ template <bool VEC, uint32_t TFLAGS, bool DEBUG>
 __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a) {
     constexpr bool MAYBE_P = (TFLAGS == RUNTIME_FLAGS) || (TFLAGS & ELD_SHOT_POISSON);
     __shared__ float s_row[MAX_LDS_ROWS];
-    __shared__ float s_cnt[MAYBE_P ? ELEMS_PER_BLOCK : 1];
-    __shared__ uint2 s_qp[MAYBE_P ? QP_CAP : 1];
-    __shared__ uint4 s_qi[MAYBE_P ? QI_CAP : 1];
+    __shared__ uint32_t s_cnt[MAYBE_P ? ELEMS_PER_BLOCK : 1];     // (count << 9) | low 9 bits of the pixel's POIS_V word (free: u01 takes w >> 9)
+    __shared__ uint4 s_qp[MAYBE_P ? QP_CAP : 1];
+    __shared__ uint32_t s_tab[MAYBE_P ? POIS_TAB_N * POIS_TAB_ENT : 1];
     __shared__ uint32_t s_qn[2];
     const uint32_t flags = (TFLAGS == RUNTIME_FLAGS) ? a.flags : TFLAGS;
     const uint32_t n = blockIdx.y;
@@ -201,7 +229,11 @@ __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a)
     const bool do_pois = MAYBE_P && (flags & ELD_SHOT_POISSON) && !inject;
     const float S = P.saturation, ratio = P.ratio, K = P.K;
 
-    if (do_pois && tid < 2) s_qn[tid] = 0;
+    if (do_pois) {
+        if (tid < 2) s_qn[tid] = 0;
+#pragma unroll
+        for (int i = 0; i < POIS_TAB_N * POIS_TAB_ENT / NOISE_THREADS; ++i) s_tab[tid + i * NOISE_THREADS] = POIS_ALIAS[tid + i * NOISE_THREADS];
+    }
 
     // ---- row normals of this block's rows -> LDS ------------------------------------------------
     uint32_t r_first = 0;
@@ -226,14 +258,15 @@ __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a)
     if (do_pois) {
         const float lam_c = (S * (1.0f / ratio)) * (1.0f / K);      // lam = y * lam_c  (oracle: poisson_lambda_fast)
 #pragma unroll 1
-        for (int half = 0; half < NOISE_ITERS / 2; ++half) {
-            float lam[8], p[8], r[8];
-            uint32_t w[8], wv[8];
-            int kk[8];
-            bool ok[8];
+        for (int half = 0; half < NOISE_ITERS / PASS_GROUPS; ++half) {
+            constexpr int PE = 4 * PASS_GROUPS;                 // pixels a lane carries through this pass
+            float lam[PE], p[PE], r[PE];
+            uint32_t w[PE], wv[PE];
+            int kk[PE];
+            bool ok[PE];
 #pragma unroll
-            for (int gi = 0; gi < 2; ++gi) {
-                const uint32_t g = g_begin + (half * 2 + gi) * NOISE_THREADS + tid;
+            for (int gi = 0; gi < PASS_GROUPS; ++gi) {
+                const uint32_t g = g_begin + (half * PASS_GROUPS + gi) * NOISE_THREADS + tid;
                 const bool gv = g < g_end;
                 const uint32_t e0 = g * 4u;
                 const uint32_t nvalid = gv ? (VEC ? 4u : min(4u, a.chw - e0)) : 0u;
@@ -253,86 +286,90 @@ __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a)
                     wv[e] = pick(wd2, j);
                 }
             }
-            // ---- inversion, INV_ITERS1 joint branch-free steps (lam < 10) -------------------------------
-            bool any_small = false;
+            // ---- lam < 32: alias table of Poisson(floor(lam)) + branch-free inversion at the fractional rate ----------------
+            uint32_t big = 0, tail = 0;                 // bit e: pixel slot e is in the PTRS regime / needs one of the rare tail loops
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const bool small = ok[e] && lam[e] < 10.0f;
-                p[e] = small ? __expf(-lam[e]) : 0.f;
-                r[e] = small ? u01(w[e]) - p[e] : -1.0f;
-                kk[e] = 0;
-                any_small |= small;
+            for (int e = 0; e < PE; ++e) {
+                const bool small = ok[e] && lam[e] < POIS_TABLE_LAM;
+                if (ok[e] && !small) big |= 1u << e;
+                const float ls = small ? lam[e] : 0.f;
+                const int n = (int)ls;
+                const float d = ls - (float)n;                              // exact
+                const uint32_t j = w[e] >> 26;
+                const uint32_t ent = s_tab[n * POIS_TAB_ENT + (int)j];
+                const uint32_t k0 = (w[e] << 6) < (ent & 0xFFFFFFC0u) ? j : (ent & 63u);
+                p[e] = __expf(-d);
+                r[e] = u01(wv[e]) - p[e];
+                int k1 = 0;
+#pragma unroll
+                for (int it = 1; it <= RES_STEPS; ++it) {                   // once r <= 0 it stays there (p > 0): no select needed
+                    k1 += r[e] > 0.f ? 1 : 0;
+                    p[e] = p[e] * (d * (1.0f / (float)it));
+                    r[e] = r[e] - p[e];
+                }
+                kk[e] = (int)k0 + k1;
+                if (small && (k0 == 63u || r[e] > 0.f)) tail |= 1u << e;
             }
-            if (__any(any_small) && !(ELD_DBG(a) & 2)) {
-#pragma unroll 1
-                for (int it = 1; it <= INV_ITERS1; ++it) {
-                    bool act = false;
+            if (__any(tail != 0u)) {                                        // < 1e-3 of the draws
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) act |= r[e] > 0.f;
-                    if (!__any(act)) break;
-                    const float inv = __builtin_amdgcn_rcpf((float)it);
+                for (int e = 0; e < PE; ++e) {
+                    if (!(tail & (1u << e))) continue;
+                    const uint32_t le = (uint32_t)(half * PASS_GROUPS + (e >> 2)) * (NOISE_THREADS * 4u) + tid * 4u + (uint32_t)(e & 3);
+                    const int n = (int)lam[e];
+                    int k0 = kk[e] - RES_STEPS, k1 = RES_STEPS;             // r > 0 after the last step: every step counted
+                    if (!(r[e] > 0.f)) { k0 = 63; k1 = kk[e] - 63; }        // only the alias draw hit its tail outcome
+                    if (k0 == 63) k0 = pois_tail_alias(n, g_begin * 4u + le, rng);
+                    if (r[e] > 0.f) k1 = pois_tail_res(lam[e] - (float)n, p[e], r[e]);
+                    kk[e] = k0 + k1;
+                }
+            }
+            // ---- lam >= 32: PTRS.  Per pixel slot the wave decides: many lanes -> attempt 0 inline, few -> queue ------------------
+            uint32_t pendF = 0, pendR = 0;              // fresh draw queued / attempt 0 rejected, retries queued
+            if (__any(big != 0u)) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const bool go = r[e] > 0.f;
-                        kk[e] += go ? 1 : 0;
-                        p[e] = p[e] * (lam[e] * inv);
-                        r[e] = go ? r[e] - p[e] : r[e];
+                for (int e = 0; e < PE; ++e) {
+                    const bool mine = (big >> e) & 1u;
+                    const int nbig = __popcll(__ballot(mine));
+                    if (nbig == 0) continue;
+                    if (nbig < PTRS_DENSE_MIN || (ELD_DBG(a) & 4)) { if (mine) pendF |= 1u << e; continue; }
+                    if (mine) {
+                        Ptrs T;
+                        T.init(lam[e]);
+                        float us;
+                        const float k0 = T.k_of(lam[e], u01(w[e]), us);
+                        const float V = u01(wv[e]);
+                        bool acc = us >= 0.07f && V <= T.vr;
+                        if (!acc) acc = T.slow_accept(lam[e], k0, us, V);
+                        kk[e] = (int)k0;
+                        if (!acc) pendR |= 1u << e;
                     }
                 }
             }
-            // ---- PTRS attempt 0 (lam >= 10), complete: squeeze test, then the slow test where it fails ----------
-            //      kk[e] = count, pend bit set when the draw is still open (PTRS rejection / inversion leftover)
-            uint32_t pendP = 0, pendI = 0;
+            // ---- one LDS atomic per lane reserves the queue slots of its open draws ----------------------------------------
+            const uint32_t pend = pendF | pendR;
+            uint32_t base = 0;
+            if (pend) base = atomicAdd(&s_qn[0], (uint32_t)__popc(pend));
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
+            for (int e = 0; e < PE; ++e) {
                 if (!ok[e]) continue;
-                if (lam[e] < 10.0f) {
-                    if (r[e] > 0.f) pendI |= 1u << e;
-                } else if (ELD_DBG(a) & 4) {
-                    kk[e] = (int)lam[e];
+                const uint32_t le = (uint32_t)(half * PASS_GROUPS + (e >> 2)) * (NOISE_THREADS * 4u) + tid * 4u + (uint32_t)(e & 3);
+                if (pend & (1u << e)) {
+                    const bool fresh = (pendF >> e) & 1u;
+                    const uint32_t pos = base + (uint32_t)__popc(pend & ((1u << e) - 1u));
+                    if (pos < QP_CAP) s_qp[pos] = make_uint4(le | (fresh ? 0x80000000u : 0u), __float_as_uint(lam[e]), w[e], wv[e]);
+                    else s_cnt[le] = pack_cnt(ptrs_resolve(lam[e], g_begin * 4u + le, rng, fresh, w[e], wv[e]), wv[e]);
                 } else {
-                    Ptrs T;
-                    T.init(lam[e]);
-                    float us;
-                    const float k0 = T.k_of(lam[e], u01(w[e]), us);
-                    const float V = u01(wv[e]);
-                    bool acc = us >= 0.07f && V <= T.vr;
-                    if (!acc) acc = T.slow_accept(lam[e], k0, us, V);
-                    kk[e] = (int)k0;
-                    if (!acc) pendP |= 1u << e;
-                }
-            }
-            // ---- one LDS atomic per lane per queue reserves the slots of its open draws --------------------------
-            uint32_t baseP = 0, baseI = 0;
-            if (pendP) baseP = atomicAdd(&s_qn[0], (uint32_t)__popc(pendP));
-            if (pendI) baseI = atomicAdd(&s_qn[1], (uint32_t)__popc(pendI));
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (!ok[e]) continue;
-                const uint32_t le = (uint32_t)(half * 2 + (e >> 2)) * (NOISE_THREADS * 4u) + tid * 4u + (uint32_t)(e & 3);
-                if (pendP & (1u << e)) {
-                    const uint32_t pos = baseP + (uint32_t)__popc(pendP & ((1u << e) - 1u));
-                    if (pos < QP_CAP) s_qp[pos] = make_uint2(le, __float_as_uint(lam[e]));
-                    else s_cnt[le] = ptrs_resolve(lam[e], g_begin * 4u + le, rng);
-                } else if (pendI & (1u << e)) {
-                    const uint32_t pos = baseI + (uint32_t)__popc(pendI & ((1u << e) - 1u));
-                    if (pos < QI_CAP) s_qi[pos] = make_uint4(le, __float_as_uint(lam[e]), __float_as_uint(p[e]), __float_as_uint(r[e]));
-                    else s_cnt[le] = inv_resolve(lam[e], p[e], r[e]);
-                } else {
-                    s_cnt[le] = (float)kk[e];
+                    s_cnt[le] = pack_cnt((float)kk[e], wv[e]);
                 }
             }
         }
         __syncthreads();
-        // ---- phase 2: drain the queues with dense lanes -------------------------------------------------------
-        const uint32_t nP = (ELD_DBG(a) & 1) ? 0u : min(s_qn[0], (uint32_t)QP_CAP), nI = (ELD_DBG(a) & 1) ? 0u : min(s_qn[1], (uint32_t)QI_CAP);
+        // ---- phase 2: drain the queue with dense lanes -----------------------------------------------------------------
+        const uint32_t nP = (ELD_DBG(a) & 1) ? 0u : min(s_qn[0], (uint32_t)QP_CAP);
         for (uint32_t q = tid; q < nP; q += NOISE_THREADS) {
-            const uint2 en = s_qp[q];
-            s_cnt[en.x] = ptrs_resolve(__uint_as_float(en.y), g_begin * 4u + en.x, rng);
-        }
-        for (uint32_t q = tid; q < nI; q += NOISE_THREADS) {
-            const uint4 en = s_qi[q];
-            s_cnt[en.x] = inv_resolve(__uint_as_float(en.y), __uint_as_float(en.z), __uint_as_float(en.w));
+            const uint4 en = s_qp[q];
+            const uint32_t le = en.x & 0x7FFFFFFFu;
+            s_cnt[le] = pack_cnt(ptrs_resolve(__uint_as_float(en.y), g_begin * 4u + le, rng, (en.x >> 31) != 0u, en.z, en.w), en.w);
         }
         __syncthreads();
     }
@@ -351,14 +388,21 @@ __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a)
         float y[4] = {0.f, 0.f, 0.f, 0.f};
         if (!do_pois || !(flags & ELD_SHOT_POISSON) || DEBUG) load_y4<VEC>(a, in_off, e0, nvalid, y);
         float4 cnt4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (do_pois) cnt4 = *reinterpret_cast<const float4*>(&s_cnt[le0]);
+        uint4 cw = make_uint4(0, 0, 0, 0);
+        if (do_pois) {
+            cw = *reinterpret_cast<const uint4*>(&s_cnt[le0]);
+            cnt4 = make_float4((float)(cw.x >> 9), (float)(cw.y >> 9), (float)(cw.z >> 9), (float)(cw.w >> 9));
+        }
+        // full model: the quantisation uniform is made of bits the other draws leave over (low 9 of the Tukey-lambda word, low 9 of the
+        // Poisson V word: u01 uses w >> 9) -- 18 bits, one Philox call per 4 pixels saved
+        const bool uq_borrow = do_pois && (flags & ELD_READ_TL) && (flags & ELD_QUANT);
 
         // one Philox call per needed stream per group
         uint4 w_tl, w_q;
         float nrd[4], nsh[4];
         if (!inject) {
             if (flags & ELD_READ_TL) w_tl = (ELD_DBG(a) & 8) ? make_uint4(g, g * 3u, g * 5u, g * 7u) : rng.words(g, STREAM_TL);
-            if (flags & ELD_QUANT) w_q = (ELD_DBG(a) & 8) ? make_uint4(g, g * 3u, g * 5u, g * 7u) : rng.words(g, STREAM_QUANT);
+            if ((flags & ELD_QUANT) && !uq_borrow) w_q = (ELD_DBG(a) & 8) ? make_uint4(g, g * 3u, g * 5u, g * 7u) : rng.words(g, STREAM_QUANT);
             if (flags & ELD_READ_GAUSS) {
                 const uint4 w = rng.words(g, STREAM_NREAD);
                 const float2 p0 = box_muller(w.x, w.y), p1 = box_muller(w.z, w.w);
@@ -418,7 +462,9 @@ __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a)
                 zz = zz + v_nrow * P.row_scale;
             }
             if (flags & ELD_QUANT) {
-                v_uq = inject ? a.inject[ELD_PLANE_UQ * a.total + ge] : u01_co(pick(w_q, j));
+                if (inject) v_uq = a.inject[ELD_PLANE_UQ * a.total + ge];
+                else if (uq_borrow) v_uq = (float)(((pick(w_tl, j) & 511u) << 9) | (pick(cw, j) & 511u)) * 0x1p-18f;
+                else v_uq = u01_co(pick(w_q, j));
                 zz = zz + (v_uq - 0.5f) * P.q_step;
             }
             if (flags & ELD_CBIAS) {

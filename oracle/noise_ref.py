@@ -243,7 +243,7 @@ def _pois_logpmf(k, lam, loglam):
     return np.where(k < F32(0.5), -lam, v).astype(F32)
 
 
-POIS_SMALL = 10.0   # same regime split as NumPy's legacy sampler (inversion below, PTRS above)
+POIS_SMALL = 32.0   # below: alias table of Poisson(floor(lam)) + inversion at the fractional rate; at or above: PTRS (valid from 10)
 POIS_KMAX = 96
 
 
@@ -256,7 +256,7 @@ def poisson_lambda_fast(y, p):
 
 
 def _pois_inversion(lam, u):
-    """lam < 10: CDF inversion by sequential search with one uniform (float32), in the form the kernel uses:
+    """CDF inversion by sequential search with one uniform (float32), in the form the kernel uses (rates below 1 there):
     r = u - p0; while r > 0: k += 1; p *= lam * fp32(1/k); r -= p."""
     lam = np.asarray(lam, F32)
     p = np.exp(-lam).astype(F32)
@@ -305,14 +305,53 @@ def _ptrs_attempt(lam, U01, V):
     return k.astype(np.int32), ok
 
 
+_ALIAS = None
+
+
+def _alias_tables():
+    global _ALIAS
+    if _ALIAS is None:
+        from . import gen_poisson_alias
+        _ALIAS = gen_poisson_alias.tables()
+    return _ALIAS
+
+
+def _pois_table(lam, wu, wv, elem, seed, sample_id):
+    """lam < 32 (eld_amd/csrc/noise.hip phase 1): X = A_n(wu) + Inv(lam - n, u01(wv)), n = floor(lam).  A_n: alias table of
+    Poisson(n) (oracle/gen_poisson_alias.py) indexed by the top 6 bits of the word, accept test on the low 26; outcome 63 is
+    the tail {X >= 63}, finished by inversion from 63 with word x of retry call 64 of the element."""
+    ent, q0 = _alias_tables()
+    lam = np.asarray(lam, F32)
+    n = lam.astype(np.int32)
+    d = (lam - n.astype(F32)).astype(F32)
+    wu = np.asarray(wu, np.uint32)
+    j = (wu >> np.uint32(26)).astype(np.int64)
+    e = ent[n, j]
+    k0 = np.where((wu << np.uint32(6)) < (e & np.uint32(0xFFFFFFC0)), j, (e & np.uint32(63)).astype(np.int64)).astype(np.int32)
+    t = np.nonzero(k0 == 63)[0]
+    if t.size:
+        words = px.sampler_words(elem[t].astype(np.uint32), sample_id, px.STREAM_POIS_R, seed, it=np.uint32(64))
+        u = px.u01(words[0])
+        for i, idx in enumerate(t):
+            q = F32(q0[n[idx]])
+            r = F32(u[i] - q)
+            k = 63
+            while r > 0 and k < 255:
+                k += 1
+                q = F32(q * F32(F32(n[idx]) / F32(k)))
+                r = F32(r - q)
+            k0[idx] = k
+    return k0 + _pois_inversion(d, px.u01(wv))
+
+
 def _poisson_philox(lam, wu, wv, elem, seed, sample_id):
-    """Poisson counts under the sampler's word usage.  lam < 10: inversion with u01(wu).  Otherwise PTRS: attempt 0
-    takes U = u01(wu), V = u01(wv) (streams POIS_U / POIS_V, group e//4, word e%4); attempts 2k+1, 2k+2 take words
-    (x,y), (z,w) of the per-element retry call k (stream POIS_R, index = element, iter = k)."""
+    """Poisson counts under the sampler's word usage (wu / wv: streams POIS_U / POIS_V, group e//4, word e%4).
+    lam < 32: alias table + fractional-rate inversion (_pois_table).  Otherwise PTRS: attempt 0 takes U = u01(wu), V = u01(wv);
+    attempts 2k+1, 2k+2 take words (x,y), (z,w) of the per-element retry call k (stream POIS_R, index = element, iter = k)."""
     n = lam.size
     k_out = np.zeros(n, np.int32)
     small = lam < F32(POIS_SMALL)
-    k_out[small] = _pois_inversion(lam[small], px.u01(wu[small]))
+    k_out[small] = _pois_table(lam[small], wu[small], wv[small], elem[small], seed, sample_id)
     idx = np.nonzero(~small)[0]
     if idx.size == 0:
         return k_out
@@ -353,7 +392,12 @@ def philox_variates(shape, p, flags, seed, sample_id, y=None):
         w = group_words(px.STREAM_TL)
         out['t_tl'] = _tl_from_uv(px.u01(w), px.u01(~w), p['tl_lambda']).reshape(shape)
     if flags & QUANT:
-        out['u_q'] = px.u01_closed_open(group_words(px.STREAM_QUANT)).reshape(shape)
+        if (flags & READ_TL) and (flags & SHOT_POISSON):
+            # full model: 18 leftover bits -- low 9 of the Tukey-lambda word, low 9 of the Poisson V word (u01 takes w >> 9)
+            bits = ((group_words(px.STREAM_TL) & np.uint32(511)) << np.uint32(9)) | (group_words(px.STREAM_POIS_V) & np.uint32(511))
+            out['u_q'] = (bits.astype(F32) * F32(2.0 ** -18)).reshape(shape)
+        else:
+            out['u_q'] = px.u01_closed_open(group_words(px.STREAM_QUANT)).reshape(shape)
     for flag, stream, name in ((READ_GAUSS, px.STREAM_NREAD, 'n_read'), (SHOT_GAUSS, px.STREAM_NSHOT, 'n_shot')):
         if flags & flag:
             w = np.stack(px.sampler_words(np.arange(ng, dtype=np.uint32), sample_id, stream, seed), axis=1)

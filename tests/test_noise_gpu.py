@@ -132,7 +132,7 @@ def test_dumped_variates_replay_bit_exact(dev, flags, shape):
 def test_philox_variates_match_oracle(dev):
     """Variates themselves vs the NumPy statement of the same Philox layout: uniforms bit-exact,
     transcendental-derived ones to hardware-intrinsic tolerance, Poisson counts equal except at
-    accept/reject boundaries decided by an ulp."""
+    accept/reject (PTRS) and CDF (fractional-rate inversion) boundaries decided by an ulp of exp / log."""
     shape = (1, 4, 40, 52)
     rng = np.random.default_rng(1)
     y = synth(rng, shape)
@@ -290,6 +290,47 @@ def test_full_size_distribution(dev):
     t = v['t_tl'][0].reshape(-1)[sub].astype(np.float64)
     assert stats.kstest(t, stats.tukeylambda(-0.14285714).cdf).pvalue > 1e-4
     assert stats.kstest(v['u_q'][0].reshape(-1)[sub].astype(np.float64), 'uniform').pvalue > 1e-4
+
+
+def _chi2_poisson(k, lam):
+    from scipy import stats
+    n = k.size
+    lo, hi = int(stats.poisson.ppf(1e-5, lam)), int(stats.poisson.ppf(1 - 1e-5, lam))
+    obs = np.bincount(np.clip(k, lo, hi) - lo, minlength=hi - lo + 1).astype(np.float64)
+    pmf = stats.poisson.pmf(np.arange(lo, hi + 1), lam)
+    pmf[0] += stats.poisson.cdf(lo - 1, lam)
+    pmf[-1] += stats.poisson.sf(hi, lam)
+    keep = pmf * n > 10
+    chi2 = ((obs[keep] - pmf[keep] * n) ** 2 / (pmf[keep] * n)).sum()
+    return chi2, stats.chi2.ppf(1 - 1e-7, keep.sum())
+
+
+def test_poisson_regimes(dev):
+    """Every route of the Poisson draw has the Poisson law and the oracle's counts: alias table + fractional inversion just below
+    32, PTRS inline where a whole wave is above 32, PTRS through the queue where few lanes are (checkerboard of a small and a
+    large rate, one pixel in eight large), and large rates (K = 0.1: lam up to 1558)."""
+    shape = (1, 4, 256, 256)
+    flags = O.SHOT_POISSON | O.READ_GAUSS
+    sat = 15583.0
+    for lam_big, lam_small, every in [(31.9, 31.9, 1), (33.0, 33.0, 1), (200.0, 200.0, 1), (1500.0, 1500.0, 1), (40.0, 2.0, 8), (50.0, 0.5, 2)]:
+        # y * (S / ratio / K) = lam: choose ratio = 100, K so that y = 1 gives lam_big
+        ratio = 100.0
+        K = float(np.float32(sat / ratio / lam_big))
+        p = P(K=K, g=1.0, sat=sat, ratio=ratio)
+        y = np.full(shape, np.float32(lam_small / lam_big), np.float32)
+        big = np.zeros(shape, bool)
+        big.reshape(-1)[::every] = True
+        y[big] = 1.0
+        _, v = run(y, [p], flags, seed=7, ids=[31], dump=True)
+        lam = O.poisson_lambda_fast(y[0], OP(p))
+        cnt = v['counts'][0].astype(np.int64)
+        for sel in ((big[0],) if every == 1 else (big[0], ~big[0])):
+            l = float(lam[sel][0])
+            chi2, lim = _chi2_poisson(cnt[sel], l)
+            assert chi2 < lim, (lam_big, lam_small, every, l, chi2, lim)
+        o = O.philox_variates(shape[1:], OP(p), flags, 7, 31, y=y[0])
+        mism = np.mean(cnt != o['counts'])
+        assert mism < 2e-3, (lam_big, lam_small, every, mism)
 
 
 def test_gaussian_terms_distribution(dev):

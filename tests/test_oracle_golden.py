@@ -164,3 +164,47 @@ def test_pack_raw_sid_matches_reference_golden(golden_dir):
     d = np.load(os.path.join(golden_dir, 'pack_raw.npz'))
     for n in ('rggb', 'grbg', 'bggr', 'gbrg'):
         assert np.array_equal(O.pack_raw_sid(d[n + '_im'], d[n + '_pattern'], d[n + '_black']), d[n + '_out'])
+
+
+# ------------------------------------------------------------------------------------------ Poisson alias tables (sampler, lam < 32)
+def test_poisson_alias_header_is_generated_and_exact():
+    """eld_amd/csrc/poisson_alias_table.h is what oracle/gen_poisson_alias.py generates, and the distribution each integer table
+    realises equals the Poisson(n) pmf (tail merged into outcome 63) to below 2^-26 per outcome."""
+    import os
+    from scipy import stats
+    from oracle import gen_poisson_alias as G
+    assert open(G.HEADER).read() == G.header_text()
+    ent, q0 = G.tables()
+    assert ent.shape == (32, 64) and ent.dtype == np.uint32
+    for n in range(32):
+        want = stats.poisson.pmf(np.arange(64), n) if n else np.eye(1, 64)[0]
+        want = want.copy()
+        want[63] = stats.poisson.sf(62, n) if n else 0.0
+        got = G.realised_pmf(ent[n])
+        assert np.max(np.abs(got - want)) < 2.0 ** -26, n
+        if n:
+            assert abs(float(q0[n]) - stats.poisson.pmf(63, n) / stats.poisson.sf(62, n)) < 1e-6
+
+
+def test_oracle_table_poisson_is_poisson():
+    """The oracle's statement of the sampler's small-rate draw (alias table + fractional-rate inversion) has the Poisson law:
+    chi-square at rates either side of the integer grid, 400k draws each from NumPy-generated words."""
+    from scipy import stats
+    from oracle import noise_ref as O
+    rng = np.random.default_rng(11)
+    n = 400_000
+    for lam in (0.0, 0.37, 1.0, 2.5, 9.99, 17.2, 31.999):
+        wu = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+        wv = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+        k = O._pois_table(np.full(n, lam, np.float32), wu, wv, np.arange(n, dtype=np.uint32), 1, 2).astype(np.int64)
+        if lam == 0.0:
+            assert not k.any()
+            continue
+        lo, hi = int(stats.poisson.ppf(1e-5, lam)), int(stats.poisson.ppf(1 - 1e-5, lam))
+        obs = np.bincount(np.clip(k, lo, hi) - lo, minlength=hi - lo + 1).astype(np.float64)
+        pmf = stats.poisson.pmf(np.arange(lo, hi + 1), lam)
+        pmf[0] += stats.poisson.cdf(lo - 1, lam)
+        pmf[-1] += stats.poisson.sf(hi, lam)
+        keep = pmf * n > 10
+        chi2 = ((obs[keep] - pmf[keep] * n) ** 2 / (pmf[keep] * n)).sum()
+        assert chi2 < stats.chi2.ppf(1 - 1e-6, keep.sum()), (lam, chi2)

@@ -3,6 +3,8 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from eld_amd import _lib as L
+if os.environ.get('ELD_DEV_LIB'):          # tools/build_dev.sh: library with the ablation switches (ELD_NOISE_DBG) compiled in
+    L.LIB_PATH = os.environ['ELD_DEV_LIB']
 from eld_amd.noise import NoiseParams, sample_noise, model_flags
 
 def main():
