@@ -96,7 +96,12 @@ int x3_slab_bn(int Nout);
 // bytes of one packed layer in slab layout: 9 taps x Nout x K/16 rows of 112 B
 __host__ __device__ inline size_t x3_slab_stride(int BN) { return (size_t)(3 * BN * 112 + 1023) / 1024 * 1024; }      // bytes of one (ky, chunk, channel-block) slab
 void conv_x3_set_prof(unsigned long long* buf);      // dev tool: 8 workgroups x 4 waves x 128 stages x 6 stamps
-int launch_conv_x3_gemm(const ConvArgs& a, int mode, hipStream_t st);      // transposed-conv directions; ELD_ENOTSUP if not covered
+int launch_conv_x3_gemm(const ConvArgs& a, int mode, hipStream_t st);
+// bf16 3x3 layers with Nout % 64 == 0 and K % 32 == 0 run on conv_bfd_kernel (conv_bfd.hip: both operands by LDS-DMA) and take their weights in its
+// slab layout; returns the slab's channel-block width BN (64 / 128) or 0 for layers that stay on conv_igemm_kernel<bf16_t>
+int bfd_slab_bn(int Nout, int K);
+__host__ __device__ inline size_t bfd_slab_bytes(int BN) { return (size_t)3 * BN * 64; }
+int launch_conv_bfd(const ConvArgs& a, hipStream_t st);      // transposed-conv directions; ELD_ENOTSUP if not covered
 
 // dW-type reduction:  P[tap][i][j] = sum_pixels G[pixel][i] * X[pixel (+) tap][j]
 struct WgradArgs {

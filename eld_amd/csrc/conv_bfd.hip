@@ -1,0 +1,354 @@
+// conv_bfd.hip -- bf16 3x3 convolution (forward and backward-data) with BOTH operands staged by LDS-DMA, gfx950.
+//
+// Same contract as conv_igemm_kernel<bf16_t, CONV_3X3, ...> (conv_igemm.hip): bf16 NHWC activations, packed bf16 weights, fp32
+// accumulation on v_mfma_f32_32x32x16_bf16, bias / LeakyReLU / slope epilogues in fp32, bf16 results -- BASELINE.json configs[2]
+// ("bf16 U-Net with MFMA convs"), replacing nn.Conv2d(3x3, p=1) + max(0.2x, x) of models/arch/Unet.py:11-46,102-104 and its autograd
+// backward-data.  What differs from the register-staged kernel is how operands reach LDS:
+//
+//   * bf16 operands need no conversion on the way in, so neither the activation halo tile nor the weight slab touches a VGPR or the
+//     VALU: every 16-byte unit travels HBM/L2 -> LDS with buffer_load_dwordx4 ... lds (one wave instruction = 1 KiB, lane l lands at
+//     LDS base + 16 l).  The landing order is linear, so the LDS layout is chosen by WHICH unit a lane fetches:
+//         unit (pixel P, channel octet o of the 32-channel chunk)  ->  16-byte slot 4 P + (o ^ f),   f = (column >> 2) & 3
+//     (column = halo column for activations, slab row for weights).  With that XOR the 16 lanes a ds_read_b128 services together
+//     (lanes {0-3,12-15,20-27}, ...: MI355X_MICROARCH.md, LDS) fall on 16 distinct slots of the 256-byte bank row for every tap
+//     shift: conflict-free fragment reads without padding.  Zero padding of the image border = out-of-range buffer offsets.
+//   * weights are packed once per step as the exact LDS image of a stage's slab (bfd_store, unet_misc.hip):
+//         slab(ky, chunk, nb) = [kx 0..2][n 0..BN)[4 units, swizzled]   = 3*BN*64 B at ((ky * K/32 + chunk) * Nout/BN + nb) * 3*BN*64
+//   * stage = (32-channel chunk, kernel row ky): one barrier per stage.  A stage is only 48 MFMAs per wave (~1.5 us), shorter than a
+//     DMA round trip under load (~2.7 us measured), so the weight slabs run TWO stages ahead in a ring of three buffers and the halo
+//     tile of the next chunk / next tile three stages ahead (double buffer).  Each wave waits for its own pieces with a counted
+//     s_waitcnt vmcnt(n), n = the DMA instructions it issued during the previous stage (every wave issues the same number: pieces are
+//     dealt round-robin modulo the piece count, a duplicate piece rewrites identical bytes), then the barrier publishes them.
+//     3 x 24 KB (BN = 128) + 2 x 39 KB (18 x 34 pixel halo, 64 B per pixel) = 150 KB, one 8-wave workgroup per CU.
+//   * tile = 16 rows x 32 pixels x BN channels; a wave owns 2 rows x BN channels (2 x 4 accumulator tiles): each k-block reads
+//     2 + 4 fragments for 8 MFMAs -> 36 KB of LDS reads per wave and stage against 48 x 32 matrix-pipe cycles (LDS 256 B/clk: 37 %).
+#include <stdlib.h>
+#include "conv.h"
+
+#define TW 32
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// One 1 KiB LDS-DMA piece (see conv_x3.hip::bdma16 for the inline-asm rationale: the compiler would order every later ds_read behind
+// a DMA it knows about; the kernel waits for its own pieces explicitly).
+__device__ __forceinline__ void bfd_dma16(i32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory");
+}
+// wait until at most N of this wave's vector-memory operations are outstanding (they retire in issue order): everything older than the
+// N youngest has landed
+template <int N>
+__device__ __forceinline__ void bfd_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ float hmax1b(float f) {       // max with lane ^ 1 (horizontal neighbour pixel): quad_perm [1,0,3,2]
+    return fmaxf(f, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(f), 0xB1, 0xF, 0xF, true)));
+}
+
+template <int BN, int RPW, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) {
+    constexpr int THREADS = 64 * WAVES;
+    constexpr int TH = WAVES * RPW, NT = BN / 32, HW2 = TW + 2, A_PIX = (TH + 2) * HW2;
+    constexpr int A_UNITS = A_PIX * 4, A_PIECES = (A_UNITS + 63) / 64, A_BYTES = A_PIECES * 1024;
+    constexpr int B_UNITS = 3 * BN * 4, B_PIECES = B_UNITS / 64, B_BYTES = B_PIECES * 1024;
+    constexpr int A_IT = (A_PIECES + WAVES - 1) / WAVES, B_IT = (B_PIECES + WAVES - 1) / WAVES;
+    static_assert(B_UNITS % 64 == 0, "slab = whole DMA pieces");
+    constexpr int NBB = 3;                                               // weight-slab ring
+    extern __shared__ __attribute__((aligned(16))) char lds[];           // [B0][B1][B2][A0][A1]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31, hi = lane >> 5;
+    const int NB = a.Nout / BN;
+    const int Cin = a.C0 + a.C1, NCH = Cin >> 5, NCH0 = a.C0 >> 5;
+    const int total_tiles = a.tiles_x * a.tiles_y * a.N * NB;
+    const int Cs0 = a.C0;                                                 // channels per source tensor (C1 == C0 or 0)
+
+    const unsigned lds_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(__attribute__((address_space(3))) char*)lds);
+    const unsigned ldsB_addr = lds_base, ldsA_addr = lds_base + NBB * B_BYTES;
+    const unsigned long long wbase = (unsigned long long)a.wp;
+    const i32x4 rsrc_w = {(int)(unsigned)wbase, (int)((unsigned)(wbase >> 32) & 0xFFFFu), (int)((size_t)3 * NCH * NB * B_BYTES), 0x00020000};
+    const unsigned dma_voff = (unsigned)lane * 16u;
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+
+    // ---- activation DMA: which (halo pixel, octet) lands in this lane's slot of piece wave + it*WAVES ----------------------------
+    int a_hy[A_IT], a_hx[A_IT];            // halo coordinates - 1 (image offsets relative to the tile origin); hy < -1: no unit
+    unsigned a_oct[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int piece = (wave + it * WAVES) % A_PIECES;                 // every wave issues A_IT pieces (a duplicate rewrites the same bytes)
+        const int u = piece * 64 + lane;
+        const int P = u >> 2;
+        const int hr = P / HW2, hc = P - hr * HW2;
+        a_hy[it] = u < A_UNITS ? hr - 1 : -1000;
+        a_hx[it] = hc - 1;
+        a_oct[it] = (unsigned)((u & 3) ^ ((hc >> 2) & 3)) * 16u;
+    }
+    unsigned a_voff[A_IT];
+    int l_img = 0;
+    auto decode = [&](int t, int& nb, int& img, int& y0, int& x0) {
+        nb = t % NB;
+        int r = t / NB;
+        const int tx = r % a.tiles_x;
+        r /= a.tiles_x;
+        const int ty = r % a.tiles_y;
+        img = r / a.tiles_y;
+        y0 = ty * TH; x0 = tx * TW;
+    };
+    auto setup_load = [&](int t) {
+        int nb, y0, x0;
+        decode(t, nb, l_img, y0, x0);
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int gy = y0 + a_hy[it], gx = x0 + a_hx[it];
+            const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            a_voff[it] = ok ? (unsigned)(gy * a.W + gx) * (unsigned)(Cs0 * 2) + a_oct[it] : OOB;
+        }
+    };
+    auto dma_A = [&](int buf, int chunk) {
+        const char* src = static_cast<const char*>(chunk < NCH0 ? a.in0 : a.in1);
+        const int cs = chunk < NCH0 ? chunk : chunk - NCH0;
+        const size_t img_bytes = (size_t)a.H * a.W * Cs0 * 2;
+        const unsigned long long ab = (unsigned long long)(src + (size_t)l_img * img_bytes);
+        const i32x4 rsrc_a = {(int)(unsigned)ab, (int)((unsigned)(ab >> 32) & 0xFFFFu), (int)img_bytes, 0x00020000};
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int piece = (wave + it * WAVES) % A_PIECES;            // wave-uniform
+            bfd_dma16(rsrc_a, a_voff[it], (unsigned)(cs * 64), ldsA_addr + (unsigned)(buf * A_BYTES + piece * 1024));
+        }
+    };
+    auto dma_B = [&](int buf, int nb, int chunk, int ky) {
+        const unsigned soff = (unsigned)(((ky * NCH + chunk) * NB + nb) * B_BYTES);
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int piece = (wave + it * WAVES) % B_PIECES;
+            bfd_dma16(rsrc_w, dma_voff, soff + (unsigned)(piece * 1024), ldsB_addr + (unsigned)(buf * B_BYTES + piece * 1024));
+        }
+    };
+
+    // ---- fragment addresses: per lane, per (kx, k-block); rows / taps / buffers are uniform or immediate offsets ---------------
+    unsigned fx_off[3][2], fw_off[2];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int hc = m + kx;
+            fx_off[kx][kb] = (unsigned)(hc * 64 + (((kb * 2 + hi) ^ ((hc >> 2) & 3)) * 16));
+        }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) fw_off[kb] = (unsigned)(m * 64 + (((kb * 2 + hi) ^ ((m >> 2) & 3)) * 16));
+    const char* ldsA = lds + NBB * B_BYTES;
+    const char* ldsB = lds;
+
+    int t = blockIdx.x;
+    if (t >= total_tiles) return;
+    setup_load(t);
+    int bufA = 0, bufB = 0;
+    // slab of the stage `ahead` stages after (chunk, ky) of tile (nb, t_next): crosses chunk and tile boundaries; false at the end of the work
+    auto dma_B_ahead = [&](int buf, int nb, int chunk, int ky, int ahead, int t_next) -> bool {
+        const int q = chunk * 3 + ky + ahead;
+        if (q < 3 * NCH) { dma_B(buf, nb, q / 3, q % 3); return true; }
+        if (t_next < total_tiles) { const int q2 = q - 3 * NCH; dma_B(buf, t_next % NB, q2 / 3, q2 % 3); return true; }
+        return false;
+    };
+    int young;                                   // DMA instructions this wave issued during the previous stage; < 0: wait for everything
+    {
+        int nb0, i0, y00, x00;
+        decode(t, nb0, i0, y00, x00);
+        dma_A(0, 0);
+        dma_B(0, nb0, 0, 0);
+        young = dma_B_ahead(1, nb0, 0, 0, 1, t + (int)gridDim.x) ? B_IT : 0;
+    }
+    for (;;) {
+        int nb, img, y0, x0;
+        decode(t, nb, img, y0, x0);
+        const int t_next = t + gridDim.x;
+        f32x16 acc[RPW][NT];
+#pragma unroll
+        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[r][tt][i] = 0.f;
+
+        for (int chunk = 0; chunk < NCH; ++chunk) {
+            const bool last_chunk = chunk + 1 >= NCH;
+#pragma unroll 1
+            for (int ky = 0; ky < 3; ++ky) {
+                __builtin_amdgcn_s_setprio(3);
+                // this wave's pieces of THIS stage's operands have landed (the younger ones, for later stages, may still fly)
+                if (young == B_IT) bfd_wait_vm<B_IT>();
+                else if (young == B_IT + A_IT) bfd_wait_vm<B_IT + A_IT>();
+                else bfd_wait_vm<0>();
+                __syncthreads();                 // ... and everybody else's; the previous stage's fragment reads are done
+                int issued = 0;
+                int b2 = bufB + 2; if (b2 >= NBB) b2 -= NBB;
+                if (dma_B_ahead(b2, nb, chunk, ky, 2, t_next)) issued += B_IT;
+                if (ky == 0) {                   // the halo tile of the next chunk / next tile has three stages to arrive
+                    if (!last_chunk) { dma_A(bufA ^ 1, chunk + 1); issued += A_IT; }
+                    else if (t_next < total_tiles) { setup_load(t_next); dma_A(bufA ^ 1, 0); issued += A_IT; }
+                }
+                young = issued == 0 ? -1 : issued;
+                __builtin_amdgcn_s_setprio(0);
+                const char* la = ldsA + bufA * A_BYTES + (wave * RPW + ky) * (HW2 * 64);
+                const char* lb = ldsB + bufB * B_BYTES;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        uint4 fx[RPW], fw[NT];
+#pragma unroll
+                        for (int r = 0; r < RPW; ++r) fx[r] = *reinterpret_cast<const uint4*>(la + r * (HW2 * 64) + fx_off[kx][kb]);
+#pragma unroll
+                        for (int tt = 0; tt < NT; ++tt) fw[tt] = *reinterpret_cast<const uint4*>(lb + (kx * BN + tt * 32) * 64 + fw_off[kb]);
+#pragma unroll
+                        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                            for (int tt = 0; tt < NT; ++tt)
+                                acc[r][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[tt]), __builtin_bit_cast(bf16x8, fx[r]),
+                                                                                     acc[r][tt], 0, 0, 0);      // D[channel][pixel]
+                    }
+                if (++bufB >= NBB) bufB = 0;
+            }
+            bufA ^= 1;
+        }
+
+        // ---- epilogue: lane (m, hi) owns pixel x0 + m and channels 8q + 4hi .. +3 of each 32-block (as conv_igemm.hip) -------------
+        {
+            const int x = x0 + m;
+            const bool xok = x < a.W;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int y = y0 + wave * RPW + r;
+                if (y >= a.H || !xok) continue;
+                const size_t pix = (size_t)(img * a.H + y) * a.W + x;
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) {
+                    const int nbase = nb * BN + tt * 32 + 4 * hi;
+                    float4 v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = make_float4(acc[r][tt][4 * q], acc[r][tt][4 * q + 1], acc[r][tt][4 * q + 2], acc[r][tt][4 * q + 3]);
+                    bf16_t* dst[4];
+                    if (a.epi == EPI_FWD) {
+                        float4 bs[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) bs[q] = *reinterpret_cast<const float4*>(a.bias + nbase + 8 * q);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            v[q].x += bs[q].x; v[q].y += bs[q].y; v[q].z += bs[q].z; v[q].w += bs[q].w;
+                            if (a.lrelu) {
+                                v[q].x = fmaxf(0.2f * v[q].x, v[q].x); v[q].y = fmaxf(0.2f * v[q].y, v[q].y);
+                                v[q].z = fmaxf(0.2f * v[q].z, v[q].z); v[q].w = fmaxf(0.2f * v[q].w, v[q].w);
+                            }
+                            dst[q] = static_cast<bf16_t*>(a.out0) + pix * a.Nout + nbase + 8 * q;
+                        }
+                    } else {
+                        float4 s[4];
+                        bool has[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int n = nbase + 8 * q;
+                            const bool lo = n < a.split;
+                            const int C = lo ? a.split : a.Nout - a.split;
+                            const size_t idx = pix * C + (lo ? n : n - a.split);
+                            dst[q] = static_cast<bf16_t*>(lo ? a.out0 : a.out1) + idx;
+                            const bf16_t* act = static_cast<const bf16_t*>(lo ? a.act0 : a.act1);
+                            has[q] = act != nullptr;
+                            s[q] = make_float4(1.f, 1.f, 1.f, 1.f);
+                            if (has[q]) s[q] = unpack_bf4(*reinterpret_cast<const uint2*>(act + idx));
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (has[q]) {
+                                v[q].x *= lrelu_slope(s[q].x); v[q].y *= lrelu_slope(s[q].y);
+                                v[q].z *= lrelu_slope(s[q].z); v[q].w *= lrelu_slope(s[q].w);
+                            }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(v[q].x), "+v"(v[q].y), "+v"(v[q].z), "+v"(v[q].w));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(dst[q]) = pack_bf4(v[q]);
+                }
+            }
+            // fused nn.MaxPool2d(2) (Unet.py:51-63): vertical pair in the lane's own rows, horizontal pair in lane ^ 1; pooled from the
+            // bf16-ROUNDED values (max commutes with the monotone rounding, so this equals pooling the stored tensor)
+            if (a.epi == EPI_FWD && a.pool_out != nullptr && xok) {
+                const int Hp = a.H >> 1, Wp = a.W >> 1;
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) {
+                    const int nbase = nb * BN + tt * 32 + 4 * hi;
+                    float4 bs[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bs[q] = *reinterpret_cast<const float4*>(a.bias + nbase + 8 * q);
+#pragma unroll
+                    for (int rp = 0; rp < RPW / 2; ++rp) {
+                        const int y = y0 + wave * RPW + 2 * rp;
+                        if (y >= a.H) continue;
+                        uint2 pk[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float bq[4] = {bs[q].x, bs[q].y, bs[q].z, bs[q].w};
+                            float u[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                float p0 = acc[2 * rp][tt][4 * q + j] + bq[j], p1 = acc[2 * rp + 1][tt][4 * q + j] + bq[j];
+                                if (a.lrelu) { p0 = fmaxf(0.2f * p0, p0); p1 = fmaxf(0.2f * p1, p1); }
+                                u[j] = hmax1b(fmaxf(p0, p1));
+                            }
+                            pk[q] = pack_bf4(make_float4(u[0], u[1], u[2], u[3]));
+                        }
+                        if (!(x & 1)) {
+                            bf16_t* dp = static_cast<bf16_t*>(a.pool_out) + ((size_t)(img * Hp + (y >> 1)) * Wp + (x >> 1)) * a.Nout + nbase;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(dp + 8 * q) = pk[q];
+                        }
+                    }
+                }
+            }
+        }
+        young = -1;                              // the epilogue's stores are younger than the DMAs in flight: the next stage waits for all of them
+        if (t_next >= total_tiles) break;
+        t = t_next;
+    }
+}
+
+template <int BN, int RPW, int WAVES>
+int launch_bfd(ConvArgs a, hipStream_t st) {
+    constexpr int TH = WAVES * RPW;
+    a.tiles_x = (a.W + TW - 1) / TW;
+    a.tiles_y = (a.H + TH - 1) / TH;
+    constexpr size_t A_BYTES = (size_t)(((TH + 2) * (TW + 2) * 4 + 63) / 64) * 1024, B_BYTES = (size_t)3 * BN * 64;
+    const size_t lds_bytes = 2 * A_BYTES + 3 * B_BYTES;
+    const long long tiles = (long long)a.tiles_x * a.tiles_y * a.N * (a.Nout / BN);
+    if (tiles <= 0) return 0;
+    if (tiles > 0x7fffffffLL) return ELD_ENOTSUP;
+    auto kern = conv_bfd_kernel<BN, RPW, WAVES>;
+    static EldAttrOnce once;
+    { const int rc = once.ensure(kern, lds_bytes); if (rc) return rc; }
+    long long grid = (long long)eld_num_cus();
+    if (grid > tiles) grid = tiles;
+    ELD_LAUNCH(kern, dim3((unsigned)grid), dim3(64 * WAVES), lds_bytes, st, a);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+// Layers the DMA kernel takes: bf16 3x3 with GEMM N (Nout) a multiple of 64 and K a multiple of 32; returns the slab's channel-block
+// width BN (what the pack kernel must lay the weights out for), or 0 for layers that stay on conv_igemm_kernel<bf16_t>.
+int bfd_slab_bn(int Nout, int K) {
+    if (K % 32 || Nout % 64) return 0;
+    return Nout % 128 == 0 ? 128 : 64;
+}
+
+// a: bf16 CONV_3X3 arguments already validated by launch_conv; weights in slab layout
+int launch_conv_bfd(const ConvArgs& a, hipStream_t st) {
+    if ((size_t)a.H * a.W * a.C0 * 2 >= 0xFFFFFFF0ull) return ELD_ENOTSUP;
+    if (a.pool_out && (a.epi != EPI_FWD || (a.H & 1) || (a.W & 1))) return ELD_EINVAL;
+    const int bn = bfd_slab_bn(a.Nout, a.C0 + a.C1);
+    if (bn == 128) return launch_bfd<128, 2, 8>(a, st);
+    if (bn == 64) return launch_bfd<64, 2, 8>(a, st);
+    return ELD_ENOTSUP;
+}

@@ -432,7 +432,10 @@ int launch_conv(const ConvArgs& a_in, int mode, hipStream_t st) {
     if (a.C1 != 0 && a.C1 != a.C0) return ELD_ENOTSUP;          // virtual concat of two equally wide tensors (all the U-Net needs)
     if (a.epi == EPI_GRAD && (a.split % 32)) return ELD_EINVAL;
     if (a.epi == EPI_CONVT_FWD && (a.Cout_t % 4)) return ELD_EINVAL;
-    if (a.dtype == DT_BF16) return a.pool_out ? ELD_ENOTSUP : launch_dt<bf16_t>(a, mode, st);
+    if (a.dtype == DT_BF16) {
+        if (mode == CONV_3X3 && a.epi != EPI_CONVT_FWD && bfd_slab_bn(a.Nout, Cin)) return launch_conv_bfd(a, st);      // weights in slab layout
+        return a.pool_out ? ELD_ENOTSUP : launch_dt<bf16_t>(a, mode, st);
+    }
     const int algo = resolve_algo(a.algo);
     if (a.pool_out && !(mode == CONV_3X3 && a.epi == EPI_FWD && algo == 1 && a.dtype == DT_F32)) return ELD_ENOTSUP;     // fused pooling: conv_x3.hip only
     if (mode == CONV_3X3 && a.epi != EPI_CONVT_FWD && algo == 1) return launch_conv_x3(a, st);

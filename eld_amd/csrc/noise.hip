@@ -172,6 +172,19 @@ __device__ __noinline__ int pois_tail_res(float d, float p, float r) {
 // Poisson count and the 9 spare bits of the V word share an LDS word (counts stay far below 2^23: beyond that float32 PTRS has no integer resolution)
 __device__ __forceinline__ uint32_t pack_cnt(float k, uint32_t wv) { return ((uint32_t)fminf(k, 8388607.0f) << 9) | (wv & 511u); }
 
+// a / b rounded to nearest, bit for bit what NumPy's float32 division gives, for a divisor that is constant over the image:
+// rb = RN(1 / b) (one IEEE division per wave) and two Markstein refinements -- q0 = RN(a rb); r = a - b q (exact, FMA); q' = RN(q + r rb).
+// After the first step q is a faithful quotient, after the second it is the correctly rounded one (Markstein 1990; Muller et al.,
+// Handbook of Floating-Point Arithmetic, sec. 4.7) provided nothing underflows: operands below 2^-100 take the hardware sequence.
+// 5 full-rate ops instead of ~11 (v_div_scale x2, v_rcp, 4 FMA, v_div_fmas, v_div_fixup) -- these two divisions were a third of
+// the streaming models' VALU work.
+__device__ __forceinline__ float div_rn(float a, float b, float rb) {
+    if (__builtin_expect(fabsf(a) < 0x1p-100f && a != 0.f, 0)) return a / b;
+    const float q0 = a * rb;
+    const float q1 = __builtin_fmaf(__builtin_fmaf(-b, q0, a), rb, q0);
+    return __builtin_fmaf(__builtin_fmaf(-b, q1, a), rb, q1);
+}
+
 __device__ __forceinline__ uint32_t pick(const uint4& w, int j) { return j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w; }
 
 __device__ __forceinline__ float row_normal(uint32_t srow, const SamplerRng& rng) {
@@ -376,17 +389,18 @@ __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a)
 
     // ================================ phase 3: the rest of the model + reference arithmetic ===================
     const float g_sigma = fmaxf(P.g_scale, 1e-10f);
+    const float r_ratio = 1.0f / ratio, r_S = 1.0f / S;          // correctly rounded reciprocals (IEEE division, once per wave)
     const float inv_tl_lambda = P.tl_lambda != 0.f ? 1.0f / P.tl_lambda : 0.f;
-#pragma unroll 1
-    for (int it = 0; it < NOISE_ITERS; ++it) {
+    auto phase3 = [&](int it, const float* ypre) {      // ypre: the group's input, already loaded (streaming models), or null
         const uint32_t g = g_begin + it * NOISE_THREADS + tid;
-        if (g >= g_end) break;
+        if (g >= g_end) return;
         const uint32_t e0 = g * 4u;
         const uint32_t nvalid = VEC ? 4u : min(4u, a.chw - e0);
         const uint32_t le0 = (uint32_t)it * (NOISE_THREADS * 4u) + tid * 4u;
 
         float y[4] = {0.f, 0.f, 0.f, 0.f};
-        if (!do_pois || !(flags & ELD_SHOT_POISSON) || DEBUG) load_y4<VEC>(a, in_off, e0, nvalid, y);
+        if (ypre) { y[0] = ypre[0]; y[1] = ypre[1]; y[2] = ypre[2]; y[3] = ypre[3]; }
+        else if (!do_pois || !(flags & ELD_SHOT_POISSON) || DEBUG) load_y4<VEC>(a, in_off, e0, nvalid, y);
         float4 cnt4 = make_float4(0.f, 0.f, 0.f, 0.f);
         uint4 cw = make_uint4(0, 0, 0, 0);
         if (do_pois) {
@@ -434,7 +448,7 @@ __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a)
                 zz = v_cnt * K;
             } else {
                 const float y1 = y[j] * S;        // noise.py:155
-                const float y2 = y1 / ratio;      // noise.py:156
+                const float y2 = div_rn(y1, ratio, r_ratio);      // noise.py:156  (y1 / ratio, correctly rounded)
                 if (flags & ELD_SHOT_GAUSS) {     // noise.py:160-161
                     v_nshot = inject ? a.inject[ELD_PLANE_NSHOT * a.total + ge] : nsh[j];
                     zz = y2 + v_nshot * __builtin_sqrtf(fmaxf(K * y2, 1e-10f));
@@ -472,7 +486,7 @@ __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a)
                 zz = zz + P.color_bias[c & 3u];
             }
             zz = zz * ratio;                      // noise.py:168
-            zz = zz / S;                          // noise.py:169
+            zz = div_rn(zz, S, r_S);              // noise.py:169  (zz / S, correctly rounded)
             if (flags & ELD_CLIP) zz = fmaxf(fminf(zz, 1.0f), 0.0f);   // sid_dataset.py:277
             z[j] = zz;
 
@@ -487,11 +501,49 @@ __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a)
         }
 
         if (VEC) {
-            *reinterpret_cast<float4*>(a.out + out_off + e0) = make_float4(z[0], z[1], z[2], z[3]);
+            // written once, never read again by this kernel: nontemporal (streaming) store keeps the output out of the L2's way
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store((f4v){z[0], z[1], z[2], z[3]}, reinterpret_cast<f4v*>(a.out + out_off + e0));
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if ((uint32_t)j < nvalid) a.out[out_off + e0 + j] = z[j];
+        }
+    };
+    if constexpr (MAYBE_P) {
+#pragma unroll 1
+        for (int it = 0; it < NOISE_ITERS; ++it) phase3(it, nullptr);
+    } else {                                     // streaming models ('g', 'pg', scale only): all four 16-byte loads of a lane in flight at once
+        float ypre[NOISE_ITERS][4];
+        if constexpr (VEC) {
+            // branch-free straight-line loads (out-of-range groups re-read the block's last group; their results are dropped): the
+            // four requests of a lane leave back to back instead of load -> wait -> store per group
+            const uint32_t g_last = g_end - 1u;
+            if (a.in_dtype == ELD_IN_U16) {
+                ushort4 q[NOISE_ITERS];
+#pragma unroll
+                for (int it = 0; it < NOISE_ITERS; ++it)
+                    q[it] = *reinterpret_cast<const ushort4*>(static_cast<const uint16_t*>(a.in) + in_off + (size_t)min(g_begin + it * NOISE_THREADS + tid, g_last) * 4u);
+#pragma unroll
+                for (int it = 0; it < NOISE_ITERS; ++it) {
+                    const float v[4] = {(float)q[it].x / 65535.0f, (float)q[it].y / 65535.0f, (float)q[it].z / 65535.0f, (float)q[it].w / 65535.0f};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ypre[it][j] = fminf(fmaxf(v[j], 0.f), 1.f);      // lmdb_dataset.py:39
+                }
+            } else {
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                f4v q[NOISE_ITERS];
+#pragma unroll
+                for (int it = 0; it < NOISE_ITERS; ++it)
+                    q[it] = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(static_cast<const float*>(a.in) + in_off + (size_t)min(g_begin + it * NOISE_THREADS + tid, g_last) * 4u));
+#pragma unroll
+                for (int it = 0; it < NOISE_ITERS; ++it) { ypre[it][0] = q[it][0]; ypre[it][1] = q[it][1]; ypre[it][2] = q[it][2]; ypre[it][3] = q[it][3]; }
+            }
+#pragma unroll
+            for (int it = 0; it < NOISE_ITERS; ++it) phase3(it, ypre[it]);
+        } else {
+#pragma unroll 1
+            for (int it = 0; it < NOISE_ITERS; ++it) phase3(it, nullptr);
         }
     }
 }

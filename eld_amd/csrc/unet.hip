@@ -260,6 +260,8 @@ int pack_weights(const Plan& P, const float* params, float* ws, bool for_backwar
         J.amax_slot = S_W + i;
         // three-piece scheme: 3x3 layers with GEMM N % 64 == 0 get pre-split slabs (N = Cout forward, Cin backward-data)
         J.x3bn = (!bf16 && g_algo == 1 && d.kind == 0) ? x3_slab_bn(for_backward ? d.cin : d.cout) : 0;
+        // bf16: 3x3 layers the DMA kernel takes get its slab layout (GEMM N = Cout forward / Cin backward-data, K the other one)
+        J.bfdbn = (bf16 && d.kind == 0) ? (for_backward ? bfd_slab_bn(d.cin, d.cout) : bfd_slab_bn(d.cout, J.Cinp)) : 0;
         jobs.job[jobs.n++] = J;
     }
     return launch_pack_all(jobs, params, ws, st, amax);

@@ -357,6 +357,18 @@ __device__ __forceinline__ void x3_store(float* dst, int t, int n, int c, int N,
     d[0] = (bf16_t)(x >> 16); d[16] = (bf16_t)(y >> 16); d[32] = (bf16_t)(__float_as_uint(q) >> 16);
 }
 
+// Slab layout of conv_bfd_kernel (conv_bfd.hip): element (tap t, GEMM column n of N, k-channel c of K) of the logical packed weight
+// B[t][n][c] as bf16 at   slab(ky, c/32, n/BN) + slot * 16 B + (c%8) * 2 B,   slot = 4 P + (octet ^ ((P >> 2) & 3)),  P = kx*BN + n%BN,
+// octet = (c%32)/8: the exact (XOR-swizzled) LDS image of a stage's slab, so it travels by linear 1 KiB LDS-DMA pieces.
+__device__ __forceinline__ void bfd_store(float* dst, int t, int n, int c, int N, int K, int BN, float v) {
+    const int NCH = K >> 5, NB = N / BN;
+    const int ky = t / 3, kx = t - 3 * ky;
+    const size_t slab = (size_t)(ky * NCH + (c >> 5)) * NB + n / BN;
+    const int P = kx * BN + (n % BN), o = (c & 31) >> 3;
+    const int slot = 4 * P + (o ^ ((P >> 2) & 3));
+    reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(dst) + slab * bfd_slab_bytes(BN))[slot * 8 + (c & 7)] = f2bf(v);
+}
+
 __global__ void pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int kind, int Cout, int Cin, int Cinp, int T, int x3bn) {
     size_t total;
     if (kind == PACK_CONV_FWD) total = (size_t)T * Cout * Cinp; else total = (size_t)T * Cout * Cin;
@@ -434,7 +446,9 @@ __global__ void pack_all_kernel(const PackJobs jobs, const float* __restrict__ p
         v = src[((size_t)ci * Cout + co) * T + t];
     }
     if (live) {
-        if (J.bf16) reinterpret_cast<bf16_t*>(dst)[i] = f2bf(v);
+        if (J.bf16 && J.bfdbn && J.kind == PACK_CONV_FWD) bfd_store(dst, (int)(i / ((size_t)Cinp * Cout)), (int)((i / Cinp) % Cout), (int)(i % Cinp), Cout, Cinp, J.bfdbn, v);
+        else if (J.bf16 && J.bfdbn && J.kind == PACK_CONV_BWD) bfd_store(dst, (int)(i / ((size_t)Cout * Cin)), (int)((i / Cout) % Cin), (int)(i % Cout), Cin, Cout, J.bfdbn, v);
+        else if (J.bf16) reinterpret_cast<bf16_t*>(dst)[i] = f2bf(v);
         else if (J.x3bn && J.kind == PACK_CONV_FWD) x3_store(dst, (int)(i / ((size_t)Cinp * Cout)), (int)((i / Cinp) % Cout), (int)(i % Cinp), Cout, Cinp, J.x3bn, v);
         else if (J.x3bn && J.kind == PACK_CONV_BWD) x3_store(dst, (int)(i / ((size_t)Cout * Cin)), (int)((i / Cout) % Cin), (int)(i % Cout), Cin, Cout, J.x3bn, v);
         else dst[i] = v;

@@ -168,6 +168,29 @@ def test_gaussian_model_z_parity(dev):
             assert np.max(np.abs(z[i] - zo)) <= 1e-5, (flags, np.max(np.abs(z[i] - zo)))
 
 
+def test_division_is_numpy_division(dev):
+    """The kernel forms y1 / ratio and z / saturation with a reciprocal + two FMA refinements (div_rn); the results must be NumPy's
+    correctly rounded float32 quotients bit for bit: scale-only and Gaussian models (every variate injected) over random inputs,
+    ratios and saturation levels, including awkward divisors (mantissa all ones, powers of two)."""
+    rng = np.random.default_rng(21)
+    shape = (1, 4, 128, 256)
+    n = int(np.prod(shape))
+    divisors = [(15583.0, 208.98), (16383.0, 100.0), (4095.0, 300.0), (float(np.float32(1.9999999)), 127.99999), (1024.0, 256.0), (65535.0, 1.0000001),
+                (float(np.nextafter(np.float32(16384), np.float32(0))), float(np.nextafter(np.float32(128), np.float32(0))))]
+    divisors += [(float(s_), float(r_)) for s_, r_ in zip(rng.uniform(1000, 70000, 12), rng.uniform(50, 400, 12))]
+    for sat, ratio in divisors:
+        y = rng.uniform(0, 1, size=shape).astype(np.float32) ** 3
+        y.reshape(-1)[:8] = [0.0, 1.0, 1e-30, 1e-38, 1e-42, 0.5, 3e-7, 0.999999]
+        p = P(K=1.7, g=3.3, sat=sat, ratio=ratio)
+        for flags in (0, O.SHOT_GAUSS | O.READ_GAUSS):
+            inj = {'n_shot': rng.standard_normal(n).astype(np.float32), 'n_read': rng.standard_normal(n).astype(np.float32)}
+            z = run(y, [p], flags, inject=inj)
+            zo = O.noise_arith(y[0], OP(p), flags, n_shot=inj['n_shot'].reshape(shape[1:]), n_read=inj['n_read'].reshape(shape[1:]))
+            assert np.array_equal(z[0].view(np.uint32), zo.view(np.uint32)), (sat, ratio, flags, int(np.sum(z[0] != zo)))
+        z = run(y, [p], 0)                                                   # production (non-debug) instantiation, scale only
+        assert np.array_equal(z[0].view(np.uint32), O.noise_arith(y[0], OP(p), 0).view(np.uint32)), (sat, ratio)
+
+
 # ------------------------------------------------------------------------------------------ E-3
 def test_determinism_and_shard_invariance(dev):
     rng = np.random.default_rng(3)
