@@ -343,8 +343,9 @@ int unet_forward(const Plan& P, const float* x, const float* prm, float* out, fl
 // bf16 forward (inference): bf16 activations and packed weights, fp32 accumulation / bias; the first layer reads the
 // fp32 NCHW planes and the head writes fp32 NCHW.  Buffers of the fp32 plan are reused (half filled).
 int conv_fwd_bf16(const bf16_t* in0, int C0, const bf16_t* in1, int C1, const bf16_t* wp, const float* bias, bf16_t* out, int N, int H, int W,
-                  int Cout, int lrelu, hipStream_t st) {
+                  int Cout, int lrelu, hipStream_t st, bf16_t* pool_out = nullptr) {
     ConvArgs a = {};
+    a.pool_out = pool_out;
     a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1; a.wp = wp; a.N = N; a.H = H; a.W = W; a.Nout = Cout;
     a.epi = EPI_FWD; a.bias = bias; a.lrelu = lrelu; a.out0 = out; a.dtype = DT_BF16;
     return launch_conv(a, CONV_3X3, st);
@@ -365,8 +366,11 @@ int unet_forward_bf16(const Plan& P, const float* x, const float* prm, float* ou
             RC(launch_conv_first_fwd_bf16(x, prm + A.w_off, prm + A.b_off, B(P.ea[0]), N, P.in_ch, P.H, P.W, 1, st));
         else
             RC(conv_fwd_bf16(B(P.pool[l - 1]), chan(l - 1), nullptr, 0, B(P.wp_fwd[2 * l]), prm + A.b_off, B(P.ea[l]), N, P.Hl[l], P.Wl[l], chan(l), 1, st));
-        RC(conv_fwd_bf16(B(P.ea[l]), chan(l), nullptr, 0, B(P.wp_fwd[2 * l + 1]), prm + Bd.b_off, B(P.eb[l]), N, P.Hl[l], P.Wl[l], chan(l), 1, st));
-        if (l < NLEV - 1) RC(launch_maxpool_fwd_bf16(B(P.eb[l]), B(P.pool[l]), N, P.Hl[l + 1], P.Wl[l + 1], chan(l), st));
+        // layers on the DMA kernel (conv_bfd.hip) write the pooled tensor from their epilogue
+        const bool fuse_pool = l < NLEV - 1 && bfd_slab_bn(chan(l), chan(l)) != 0;
+        RC(conv_fwd_bf16(B(P.ea[l]), chan(l), nullptr, 0, B(P.wp_fwd[2 * l + 1]), prm + Bd.b_off, B(P.eb[l]), N, P.Hl[l], P.Wl[l], chan(l), 1, st,
+                         fuse_pool ? B(P.pool[l]) : nullptr));
+        if (l < NLEV - 1 && !fuse_pool) RC(launch_maxpool_fwd_bf16(B(P.eb[l]), B(P.pool[l]), N, P.Hl[l + 1], P.Wl[l + 1], chan(l), st));
     }
     for (int l = 3; l >= 0; --l) {
         const int iu = L_UP3 + 3 * (3 - l);
