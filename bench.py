@@ -135,6 +135,7 @@ def main():
     ap.add_argument('--width', type=int, default=W_FULL)
     ap.add_argument('--noise', default='PGRU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-alt', action='store_true', help='skip the alt_fp16x2_products leg (profiling runs: only the default kernels in the trace)')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'], help="U-Net precision; the contract's metric is quoted on fp32 (BASELINE configs[1]); bf16 = configs[2]")
     args = ap.parse_args()
 
@@ -253,7 +254,7 @@ def main():
         x3 = args.precision == 'fp32' and eld_amd.load_library().eld_conv_fp32_algo(-1) == 1
         peak = 2500.0 if args.precision == 'bf16' else (PEAK_BF16_MFMA_TF / 6.0 if x3 else PEAK_F32_MFMA_TF)
         res['roofline'] = {'bound': 'mfma', 'kernel': 'U-Net convolution launches of one step (%s), timed as eld_unet_forward + eld_unet_backward' % (
-                               'conv_x3_kernel fwd/bwd-data + wgrad_kernel<ALG_X3>: fp32 operands as 3 bf16 pieces, 6 x v_mfma_f32_32x32x16_bf16 per k-block'
+                               'conv_x3d_kernel / conv_x3_kernel fwd + bwd-data, wgrad8_kernel: fp32 operands as 3 bf16 pieces, 6 x v_mfma_f32_32x32x16_bf16 per k-block'
                                if x3 else 'conv_igemm_kernel fwd/bwd-data + wgrad_kernel'),
                            'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                            'peak_note': ('bf16 dense MFMA peak 2500 TFLOP/s / 6 piece products per fp32 product' if x3 else 'dense MFMA peak of the dtype'),
@@ -261,7 +262,7 @@ def main():
                            'fwd_ms': round(t_f, 3), 'bwd_ms': round(t_b, 3),
                            'fwd_tflops': round(FLOP_FWD_PER_PIX * B * 4.0 * Hh * Ww / (t_f * 1e-3) / 1e12, 2)}
         # one launch of the dominant kernel, timed live: conv7_1's forward (256 -> 128 channels at 1/4 resolution, the step's
-        # median 3x3 layer) through the single-layer entry point -- conv_x3_kernel<64,2> (or conv_igemm_kernel<float,0,64,2>)
+        # median 3x3 layer) through the single-layer entry point -- conv_x3d_kernel<128,2,8> (or conv_igemm_kernel<float,0,64,2>)
         if args.precision == 'fp32' and Hh % 4 == 0 and Ww % 4 == 0:
             lib = eld_amd.load_library()
             h4, w4, ci, co = Hh // 4, Ww // 4, 256, 128
@@ -277,14 +278,14 @@ def main():
             one(); torch.cuda.synchronize()
             t_l = timed_events(one, 5)
             fl = 2.0 * B * h4 * w4 * co * ci * 9
-            res['roofline']['per_launch'] = {'kernel': ('conv_x3_kernel<64, 2, true>' if x3 else 'conv_igemm_kernel<float, 0, 64, 2>') +
+            res['roofline']['per_launch'] = {'kernel': ('conv_x3d_kernel<128, 2, 8>' if x3 else 'conv_igemm_kernel<float, 0, 64, 2>') +
                                              ' (+ its 50 us weight-pack launch): conv7_1 forward, %d x %dx%d, 256 -> 128 channels' % (B, h4, w4),
                                              'algorithmic_gflop': round(fl / 1e9, 1), 'ms': round(t_l, 4), 'achieved': round(fl / (t_l * 1e-3) / 1e12, 2),
                                              'frac': round(fl / (t_l * 1e-3) / 1e12 / peak, 4)}
             del xl, wl, ol, wsl
         # the same step with eld_conv_fp32_algo(2) (two fp16 pieces per operand: 22-bit products, fp32 accumulation), reported
         # beside the default; `value` above stays on the exact three-piece split
-        if args.precision == 'fp32' and world == 1 and x3:
+        if args.precision == 'fp32' and world == 1 and x3 and not args.no_alt:
             lib2 = eld_amd.load_library()
             lib2.eld_conv_fp32_algo(2)
             try:
