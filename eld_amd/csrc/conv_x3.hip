@@ -610,11 +610,12 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
 // ---- transposed conv 2x2/s2 as a pixel GEMM on the same split-operand scheme -----------------------------------------------
 // MODE CONV_1X1 (forward): out[(2y+dy, 2x+dx)][co] = sum_c in[(y,x)][c] * Wp[(dy,dx,co)][c]     (N = 4*Cout, K = Cin)
 // MODE CONV_GATHER2X2 (backward-data): din[(y,x)][ci] = sum_{tap,c} dout[(2y+dy, 2x+dx)][c] * Wp[tap][ci][c]   (K = 4*Cout)
-// Tile = 8 rows x 32 pixels x 64 channels, K stage = 32 k-values (two 16-k sub-chunks; a stage never straddles a tap),
-// LDS = [sub][256 pixels][28 words] + [sub][64][28 words] = 71.7 KB -> two workgroups per CU.
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void conv_x3_gemm_kernel(const ConvArgs a) {
-    constexpr int BN = 64, RPW = 2, TH = 8, NT = 2, NS = 2;
+// Tile = 2*WAVES rows x 32 pixels x BN channels, K stage = 32 k-values (two 16-k sub-chunks; a stage never straddles a tap):
+//   <64, 4>:  8 x 32 x 64,  LDS = [sub][256 pixels][28 words] + [sub][64][28 words] = 71.7 KB, two workgroups per CU;
+//   <128, 8>: 16 x 32 x 128, 143 KB, one 8-wave workgroup per CU -- each cut operand feeds twice the MFMAs.
+template <int MODE, int BN, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv_x3_gemm_kernel(const ConvArgs a) {
+    constexpr int THREADS = 64 * WAVES, RPW = 2, TH = WAVES * RPW, NT = BN / 32, NS = 2;
     constexpr int TPIX = TH * TW;
     constexpr int A_WORDS = NS * TPIX * PX;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -629,7 +630,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3_gemm_kernel(const ConvArgs a) 
     const int total_tiles = a.tiles_x * a.tiles_y * a.N * NB;
 
     constexpr int A_UNITS = NS * TPIX * 4, B_UNITS = NS * BN * 4;
-    constexpr int A_IT = A_UNITS / 256, B_IT = B_UNITS / 256;
+    constexpr int A_IT = A_UNITS / THREADS, B_IT = B_UNITS / THREADS;
+    static_assert(A_UNITS % THREADS == 0 && B_UNITS % THREADS == 0, "whole staging passes");
     float4 ra[A_IT], rb[B_IT];
     constexpr unsigned OOB = 0xFFFFFFF0u;
     unsigned a_voff[A_IT], b_voff[B_IT];
@@ -637,7 +639,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_gemm_kernel(const ConvArgs a) 
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (int)((size_t)(MODE == CONV_1X1 ? 1 : 4) * a.Nout * C0 * 4), 0x00020000);
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-        const int u = tid + it * 256;                              // (sub, n, part)
+        const int u = tid + it * THREADS;                              // (sub, n, part)
         const int part = u & 3, n = (u >> 2) % BN, sub = u / (4 * BN);
         b_voff[it] = (unsigned)(n * C0 * 4 + sub * 64 + part * 16);
     }
@@ -655,7 +657,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_gemm_kernel(const ConvArgs a) 
         decode(t, nb, l_img, y0, x0);
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            const int u = tid + it * 256;                          // (sub, pixel, part)
+            const int u = tid + it * THREADS;                          // (sub, pixel, part)
             const int part = u & 3, lp = (u >> 2) % TPIX, sub = u / (4 * TPIX);
             const int gy = y0 + lp / TW, gx = x0 + lp % TW;
             const bool ok = gy < a.H && gx < a.W;
@@ -680,12 +682,12 @@ __global__ __launch_bounds__(256, 2) void conv_x3_gemm_kernel(const ConvArgs a) 
     auto store_stage = [&]() {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            const int u = tid + it * 256;
+            const int u = tid + it * THREADS;
             split_store(ldsA + (u >> 2) * PX + (u & 3) * 2, ra[it]);          // (u >> 2) = sub * TPIX + pixel
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
-            const int u = tid + it * 256;
+            const int u = tid + it * THREADS;
             split_store(ldsB + (u >> 2) * PX + (u & 3) * 2, rb[it]);
         }
     };
@@ -715,7 +717,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3_gemm_kernel(const ConvArgs a) 
             constexpr int XI[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
             for (int sub = 0; sub < NS; ++sub) {
-                uint4 fx[3][RPW], fw[3][NT];
+                constexpr int NTH = NT > 2 ? 1 : NT;                  // channel blocks whose fragments are live together (register budget at NT = 4)
+                uint4 fx[3][RPW];
 #pragma unroll
                 for (int r = 0; r < RPW; ++r) {
                     const float* p = ldsA + (sub * TPIX + (wave * RPW + r) * TW + m) * PX + hi * 4;
@@ -723,19 +726,24 @@ __global__ __launch_bounds__(256, 2) void conv_x3_gemm_kernel(const ConvArgs a) 
                     for (int pc = 0; pc < 3; ++pc) fx[pc][r] = *reinterpret_cast<const uint4*>(p + pc * 8);
                 }
 #pragma unroll
-                for (int tt = 0; tt < NT; ++tt) {
-                    const float* p = ldsB + (sub * BN + tt * 32 + m) * PX + hi * 4;
+                for (int t0 = 0; t0 < NT; t0 += NTH) {
+                    uint4 fw[3][NTH];
 #pragma unroll
-                    for (int pc = 0; pc < 3; ++pc) fw[pc][tt] = *reinterpret_cast<const uint4*>(p + pc * 8);
+                    for (int tt = 0; tt < NTH; ++tt) {
+                        const float* p = ldsB + (sub * BN + (t0 + tt) * 32 + m) * PX + hi * 4;
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc) fw[pc][tt] = *reinterpret_cast<const uint4*>(p + pc * 8);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 6; ++q)
+#pragma unroll
+                        for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                            for (int tt = 0; tt < NTH; ++tt)
+                                acc[r][t0 + tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[WI[q]][tt]), __builtin_bit_cast(bf16x8, fx[XI[q]][r]),
+                                                                                          acc[r][t0 + tt], 0, 0, 0);
+                    if constexpr (NT > NTH) __builtin_amdgcn_sched_barrier(0);
                 }
-#pragma unroll
-                for (int q = 0; q < 6; ++q)
-#pragma unroll
-                    for (int r = 0; r < RPW; ++r)
-#pragma unroll
-                        for (int tt = 0; tt < NT; ++tt)
-                            acc[r][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[WI[q]][tt]), __builtin_bit_cast(bf16x8, fx[XI[q]][r]),
-                                                                                 acc[r][tt], 0, 0, 0);
             }
         }
         {   // epilogue: lane (m, hi) owns pixel x0+m and channels 8q+4hi..+3 of each 32-block (see conv_igemm.hip)
@@ -837,20 +845,23 @@ int launch_x3d(ConvArgs a, hipStream_t st) {
     return 0;
 }
 
-template <int MODE>
+template <int MODE, int BN, int WAVES>
 int launch_x3_gemm(ConvArgs a, hipStream_t st) {
+    constexpr int TH = 2 * WAVES;
     a.tiles_x = (a.W + TW - 1) / TW;
-    a.tiles_y = (a.H + 7) / 8;
-    const size_t lds_bytes = (size_t)(2 * 256 + 2 * 64) * PX * sizeof(float);
-    const long long tiles = (long long)a.tiles_x * a.tiles_y * a.N * (a.Nout / 64);
+    a.tiles_y = (a.H + TH - 1) / TH;
+    const size_t lds_bytes = (size_t)(2 * TH * TW + 2 * BN) * PX * sizeof(float);
+    const long long tiles = (long long)a.tiles_x * a.tiles_y * a.N * (a.Nout / BN);
     if (tiles <= 0) return 0;
     if (tiles > 0x7fffffffLL) return ELD_ENOTSUP;
-    auto kern = conv_x3_gemm_kernel<MODE>;
+    auto kern = conv_x3_gemm_kernel<MODE, BN, WAVES>;
     static EldAttrOnce once;
     { const int rc = once.ensure(kern, lds_bytes); if (rc) return rc; }
-    long long grid = (long long)eld_num_cus() * 2;
+    int per_cu = (int)((160 * 1024) / lds_bytes);
+    if (per_cu > 2) per_cu = 2;
+    long long grid = (long long)eld_num_cus() * per_cu;
     if (grid > tiles) grid = tiles;
-    ELD_LAUNCH(kern, dim3((unsigned)grid), dim3(256), lds_bytes, st, a);
+    ELD_LAUNCH(kern, dim3((unsigned)grid), dim3(64 * WAVES), lds_bytes, st, a);
     ELD_LAUNCH_CHECK();
     return 0;
 }
@@ -884,7 +895,9 @@ int launch_conv_x3(const ConvArgs& a_in, hipStream_t st) {
 int launch_conv_x3_gemm(const ConvArgs& a, int mode, hipStream_t st) {
     const size_t src_img = (size_t)a.H * a.W * a.C0 * 4 * (mode == CONV_GATHER2X2 ? 4 : 1);
     if (a.Nout % 64 || a.C0 % 32 || a.C1 != 0 || src_img >= 0xFFFFFFF0ull) return ELD_ENOTSUP;
-    if (mode == CONV_1X1 && a.epi == EPI_CONVT_FWD) return launch_x3_gemm<CONV_1X1>(a, st);
-    if (mode == CONV_GATHER2X2 && a.epi == EPI_GRAD && a.split == a.Nout) return launch_x3_gemm<CONV_GATHER2X2>(a, st);
+    // (an 8-wave 16 x 32 x 128 tile, <.., 128, 8>, was measured at the same speed as the 4-wave 8 x 32 x 64 one: these launches are not bound by
+    // the operand cuts; the small tile wastes less on the 89 x 133 / 178 x 266 levels)
+    if (mode == CONV_1X1 && a.epi == EPI_CONVT_FWD) return launch_x3_gemm<CONV_1X1, 64, 4>(a, st);
+    if (mode == CONV_GATHER2X2 && a.epi == EPI_GRAD && a.split == a.Nout) return launch_x3_gemm<CONV_GATHER2X2, 64, 4>(a, st);
     return ELD_ENOTSUP;
 }
