@@ -1,0 +1,15 @@
+# round profile set: bench lines, kernel traces, sampler table, PMC passes (run from the repo root on the GPU box)
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/final; mkdir -p $O
+timeout 900 python bench.py > $O/bench_fp32.json 2> $O/bench_fp32.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o fp32 -- python bench.py --no-cpu-baseline --no-alt > $O/bench_fp32_prof.json 2> $O/prof_fp32.err
+timeout 600 python bench.py --precision bf16 --no-cpu-baseline > $O/bench_bf16.json 2> $O/bench_bf16.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bf16 -- python bench.py --precision bf16 --no-cpu-baseline > $O/bench_bf16_prof.json 2> $O/prof_bf16.err
+timeout 200 python tools/noise_microbench.py 8 > $O/noise_microbench.txt 2>&1
+B="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt"
+timeout 500 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES --output-format csv -d $O/pmc -o sq -- $B > $O/pmc_sq.log 2>&1
+timeout 500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc -o fetch -- $B > $O/pmc_fetch.log 2>&1
+timeout 500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc -o write -- $B > $O/pmc_write.log 2>&1
+ls $O $O/prof $O/pmc
+cut -c1-700 $O/bench_fp32.json
