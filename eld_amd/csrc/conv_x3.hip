@@ -51,6 +51,16 @@ __device__ __forceinline__ void split_store(float* row, float4 v) {
 }
 
 
+// Which LDS row a staging unit's 4 lanes fill.  ds_write_b64 is serviced in groups of 16 consecutive lanes (32 banks of 4 B): rows r .. r+3 at the
+// 28-word row stride start at banks 0, 28, 24, 20 and their 8-word piece windows overlap pairwise (2-way conflicts on half the banks, measured as
+// 27-100 % of the LDS-active cycles of these kernels); rows r, r+2, r+4, r+6 start at banks 0, 24, 16, 8: disjoint.  So inside every aligned
+// block of 8 rows the staging order is 0,2,4,6,1,3,5,7 -- a bijection on [0, limit) (a trailing partial block keeps its order); loads and
+// stores use the same map, the LDS image is unchanged.
+__device__ __forceinline__ int stage_row(int r, int limit) {
+    const int b = r & ~7, j = r & 7;
+    return b + 8 > limit ? r : b + ((j & 3) << 1) + (j >> 2);
+}
+
 // max over the horizontal neighbour pixel (lane ^ 1 holds pixel x ^ 1 of the same row and the same channels): quad_perm [1,0,3,2]
 __device__ __forceinline__ float hmax1(float f) {
     return fmaxf(f, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(f), 0xB1, 0xF, 0xF, true)));
@@ -124,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
         const int u = tid + it * 256;
-        const int row = u >> 2, part = u & 3;
+        const int row = stage_row(u >> 2, B_ROWS), part = u & 3;
         const int kx = row / BN, n = row - kx * BN;
         b_voff[it] = u < B_UNITS ? (unsigned)((kx * a.Nout + n) * Cin * 4 + part * 16) : OOB;
     }
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int u = tid + it * 256;
-            const int hp = u >> 2, part = u & 3;
+            const int hp = stage_row(u >> 2, A_PIX), part = u & 3;
             const int hy = hp / (TW + 2), hx = hp - hy * (TW + 2);
             const int gy = y0 + hy - 1, gx = x0 + hx - 1;
             const bool ok = u < A_UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
@@ -170,14 +180,14 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int u = tid + it * 256;
-            if (u < A_UNITS) split_store(ldsA + (u >> 2) * PX + (u & 3) * 2, ra[it]);
+            if (u < A_UNITS) split_store(ldsA + stage_row(u >> 2, A_PIX) * PX + (u & 3) * 2, ra[it]);
         }
     };
     auto store_B = [&]() {
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             const int u = tid + it * 256;
-            if (u < B_UNITS) split_store(ldsB + (u >> 2) * PX + (u & 3) * 2, rb[it]);
+            if (u < B_UNITS) split_store(ldsB + stage_row(u >> 2, B_ROWS) * PX + (u & 3) * 2, rb[it]);
         }
     };
 
@@ -414,7 +424,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int u = tid + it * THREADS;
-            const int hp = u >> 2, part = u & 3;
+            const int hp = stage_row(u >> 2, A_PIX), part = u & 3;
             const int hy = hp / (TW + 2), hx = hp - hy * (TW + 2);
             const int gy = y0 + hy - 1, gx = x0 + hx - 1;
             const bool ok = u < A_UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
@@ -434,7 +444,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int u = tid + it * THREADS;
-            if (u < A_UNITS) split_store(ldsA + (u >> 2) * PX + (u & 3) * 2, ra[it]);
+            if (u < A_UNITS) split_store(ldsA + stage_row(u >> 2, A_PIX) * PX + (u & 3) * 2, ra[it]);
         }
     };
     // slab (nb, chunk, ky) -> LDS buffer `buf`: wave w moves pieces w, w + WAVES, ...
@@ -640,7 +650,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv_x3_gemm_k
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
         const int u = tid + it * THREADS;                              // (sub, n, part)
-        const int part = u & 3, n = (u >> 2) % BN, sub = u / (4 * BN);
+        const int part = u & 3, rr = stage_row(u >> 2, NS * BN), n = rr % BN, sub = rr / BN;
         b_voff[it] = (unsigned)(n * C0 * 4 + sub * 64 + part * 16);
     }
     auto decode = [&](int t, int& nb, int& img, int& y0, int& x0) {
@@ -658,7 +668,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv_x3_gemm_k
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int u = tid + it * THREADS;                          // (sub, pixel, part)
-            const int part = u & 3, lp = (u >> 2) % TPIX, sub = u / (4 * TPIX);
+            const int part = u & 3, rr = stage_row(u >> 2, NS * TPIX), lp = rr % TPIX, sub = rr / TPIX;
             const int gy = y0 + lp / TW, gx = x0 + lp % TW;
             const bool ok = gy < a.H && gx < a.W;
             const unsigned pix = MODE == CONV_GATHER2X2 ? (unsigned)(2 * gy * Ws + 2 * gx) : (unsigned)(gy * Ws + gx);
@@ -683,12 +693,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv_x3_gemm_k
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int u = tid + it * THREADS;
-            split_store(ldsA + (u >> 2) * PX + (u & 3) * 2, ra[it]);          // (u >> 2) = sub * TPIX + pixel
+            split_store(ldsA + stage_row(u >> 2, NS * TPIX) * PX + (u & 3) * 2, ra[it]);          // row = sub * TPIX + pixel
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             const int u = tid + it * THREADS;
-            split_store(ldsB + (u >> 2) * PX + (u & 3) * 2, rb[it]);
+            split_store(ldsB + stage_row(u >> 2, NS * BN) * PX + (u & 3) * 2, rb[it]);
         }
     };
 
