@@ -113,7 +113,7 @@ struct WgradArgs {
     int N, H, W;         // pixel domain of g
     float* part;         // partials [psplit][taps][CA][CBp]
     float* bpart;        // optional bias partials [psplit][CA] (sum over pixels of g); null to skip
-    float* xbpart;       // CONV_GATHER2X2, fp32 inputs, optional: partials [psplit][CBp] of the column sums of the gathered operand (every pixel
+    float* xbpart;       // CONV_GATHER2X2, optional: partials [psplit][CBp] of the column sums of the gathered operand (every pixel
                          // of x0 is staged exactly once per block column) = the transposed conv's bias gradient; null to skip
     int CBp;             // padded CB (multiple of 32)
     int psplit;

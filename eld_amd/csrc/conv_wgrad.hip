@@ -86,10 +86,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     float bsum = 0.f;
-    // column sums of the gathered operand (transposed-conv bias gradient): a thread always stages the same channel quad (256 % 8 == 0)
-    constexpr bool XSUM = MODE == CONV_GATHER2X2 && ES == 4;
+    // column sums of the gathered operand (transposed-conv bias gradient): a thread always stages the same channel group (256 % (JB/EPU) == 0)
+    constexpr bool XSUM = MODE == CONV_GATHER2X2;
     const bool xsum_on = XSUM && a.xbpart != nullptr && ib == 0;
-    float4 xs = make_float4(0.f, 0.f, 0.f, 0.f);
+    float xs[EPU];                           // 4 channels (fp32 units) or 8 (bf16 units) of this thread's quad / octet
+#pragma unroll
+    for (int e = 0; e < EPU; ++e) xs[e] = 0.f;
 
     const int tiles_per_img = a.tiles_x * a.tiles_y;
     const int ntiles = tiles_per_img * a.N;
@@ -188,7 +190,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
         if constexpr (XSUM) {
             if (xsum_on) {
 #pragma unroll
-                for (int it = 0; it < X_IT; ++it) { xs.x += rx[it].x; xs.y += rx[it].y; xs.z += rx[it].z; xs.w += rx[it].w; }      // out-of-image units load zeros
+                for (int it = 0; it < X_IT; ++it) {                            // out-of-image units load zeros
+                    if constexpr (ES == 4) { xs[0] += rx[it].x; xs[1] += rx[it].y; xs[2] += rx[it].z; xs[3] += rx[it].w; }
+                    else {
+                        const uint4 q = __builtin_bit_cast(uint4, rx[it]);
+                        const float4 lo = unpack_bf4(make_uint2(q.x, q.y)), hi4 = unpack_bf4(make_uint2(q.z, q.w));
+                        xs[0] += lo.x; xs[1] += lo.y; xs[2] += lo.z; xs[3] += lo.w; xs[4] += hi4.x; xs[5] += hi4.y; xs[6] += hi4.z; xs[7] += hi4.w;
+                    }
+                }
             }
         }
     };
@@ -342,13 +351,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     if constexpr (XSUM) {
         if (xsum_on) {                                  // block-uniform: 32 threads hold each channel quad; fixed-order combine through LDS
             __syncthreads();
-            float4* r4 = reinterpret_cast<float4*>(lds);
-            r4[tid] = xs;
+            float* r = lds;                             // [256 threads][EPU]
+#pragma unroll
+            for (int e = 0; e < EPU; ++e) r[tid * EPU + e] = xs[e];
             __syncthreads();
             if (tid < JB) {
-                const int part = tid >> 2, comp = tid & 3;
+                constexpr int PARTS = JB / EPU;         // threads tid, tid + PARTS, ... stage the same channel group
+                const int part = tid / EPU, comp = tid % EPU;
                 float s = 0.f;
-                for (int k = 0; k < 32; ++k) s += reinterpret_cast<const float*>(&r4[k * 8 + part])[comp];
+                for (int k = 0; k < 256 / PARTS; ++k) s += r[(k * PARTS + part) * EPU + comp];
                 a.xbpart[(size_t)ps * a.CBp + j0 + tid] = s;
             }
         }

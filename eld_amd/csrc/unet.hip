@@ -515,9 +515,10 @@ int unet_backward_bf16(const Plan& P, const float* dout, const float* prm, float
             WgradArgs a = {};
             a.g = src; a.CA = 2 * C; a.x0 = cur; a.C0 = C; a.N = N; a.H = Hi; a.W = Wi; a.dtype = DT_BF16;
             a.part = part; a.bpart = nullptr; a.CBp = q.CBp; a.psplit = q.psplit;
+            a.xbpart = part + (size_t)q.psplit * q.T * q.CA * q.CBp;          // bias gradient = column sums of d_up, from the staging registers
             RC(launch_wgrad(a, CONV_GATHER2X2, st));
             RC(launch_wgrad_reduce(part, nullptr, grd + P.L[iu].w_off, nullptr, q.psplit, q.T, q.CA, q.CBp, C, st));
-            RC(launch_colsum_bf16(cur, grd + P.L[iu].b_off, part, (size_t)N * 4 * Hi * Wi, C, st));
+            RC(launch_colsum_reduce(a.xbpart, grd + P.L[iu].b_off, q.psplit, C, st));
             RC(marks.done(P, iu, st));
             ConvArgs c = {};
             c.in0 = cur; c.C0 = C; c.wp = B(P.wp_bwd[iu]); c.N = N; c.H = Hi; c.W = Wi; c.Nout = 2 * C;
