@@ -316,6 +316,18 @@ def main():
                                    'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
                                    'traffic': (round(traffic['sampler_bytes_per_pixel'] * yb.numel()) if traffic and 'sampler_bytes_per_pixel' in traffic else None),
                                    'algorithmic_bytes': 8 * yb.numel(), 'ms_per_launch': round(t_s, 4), 'mpix_s': round(yb.numel() / (t_s * 1e-3) / 1e6, 1)}
+        # the other model strings of the reference (noise.py:158-166: 'Pg', 'pg', 'g'), same launch shape: achieved GB/s and fraction per model
+        per_model = {}
+        for ms_ in ('Pg', 'pg', 'g'):
+            flm = model_flags(ms_) | L.CLIP
+
+            def samp_m():
+                sample_noise(yb, pl, flm, 2018, list(range(nb)), out=zb)
+            samp_m(); torch.cuda.synchronize()
+            tm = timed_events(samp_m, 10)
+            gm = 8.0 * yb.numel() / (tm * 1e-3) / 1e9
+            per_model[ms_] = {'ms_per_launch': round(tm, 4), 'achieved': round(gm, 1), 'frac': round(gm / PEAK_HBM_GBS, 4)}
+        res['roofline_sampler']['models'] = per_model
         del yb, zb
         if world == 1 and not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(Hh, Ww)
