@@ -44,7 +44,7 @@ struct NoiseArgs {
     FastDiv divW, divH;    // divW divides by W/4 in the vector kernel, by W in the scalar kernel
     uint32_t flags, in_dtype;
     PhiloxKey key;
-    uint32_t dbg;          // ablation switches (env ELD_NOISE_DBG): 1 skip queue drain, 2 skip inversion loop, 4 skip PTRS attempt 0, 8 skip phase 3 RNG
+    uint32_t dbg;          // ablation switches (dev builds, env ELD_NOISE_DBG): 1 skip the queue drain, 4 PTRS draws always take the queue route, 8 skip phase 3 RNG
 };
 
 // ---------------------------------------------------------------------------------------------

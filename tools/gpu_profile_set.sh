@@ -1,3 +1,5 @@
+#!/bin/bash
+# usage (from the repo root): gpurun --timeout 3000 -- "bash tools/gpu_profile_set.sh"; then copy the summaries from gpurun_out/final into profiles/
 # round profile set: bench lines, kernel traces, sampler table, PMC passes (run from the repo root on the GPU box)
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
@@ -13,3 +15,5 @@ timeout 500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc -o fetch --
 timeout 500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc -o write -- $B > $O/pmc_write.log 2>&1
 ls $O $O/prof $O/pmc
 cut -c1-700 $O/bench_fp32.json
+# sampler counters (VALU instructions per pixel, VALU pipe occupancy)
+timeout 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU --output-format csv -d $O/pmc -o noise_sq -- python tools/noise_microbench.py 8 > $O/pmc_noise.log 2>&1
