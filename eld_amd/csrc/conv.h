@@ -127,7 +127,7 @@ struct WgradArgs {
 int launch_wgrad(const WgradArgs& a, int mode, hipStream_t st);
 // block shape (COB out-channels x JB in-channels, TH-row tiles) wgrad8_kernel uses for a 3x3 layer under the three-piece scheme;
 // false if the layer stays on wgrad_kernel
-bool wgrad8_shape(int CA, int CBp, int& COB, int& JB, int& TH);
+bool wgrad8_shape(int CA, int CBp, int& COB, int& JB, int& TH, bool bf16 = false);
 // out[(i*CBr + j)*T + tap] = sum_s part[s][tap][i][j]   (OIHW / (Cin,Cout,2,2) layouts);  bgrad[i] = sum_s bpart[s][i]
 int launch_wgrad_reduce(const float* part, const float* bpart, float* wgrad, float* bgrad, int psplit, int T, int CA,
                         int CBp, int CBr, hipStream_t st);

@@ -378,20 +378,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 //   * small blocks take taller tiles (TH = 4 / 8 rows): the 3x3 halo overhead of X falls from 2.1x to 1.6x / 1.3x.
 // LDS planes are [32-channel block][pixel][32] bf16 (64-byte rows: what ds_read_b64_tr_b16 reads conflict-free), three planes
 // (pieces) per operand.  Partials / reduction kernel / numerics are those of wgrad_kernel.
-template <int WCO, int WCI, int WPIX, int TH>
+template <typename T, int WCO, int WCI, int WPIX, int TH>      // T = float (three bf16 pieces per operand, six products) or bf16_t (the tiles as they are, one product)
 __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradArgs a) {
+    constexpr int ES = sizeof(T), EPU = 16 / ES, NPC = ES == 4 ? 3 : 1, XQ = 32 / EPU;      // element size, elements per 16-byte unit, pieces, units per 32-channel pixel
     static_assert(WCO * WCI * WPIX == 8, "8 waves");
     constexpr int THREADS = 512, TAPS = 9;
     constexpr int COB = 32 * WCO, JBK = 32 * WCI, TPIX = TH * TW, PW = TPIX / WPIX, KSB = PW / 16;
     static_assert(PW % 16 == 0 && PW >= 16, "a wave's pixel slice is a whole number of 16-pixel k-steps");
     constexpr int X_PIX = (TH + 2) * (TW + 2);
     constexpr int GPL = TPIX * COB, XPL = X_PIX * JBK;                 // elements per piece plane
-    constexpr int G_Q = COB / 4, G_UNITS = TPIX * G_Q, G_IT = G_UNITS / THREADS;
+    constexpr int G_Q = COB / EPU, G_UNITS = TPIX * G_Q, G_IT = G_UNITS / THREADS;
     static_assert(G_UNITS % THREADS == 0 && THREADS % G_Q == 0, "a thread stages the same channel quad of G in every iteration");
-    constexpr int X_UNITS1 = X_PIX * 8, X_IT = (X_UNITS1 + THREADS - 1) / THREADS;      // per 32-channel block of X
+    constexpr int X_UNITS1 = X_PIX * XQ, X_IT = (X_UNITS1 + THREADS - 1) / THREADS;     // per 32-channel block of X
     extern __shared__ __attribute__((aligned(16))) float lds[];
     bf16_t* ldsG = reinterpret_cast<bf16_t*>(lds);                    // [3][WCO][TPIX][32]
-    bf16_t* ldsX = ldsG + 3 * GPL;                                    // [3][WCI][X_PIX][32]
+    bf16_t* ldsX = ldsG + NPC * GPL;                                  // [NPC][WCI][X_PIX][32]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 31, hi = lane >> 5;
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradArgs a) {
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-    float4 bsum4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 bsum4 = make_float4(0.f, 0.f, 0.f, 0.f), bsum4b = make_float4(0.f, 0.f, 0.f, 0.f);      // bias sums of this thread's channel group (second quad: bf16 units of 8)
 
     const int tiles_per_img = a.tiles_x * a.tiles_y;
     const int ntiles = tiles_per_img * a.N;
@@ -420,22 +421,22 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradArgs a) {
     constexpr int G_STEP = THREADS / G_Q;                             // 16, 32 or 64 pixels per pass
     const int g_part = tid % G_Q, g_lp0 = tid / G_Q;
     const int g_px0 = g_lp0 % TW, g_py0 = g_lp0 / TW;
-    const unsigned g_off0 = (unsigned)((g_py0 * a.W + g_px0) * a.CA + i0 + g_part * 4) * 4u;
-    const int g_lds0 = (((g_part * 4) >> 5) * TPIX + g_lp0) * 32 + ((g_part * 4) & 31);
+    const unsigned g_off0 = (unsigned)((g_py0 * a.W + g_px0) * a.CA + i0 + g_part * EPU) * (unsigned)ES;
+    const int g_lds0 = (((g_part * EPU) >> 5) * TPIX + g_lp0) * 32 + ((g_part * EPU) & 31);
     auto g_pxy = [&](int it, int& dpx, int& dpy) {                    // pixel offset of pass `it` relative to (g_px0, g_py0): compile-time
         if (G_STEP >= TW) { dpx = 0; dpy = it * (G_STEP / TW); }
         else { dpx = (it * G_STEP) % TW; dpy = (it * G_STEP) / TW; }   // G_STEP == 16: lp0 < 16, so px0 + dpx < 32 stays in the row
     };
     // X unit (per 32-channel block) u = tid + it*512: halo pixel hp = u / 8, quad part = u % 8; (hy, hx) packed in one register
-    const int x_part = tid & 7;
+    const int x_part = (int)((unsigned)tid % (unsigned)XQ);
     int x_hyx[X_IT];
 #pragma unroll
     for (int it = 0; it < X_IT; ++it) {
-        const int hp = (tid + it * THREADS) >> 3;
+        const int hp = (int)((unsigned)(tid + it * THREADS) / (unsigned)XQ);
         const int hy = hp / (TW + 2);
         x_hyx[it] = (hy << 8) | (hp - hy * (TW + 2));
     }
-    auto x_alive = [&](int it) { return (it + 1) * THREADS <= X_UNITS1 || ((tid + it * THREADS) >> 3) < X_PIX; };
+    auto x_alive = [&](int it) { return (it + 1) * THREADS <= X_UNITS1 || (int)((unsigned)(tid + it * THREADS) / (unsigned)XQ) < X_PIX; };
     // sources of the WCI 32-channel blocks of X (virtual concat [x0, x1]); blocks beyond C0 + C1 are zero padding
     const char* xs[WCI]; int xC[WCI], xc0[WCI];
 #pragma unroll
@@ -446,36 +447,37 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradArgs a) {
         else { xs[cb] = nullptr; xC[cb] = 32; xc0[cb] = 0; }
     }
     float4 rg[G_IT], rx[WCI][X_IT];
-    const size_t g_img = (size_t)a.H * a.W * a.CA * 4;
+    const size_t g_img = (size_t)a.H * a.W * a.CA * ES;
     auto load_tile = [&](int tile) {
         const int img = tile / tiles_per_img;
         const int trem = tile - img * tiles_per_img;
         const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
         const int y0 = ty * TH, x0 = tx * TW;
         const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)(static_cast<const char*>(a.g) + (size_t)img * g_img), 0, (int)g_img, 0x00020000);
-        const int gbase = (y0 * a.W + x0) * a.CA * 4;                 // rows past the image end fall outside the descriptor: zero fill
+        const int gbase = (y0 * a.W + x0) * a.CA * ES;                // rows past the image end fall outside the descriptor: zero fill
         const int wrem = a.W - x0;
 #pragma unroll
         for (int it = 0; it < G_IT; ++it) {
             int dpx, dpy;
             g_pxy(it, dpx, dpy);
-            const unsigned off = g_off0 + (unsigned)((dpy * a.W + dpx) * a.CA) * 4u;
+            const unsigned off = g_off0 + (unsigned)((dpy * a.W + dpx) * a.CA) * (unsigned)ES;
             rg[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, g_px0 + dpx < wrem ? (int)off : (int)OOB, gbase, 0));
         }
 #pragma unroll
         for (int cb = 0; cb < WCI; ++cb) {
-            const size_t x_img = (size_t)a.H * a.W * xC[cb] * 4;
+            const size_t x_img = (size_t)a.H * a.W * xC[cb] * ES;
             const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(xs[cb] ? xs[cb] + (size_t)img * x_img : nullptr), 0, xs[cb] ? (int)x_img : 0, 0x00020000);
 #pragma unroll
             for (int it = 0; it < X_IT; ++it) {
                 const int gy = y0 - 1 + (x_hyx[it] >> 8), gx = x0 - 1 + (x_hyx[it] & 255);
                 const bool ok = x_alive(it) && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-                const unsigned off = ok ? (unsigned)((gy * a.W + gx) * xC[cb] + xc0[cb] + x_part * 4) * 4u : OOB;
+                const unsigned off = ok ? (unsigned)((gy * a.W + gx) * xC[cb] + xc0[cb] + x_part * EPU) * (unsigned)ES : OOB;
                 rx[cb][it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)off, 0, 0));
             }
         }
     };
-    auto put3 = [&](bf16_t* d, int plane_elems, const float4& raw) {       // the exact three-piece cut of conv_x3.hip::split_store
+    auto put3 = [&](bf16_t* d, int plane_elems, const float4& raw) {       // fp32: the exact three-piece cut of conv_x3.hip::split_store; bf16: 8 elements as loaded
+        if constexpr (ES == 2) { *reinterpret_cast<float4*>(d) = raw; return; }
         const unsigned x0 = __float_as_uint(raw.x), x1 = __float_as_uint(raw.y), x2 = __float_as_uint(raw.z), x3 = __float_as_uint(raw.w);
         const float r0 = raw.x - __uint_as_float(x0 & 0xFFFF0000u), r1 = raw.y - __uint_as_float(x1 & 0xFFFF0000u);
         const float r2 = raw.z - __uint_as_float(x2 & 0xFFFF0000u), r3 = raw.w - __uint_as_float(x3 & 0xFFFF0000u);
@@ -491,13 +493,21 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradArgs a) {
 #pragma unroll
         for (int it = 0; it < G_IT; ++it) {
             put3(ldsG + g_lds0 + it * G_STEP * 32, GPL, rg[it]);
-            if (do_bias) { bsum4.x += rg[it].x; bsum4.y += rg[it].y; bsum4.z += rg[it].z; bsum4.w += rg[it].w; }
+            if (do_bias) {
+                if constexpr (ES == 4) { bsum4.x += rg[it].x; bsum4.y += rg[it].y; bsum4.z += rg[it].z; bsum4.w += rg[it].w; }
+                else {
+                    const uint4 q = __builtin_bit_cast(uint4, rg[it]);
+                    const float4 lo = unpack_bf4(make_uint2(q.x, q.y)), hi4 = unpack_bf4(make_uint2(q.z, q.w));
+                    bsum4.x += lo.x; bsum4.y += lo.y; bsum4.z += lo.z; bsum4.w += lo.w;
+                    bsum4b.x += hi4.x; bsum4b.y += hi4.y; bsum4b.z += hi4.z; bsum4b.w += hi4.w;
+                }
+            }
         }
 #pragma unroll
         for (int cb = 0; cb < WCI; ++cb)
 #pragma unroll
             for (int it = 0; it < X_IT; ++it)
-                if (x_alive(it)) put3(ldsX + (cb * X_PIX + ((tid + it * THREADS) >> 3)) * 32 + x_part * 4, XPL, rx[cb][it]);
+                if (x_alive(it)) put3(ldsX + (cb * X_PIX + (int)((unsigned)(tid + it * THREADS) / (unsigned)XQ)) * 32 + x_part * EPU, XPL, rx[cb][it]);
     };
 
     // fragment addresses (see wgrad_kernel): a 16-lane group reads a [4 pixels][16 channels] block per ds_read_b64_tr_b16
@@ -522,25 +532,30 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradArgs a) {
         for (int ks = 0; ks < KSB; ++ks) {
             const int lrel = ks * 16;
             const int dy0 = lrel / TW, dxp = lrel - dy0 * TW;
-            bf16x8 ga[3];
+            bf16x8 ga[NPC];
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) ga[pc] = tr8(gq + pc * GPL + lrel * 32);
+            for (int pc = 0; pc < NPC; ++pc) ga[pc] = tr8(gq + pc * GPL + lrel * 32);
 #pragma unroll
             for (int t0 = 0; t0 < TAPS; t0 += 3) {
-                bf16x8 xb[3][3];
+                bf16x8 xb[3][NPC];
 #pragma unroll
                 for (int tt = 0; tt < 3; ++tt) {
                     const int xoff = (dy0 + t0 / 3) * (TW + 2) + dxp + tt;
 #pragma unroll
-                    for (int pc = 0; pc < 3; ++pc) xb[tt][pc] = tr8(xq + pc * XPL + xoff * 32);
+                    for (int pc = 0; pc < NPC; ++pc) xb[tt][pc] = tr8(xq + pc * XPL + xoff * 32);
                 }
-                constexpr int GI[6] = {0, 1, 2, 0, 1, 0};
-                constexpr int XI[6] = {2, 1, 0, 1, 0, 0};
+                if constexpr (NPC == 3) {
+                    constexpr int GI[6] = {0, 1, 2, 0, 1, 0};
+                    constexpr int XI[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
-                for (int q = 0; q < 6; ++q)
+                    for (int q = 0; q < 6; ++q)
 #pragma unroll
-                    for (int tt = 0; tt < 3; ++tt)
-                        acc[t0 + tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[GI[q]], xb[tt][XI[q]], acc[t0 + tt], 0, 0, 0);
+                        for (int tt = 0; tt < 3; ++tt)
+                            acc[t0 + tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[GI[q]], xb[tt][XI[q]], acc[t0 + tt], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int tt = 0; tt < 3; ++tt) acc[t0 + tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[0], xb[tt][0], acc[t0 + tt], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);                    // keep the next kernel row's reads below: 256-VGPR budget
             }
         }
@@ -576,39 +591,43 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradArgs a) {
     }
     if (do_bias) {                                                     // thread -> channel quad g_part; 512 / G_Q threads per quad, fixed order
         __syncthreads();
-        reinterpret_cast<float4*>(red)[tid] = bsum4;
+        if constexpr (ES == 4) reinterpret_cast<float4*>(red)[tid] = bsum4;
+        else { reinterpret_cast<float4*>(red)[2 * tid] = bsum4; reinterpret_cast<float4*>(red)[2 * tid + 1] = bsum4b; }
         __syncthreads();
         if (tid < COB) {
-            const int q = tid >> 2, comp = tid & 3;
+            const int q = tid / EPU, comp = tid % EPU;
             float s_ = 0.f;
-            for (int k = 0; k < THREADS / G_Q; ++k) s_ += red[(q + k * G_Q) * 4 + comp];
+            for (int k = 0; k < THREADS / G_Q; ++k) s_ += red[(q + k * G_Q) * EPU + comp];
             a.bpart[(size_t)ps * a.CA + i0 + tid] = s_;
         }
     }
 }
 
-// block shape of wgrad8_kernel for a layer (CA out-channels of G, CBp padded in-channels of X); false: the layer stays on wgrad_kernel
-bool wgrad8_shape(int CA, int CBp, int& COB, int& JBK, int& TH) {
+// block shape of wgrad8_kernel for a layer (CA out-channels of G, CBp padded in-channels of X); false: the layer stays on wgrad_kernel.
+// bf16 inputs keep one plane per operand (a third of the LDS of the three-piece tiles), so every block shape takes 8-row tiles:
+// halo overhead of X 1.33x instead of 2.1x / 1.6x and a quarter of the barriers per pixel.
+bool wgrad8_shape(int CA, int CBp, int& COB, int& JBK, int& TH, bool bf16) {
     if (CA % 32 || CBp % 32) return false;
-    if (CA % 128 == 0 && CBp % 64 == 0) { COB = 128; JBK = 64; TH = 2; return true; }
-    if (CA % 64 == 0 && CBp % 64 == 0) { COB = 64; JBK = 64; TH = 2; return true; }      // TH = 4 spills 9 registers: 3.06 vs 2.79 ms (measured)
-    if (CA % 64 == 0) { COB = 64; JBK = 32; TH = 4; return true; }
-    if (CBp % 64 == 0) { COB = 32; JBK = 64; TH = 4; return true; }
-    COB = 32; JBK = 32; TH = 4;
+    if (CA % 128 == 0 && CBp % 64 == 0) { COB = 128; JBK = 64; TH = 2; }
+    else if (CA % 64 == 0 && CBp % 64 == 0) { COB = 64; JBK = 64; TH = 2; }      // fp32: TH = 4 spills 9 registers: 3.06 vs 2.79 ms (measured)
+    else if (CA % 64 == 0) { COB = 64; JBK = 32; TH = 4; }
+    else if (CBp % 64 == 0) { COB = 32; JBK = 64; TH = 4; }
+    else { COB = 32; JBK = 32; TH = 4; }
+    if (bf16) TH = 8;
     return true;
 }
 
-template <int WCO, int WCI, int WPIX, int TH>
+template <typename T, int WCO, int WCI, int WPIX, int TH>
 static int launch_w8(WgradArgs a, hipStream_t st) {
     constexpr int COB = 32 * WCO, JBK = 32 * WCI;
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + TH - 1) / TH;
-    size_t lds_bytes = (size_t)(TH * TW * COB + (TH + 2) * (TW + 2) * JBK) * 6;
+    size_t lds_bytes = (size_t)(TH * TW * COB + (TH + 2) * (TW + 2) * JBK) * (sizeof(T) == 4 ? 6 : 2);
     const size_t red_bytes = (size_t)7 * 16 * 64 * sizeof(float) * 1;       // WPIX-1 <= 7 slices of WCO*WCI*WPIX/... tiles: (WPIX-1)*WCO*WCI <= 7
     if (lds_bytes < red_bytes) lds_bytes = red_bytes;
     const long long blocks = (long long)(a.CA / COB) * (a.CBp / JBK) * a.psplit;
     if (blocks <= 0) return 0;
-    auto kern = wgrad8_kernel<WCO, WCI, WPIX, TH>;
+    auto kern = wgrad8_kernel<T, WCO, WCI, WPIX, TH>;
     static EldAttrOnce once;
     { const int rc = once.ensure(kern, lds_bytes); if (rc) return rc; }
     ELD_LAUNCH(kern, dim3((unsigned)blocks), dim3(512), lds_bytes, st, a);
@@ -617,15 +636,24 @@ static int launch_w8(WgradArgs a, hipStream_t st) {
 }
 
 static int launch_wgrad8(const WgradArgs& a, hipStream_t st) {
+    const bool bf16 = a.dtype == DT_BF16;
+    const size_t es = bf16 ? 2 : 4;
     int COB, JBK, TH;
-    if (!wgrad8_shape(a.CA, a.CBp, COB, JBK, TH)) return ELD_ENOTSUP;
+    if (!wgrad8_shape(a.CA, a.CBp, COB, JBK, TH, bf16)) return ELD_ENOTSUP;
     if ((a.C0 % 32) || (a.C1 % 32)) return ELD_ENOTSUP;
-    if ((size_t)a.H * a.W * a.CA * 4 >= 0x7FFFFFF0ull || (size_t)a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) * 4 >= 0x7FFFFFF0ull) return ELD_ENOTSUP;
-    if (COB == 128) return launch_w8<4, 2, 1, 2>(a, st);
-    if (COB == 64 && JBK == 64) return launch_w8<2, 2, 2, 2>(a, st);
-    if (COB == 64) return launch_w8<2, 1, 4, 4>(a, st);
-    if (JBK == 64) return launch_w8<1, 2, 4, 4>(a, st);
-    return launch_w8<1, 1, 8, 4>(a, st);
+    if ((size_t)a.H * a.W * a.CA * es >= 0x7FFFFFF0ull || (size_t)a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) * es >= 0x7FFFFFF0ull) return ELD_ENOTSUP;
+    if (bf16) {
+        if (COB == 128) return launch_w8<bf16_t, 4, 2, 1, 8>(a, st);
+        if (COB == 64 && JBK == 64) return launch_w8<bf16_t, 2, 2, 2, 8>(a, st);
+        if (COB == 64) return launch_w8<bf16_t, 2, 1, 4, 8>(a, st);
+        if (JBK == 64) return launch_w8<bf16_t, 1, 2, 4, 8>(a, st);
+        return launch_w8<bf16_t, 1, 1, 8, 8>(a, st);
+    }
+    if (COB == 128) return launch_w8<float, 4, 2, 1, 2>(a, st);
+    if (COB == 64 && JBK == 64) return launch_w8<float, 2, 2, 2, 2>(a, st);
+    if (COB == 64) return launch_w8<float, 2, 1, 4, 4>(a, st);
+    if (JBK == 64) return launch_w8<float, 1, 2, 4, 4>(a, st);
+    return launch_w8<float, 1, 1, 8, 4>(a, st);
 }
 
 template <typename T, int MODE, int WCO, int TH, int ALG = ALG_F32>
@@ -653,6 +681,10 @@ int launch_wgrad(const WgradArgs& a, int mode, hipStream_t st) {
     const bool c64 = a.CA % 64 == 0;
     if (a.dtype == DT_BF16) {
         if (a.C0 % 8 || a.C1 % 8) return ELD_EINVAL;
+        if (mode == CONV_3X3 && a.wgrad8) {                 // 8-wave re-blocked kernel (partials sized for its block shape)
+            const int rc = launch_wgrad8(a, st);
+            if (rc != ELD_ENOTSUP) return rc;
+        }
         static int mma = -1;                  // ELD_WGRAD_BF16_MMA=0 falls back to fp32-MFMA accumulation of the widened operands
         if (mma < 0) { const char* e = getenv("ELD_WGRAD_BF16_MMA"); mma = e ? atoi(e) : 1; }
         if (mma) {

@@ -67,7 +67,8 @@ WgradGeom wgrad_geom(int mode, int CA, int CB, int N, int H, int W, int algo) {
     g.CBp = (CB + 31) / 32 * 32;
     g.w8 = 0;
     int cob8, jb8, th8;
-    if (algo == 1 && mode == CONV_3X3 && CB % 32 == 0 && wgrad8_shape(CA, g.CBp, cob8, jb8, th8)) {
+    // algo 3 = bf16 tensors on the same re-blocked kernel (one plane per operand, 8-row tiles)
+    if ((algo == 1 || algo == 3) && mode == CONV_3X3 && CB % 32 == 0 && wgrad8_shape(CA, g.CBp, cob8, jb8, th8, algo == 3)) {
         g.w8 = 1;
         g.groups = (CA / cob8) * (g.CBp / jb8);
         g.ntiles = ((W + 31) / 32) * ((H + th8 - 1) / th8) * N;
@@ -228,6 +229,8 @@ int make_plan(Plan& P, int N, int H, int W, int in_ch, int out_ch) {
             f = wgrad_geom(CONV_3X3, d.cout, i == L_E0A ? 16 : d.cin, N, P.Hl[lev], P.Wl[lev], 0).floats;
             const size_t f1 = wgrad_geom(CONV_3X3, d.cout, i == L_E0A ? 16 : d.cin, N, P.Hl[lev], P.Wl[lev], 1).floats;
             f = f1 > f ? f1 : f;
+            const size_t f3 = wgrad_geom(CONV_3X3, d.cout, i == L_E0A ? 16 : d.cin, N, P.Hl[lev], P.Wl[lev], 3).floats;
+            f = f3 > f ? f3 : f;
         } else if (d.kind == 1) f = wgrad_geom(CONV_GATHER2X2, d.cin, d.cout, N, P.Hl[lev + 1], P.Wl[lev + 1], 0).floats;
         pmax = f > pmax ? f : pmax;
     }
@@ -479,10 +482,11 @@ int conv_bwd_data_bf16(const bf16_t* g, const bf16_t* wb, bf16_t* out0, bf16_t* 
 
 int conv_wgrad_bf16(const bf16_t* g, int Cout, const bf16_t* x0, int C0, const bf16_t* x1, int C1, float* dw, float* db, float* part,
                     int N, int H, int W, hipStream_t st) {
-    const WgradGeom q = wgrad_geom(CONV_3X3, Cout, C0 + C1, N, H, W, 0);
+    const WgradGeom q = wgrad_geom(CONV_3X3, Cout, C0 + C1, N, H, W, (C0 % 32 || C1 % 32) ? 0 : 3);
     WgradArgs a = {};
     a.g = g; a.CA = Cout; a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.N = N; a.H = H; a.W = W; a.dtype = DT_BF16;
     a.part = part; a.bpart = db ? part + (size_t)q.psplit * q.T * q.CA * q.CBp : nullptr; a.CBp = q.CBp; a.psplit = q.psplit;
+    a.wgrad8 = q.w8;
     RC(launch_wgrad(a, CONV_3X3, st));
     return launch_wgrad_reduce(part, a.bpart, dw, db, q.psplit, q.T, q.CA, q.CBp, C0 + C1, st);
 }
