@@ -92,7 +92,7 @@ inline int resolve_algo(int algo) { return (algo >= 0 && algo <= 2) ? algo : con
 int launch_conv_x3(const ConvArgs& a, hipStream_t st);
 // three-piece scheme: 3x3 layers whose GEMM N (Nout) is a multiple of 64 take their weights PRE-SPLIT in the slab layout of
 // conv_x3d_kernel (conv_x3.hip); returns the slab's channel-block width BN (64 or 128), or 0 for layers that keep fp32 packed weights
-int x3_slab_bn(int Nout);
+int x3_slab_bn(int Nout, int N, int H, int W, int* waves = nullptr);      // (N, H, W): the launch's tile domain -- small problems take smaller tiles
 // bytes of one packed layer in slab layout: 9 taps x Nout x K/16 rows of 112 B
 __host__ __device__ inline size_t x3_slab_stride(int BN) { return (size_t)(3 * BN * 112 + 1023) / 1024 * 1024; }      // bytes of one (ky, chunk, channel-block) slab
 void conv_x3_set_prof(unsigned long long* buf);      // dev tool: 8 workgroups x 4 waves x 128 stages x 6 stamps

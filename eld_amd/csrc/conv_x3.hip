@@ -884,9 +884,17 @@ void conv_x3_set_prof(unsigned long long*) {}       // the s_memtime stage profi
 // tile where the layer has them (half the halo cuts per MFMA), else 64.  Layers with 32 output channels stay on the register-staged
 // conv_x3_kernel<32, 4> with two workgroups per CU: their K loop is 2-4 chunks long and a lone workgroup cannot hide its epilogue
 // (DMA variants with 32-channel slabs measured 0-2 % slower).
-int x3_slab_bn(int Nout) {
+// Small problems (the reference trains on single 512 x 512 patches, train_syn.py defaults): when the big tiles do not give every CU a
+// workgroup the layer drops to 64-channel tiles, and then to 8-row tiles with 4-wave workgroups -- 4x the workgroups of the 16 x 128 tile
+// (conv5_x of a 512 x 512 patch: 8 -> 32 workgroups).  The pack kernel lays the slabs out for the same choice (same function, same arguments).
+int x3_slab_bn(int Nout, int N, int H, int W, int* waves) {
+    if (waves) *waves = 8;
     if (Nout % 64) return 0;
-    return Nout % 128 == 0 ? 128 : 64;
+    const long long px_tiles = (long long)((W + TW - 1) / TW) * ((H + 15) / 16) * N;
+    const int cus = eld_num_cus();
+    if (Nout % 128 == 0 && px_tiles * (Nout / 128) >= cus) return 128;
+    if (waves && px_tiles * (Nout / 64) < cus) *waves = 4;
+    return 64;
 }
 
 // a: fp32 CONV_3X3 arguments already validated by launch_conv
@@ -895,8 +903,10 @@ int launch_conv_x3(const ConvArgs& a_in, hipStream_t st) {
     a.prof = nullptr;
     if ((size_t)a.H * a.W * a.C0 * 4 >= 0xFFFFFFF0ull) return ELD_ENOTSUP;
     if (a.pool_out && (a.epi != EPI_FWD || (a.H & 1) || (a.W & 1))) return ELD_EINVAL;
-    if (x3_slab_bn(a.Nout) == 128) return launch_x3d<128, 2, 8, false>(a, st);      // weights pre-split in slab layout: LDS-DMA kernel
-    if (x3_slab_bn(a.Nout) == 64) return launch_x3d<64, 2, 8, false>(a, st);
+    int waves = 8;
+    const int bn = x3_slab_bn(a.Nout, a.N, a.H, a.W, &waves);
+    if (bn == 128) return launch_x3d<128, 2, 8, false>(a, st);      // weights pre-split in slab layout: LDS-DMA kernel
+    if (bn == 64) return waves == 8 ? launch_x3d<64, 2, 8, false>(a, st) : launch_x3d<64, 2, 4, false>(a, st);
     return launch_x3<32, 4, false>(a, st);
 }
 

@@ -262,7 +262,9 @@ int pack_weights(const Plan& P, const float* params, float* ws, bool for_backwar
         J.bf16 = bf16 ? 1 : 0;
         J.amax_slot = S_W + i;
         // three-piece scheme: 3x3 layers with GEMM N % 64 == 0 get pre-split slabs (N = Cout forward, Cin backward-data)
-        J.x3bn = (!bf16 && g_algo == 1 && d.kind == 0) ? x3_slab_bn(for_backward ? d.cin : d.cout) : 0;
+        int lev;                                   // resolution level the layer runs at (its tile domain decides the slab's channel-block width)
+        if (i <= L_E4B) lev = i / 2; else if (i < L_HEAD) lev = 3 - (i - L_UP3) / 3; else lev = 0;
+        J.x3bn = (!bf16 && g_algo == 1 && d.kind == 0) ? x3_slab_bn(for_backward ? d.cin : d.cout, P.N, P.Hl[lev], P.Wl[lev]) : 0;
         // bf16: 3x3 layers the DMA kernel takes get its slab layout (GEMM N = Cout forward / Cin backward-data, K the other one)
         J.bfdbn = (bf16 && d.kind == 0) ? (for_backward ? bfd_slab_bn(d.cin, d.cout) : bfd_slab_bn(d.cout, J.Cinp)) : 0;
         jobs.job[jobs.n++] = J;
@@ -699,7 +701,7 @@ extern "C" int eld_conv3x3_forward(const float* in0, int C0, const float* in1, i
     float *pack, *part;
     RC(layer_ws(ws, ws_bytes, N, H, W, C0 + C1, Cout, &pack, &part));
     hipStream_t st = as_stream(stream);
-    RC(launch_pack(w, pack, PACK_CONV_FWD, Cout, C0 + C1, C0 + C1, 9, st, g_algo == 1 ? x3_slab_bn(Cout) : 0));
+    RC(launch_pack(w, pack, PACK_CONV_FWD, Cout, C0 + C1, C0 + C1, 9, st, g_algo == 1 ? x3_slab_bn(Cout, N, H, W) : 0));
     float* am;
     RC(layer_amax(ws, eld_layer_workspace_bytes(N, H, W, C0 + C1, Cout), st, in0, (size_t)N * H * W * C0, in1, (size_t)N * H * W * C1, pack, (size_t)9 * Cout * (C0 + C1), &am));
     if (am) { g_am.in0 = am; g_am.in1 = in1 ? am + 1 : nullptr; g_am.w = am + 2; g_am.out0 = am + 3; }
@@ -714,7 +716,7 @@ extern "C" int eld_conv3x3_backward_data(const float* g, const float* w, float* 
     float *pack, *part;
     RC(layer_ws(ws, ws_bytes, N, H, W, Cin, Cout, &pack, &part));
     hipStream_t st = as_stream(stream);
-    RC(launch_pack(w, pack, PACK_CONV_BWD, Cout, Cin, Cin, 9, st, g_algo == 1 ? x3_slab_bn(Cin) : 0));
+    RC(launch_pack(w, pack, PACK_CONV_BWD, Cout, Cin, Cin, 9, st, g_algo == 1 ? x3_slab_bn(Cin, N, H, W) : 0));
     float* am;
     RC(layer_amax(ws, eld_layer_workspace_bytes(N, H, W, Cin, Cout), st, g, (size_t)N * H * W * Cout, nullptr, 0, pack, (size_t)9 * Cout * Cin, &am));
     if (am) { g_am.in0 = am; g_am.w = am + 2; g_am.out0 = am + 3; g_am.out1 = am + 4; }
