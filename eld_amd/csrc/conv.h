@@ -99,7 +99,7 @@ void conv_x3_set_prof(unsigned long long* buf);      // dev tool: 8 workgroups x
 int launch_conv_x3_gemm(const ConvArgs& a, int mode, hipStream_t st);
 // bf16 3x3 layers with Nout % 64 == 0 and K % 32 == 0 run on conv_bfd_kernel (conv_bfd.hip: both operands by LDS-DMA) and take their weights in its
 // slab layout; returns the slab's channel-block width BN (64 / 128) or 0 for layers that stay on conv_igemm_kernel<bf16_t>
-int bfd_slab_bn(int Nout, int K);
+int bfd_slab_bn(int Nout, int K, int N, int H, int W);
 __host__ __device__ inline size_t bfd_slab_bytes(int BN) { return (size_t)3 * BN * 64; }
 int launch_conv_bfd(const ConvArgs& a, hipStream_t st);      // transposed-conv directions; ELD_ENOTSUP if not covered
 

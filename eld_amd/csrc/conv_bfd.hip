@@ -336,18 +336,23 @@ int launch_bfd(ConvArgs a, hipStream_t st) {
 
 }  // namespace
 
-// Layers the DMA kernel takes: bf16 3x3 with GEMM N (Nout) a multiple of 64 and K a multiple of 32; returns the slab's channel-block
-// width BN (what the pack kernel must lay the weights out for), or 0 for layers that stay on conv_igemm_kernel<bf16_t>.
-int bfd_slab_bn(int Nout, int K) {
+// Layers the DMA kernel takes: bf16 3x3 with GEMM N (Nout) a multiple of 64 and K a multiple of 32, on a tile domain (N images of H x W) that
+// gives every CU one of its 16-row tiles; returns the slab's channel-block width BN (what the pack kernel must lay the weights out for), or 0 for
+// launches that stay on conv_igemm_kernel<bf16_t> (32-channel layers; small problems, where its 8-row tiles with two 4-wave workgroups per CU
+// spread the work over more CUs).
+int bfd_slab_bn(int Nout, int K, int N, int H, int W) {
     if (K % 32 || Nout % 64) return 0;
-    return Nout % 128 == 0 ? 128 : 64;
+    const long long px_tiles = (long long)((W + TW - 1) / TW) * ((H + 15) / 16) * N;
+    const int cus = eld_num_cus();
+    if (Nout % 128 == 0 && px_tiles * (Nout / 128) >= cus) return 128;
+    return px_tiles * (Nout / 64) >= cus ? 64 : 0;
 }
 
 // a: bf16 CONV_3X3 arguments already validated by launch_conv; weights in slab layout
 int launch_conv_bfd(const ConvArgs& a, hipStream_t st) {
     if ((size_t)a.H * a.W * a.C0 * 2 >= 0xFFFFFFF0ull) return ELD_ENOTSUP;
     if (a.pool_out && (a.epi != EPI_FWD || (a.H & 1) || (a.W & 1))) return ELD_EINVAL;
-    const int bn = bfd_slab_bn(a.Nout, a.C0 + a.C1);
+    const int bn = bfd_slab_bn(a.Nout, a.C0 + a.C1, a.N, a.H, a.W);
     if (bn == 128) return launch_bfd<128, 2, 8>(a, st);
     if (bn == 64) return launch_bfd<64, 2, 8>(a, st);
     return ELD_ENOTSUP;

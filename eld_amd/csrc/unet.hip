@@ -266,7 +266,7 @@ int pack_weights(const Plan& P, const float* params, float* ws, bool for_backwar
         if (i <= L_E4B) lev = i / 2; else if (i < L_HEAD) lev = 3 - (i - L_UP3) / 3; else lev = 0;
         J.x3bn = (!bf16 && g_algo == 1 && d.kind == 0) ? x3_slab_bn(for_backward ? d.cin : d.cout, P.N, P.Hl[lev], P.Wl[lev]) : 0;
         // bf16: 3x3 layers the DMA kernel takes get its slab layout (GEMM N = Cout forward / Cin backward-data, K the other one)
-        J.bfdbn = (bf16 && d.kind == 0) ? (for_backward ? bfd_slab_bn(d.cin, d.cout) : bfd_slab_bn(d.cout, J.Cinp)) : 0;
+        J.bfdbn = (bf16 && d.kind == 0) ? (for_backward ? bfd_slab_bn(d.cin, d.cout, P.N, P.Hl[lev], P.Wl[lev]) : bfd_slab_bn(d.cout, J.Cinp, P.N, P.Hl[lev], P.Wl[lev])) : 0;
         jobs.job[jobs.n++] = J;
     }
     return launch_pack_all(jobs, params, ws, st, amax);
@@ -372,7 +372,7 @@ int unet_forward_bf16(const Plan& P, const float* x, const float* prm, float* ou
         else
             RC(conv_fwd_bf16(B(P.pool[l - 1]), chan(l - 1), nullptr, 0, B(P.wp_fwd[2 * l]), prm + A.b_off, B(P.ea[l]), N, P.Hl[l], P.Wl[l], chan(l), 1, st));
         // layers on the DMA kernel (conv_bfd.hip) write the pooled tensor from their epilogue
-        const bool fuse_pool = l < NLEV - 1 && bfd_slab_bn(chan(l), chan(l)) != 0;
+        const bool fuse_pool = l < NLEV - 1 && bfd_slab_bn(chan(l), chan(l), N, P.Hl[l], P.Wl[l]) != 0;
         RC(conv_fwd_bf16(B(P.ea[l]), chan(l), nullptr, 0, B(P.wp_fwd[2 * l + 1]), prm + Bd.b_off, B(P.eb[l]), N, P.Hl[l], P.Wl[l], chan(l), 1, st,
                          fuse_pool ? B(P.pool[l]) : nullptr));
         if (l < NLEV - 1 && !fuse_pool) RC(launch_maxpool_fwd_bf16(B(P.eb[l]), B(P.pool[l]), N, P.Hl[l + 1], P.Wl[l + 1], chan(l), st));

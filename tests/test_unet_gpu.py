@@ -395,6 +395,49 @@ def test_bf16x3_is_as_accurate_as_fp32_mfma(lib):
     assert r2 <= 1.5 * r0 + 1e-8 and m2 <= 2.0 * m0 + 1e-8, errs
 
 
+def test_unet_bf16_dma_kernels_full_frame(lib):
+    """BASELINE.json configs[2] at frame size (1 x 4 x 1424 x 2128): here the bf16 3x3 layers run on conv_bfd_kernel (both operands by LDS-DMA;
+    small problems stay on conv_igemm_kernel<bf16>).  Checked against independently tested paths:
+      * inference vs the fp32 engine: PSNR >= 60 dB (SURVEY.md App. E-4);
+      * crop consistency ACROSS kernels: a 512 x 512 crop runs on the register-staged kernel; away from the crop border its output matches the
+        full-frame output of the DMA kernel to PSNR >= 60 dB (same arithmetic, different accumulation order and tile geometry);
+      * training gradients (DMA backward-data, fused pool epilogue, re-blocked bf16 weight gradient) vs the fp32 engine: cosine >= 0.995."""
+    from eld_amd.unet import UNetSeeInDark
+    torch.manual_seed(13)
+    net = UNetSeeInDark(4, 4).cuda()
+    g = torch.Generator(device='cuda').manual_seed(17)
+    H, W = 1424, 2128
+    x = torch.rand(1, 4, H, W, device='cuda', generator=g)
+
+    def psnr(a, b):
+        mse = torch.mean((a.double() * 255 - b.double() * 255) ** 2)
+        return float(10 * torch.log10(255.0 ** 2 / mse))
+    with torch.no_grad():
+        ref32 = net(x)
+        net.inference_precision = 'bf16'
+        full = net(x)
+        y0, x0 = 448, 800
+        crop = net(x[:, :, y0:y0 + 512, x0:x0 + 512].contiguous())
+        net.inference_precision = 'fp32'
+    assert psnr(full, ref32) >= 60.0, psnr(full, ref32)
+    m = 200
+    a, b = full[:, :, y0 + m:y0 + 512 - m, x0 + m:x0 + 512 - m], crop[:, :, m:512 - m, m:512 - m]
+    assert psnr(a, b) >= 60.0, psnr(a, b)
+    t = torch.rand(1, 4, H, W, device='cuda', generator=g)
+    grads = {}
+    for prec in ('fp32', 'bf16'):
+        net.train_precision = prec
+        net.zero_grad()
+        loss = torch.nn.functional.l1_loss(net(x), t)
+        loss.backward()
+        grads[prec] = {n: p.grad.detach().double().reshape(-1).clone() for n, p in net.named_parameters()}
+    net.train_precision = 'fp32'
+    for n in grads['fp32']:
+        r, q = grads['fp32'][n], grads['bf16'][n]
+        cos = float(torch.dot(r, q) / (r.norm() * q.norm() + 1e-300))
+        assert cos >= 0.995, (n, cos)
+
+
 def test_unet_full_frame_properties(lib):
     """BASELINE.json configs[1] size (1 x 4 x 1424 x 2128), where the fp64 oracle is out of reach: size-independent properties.
       * crop consistency: away from the crop border (beyond the receptive field) the output of a 16-aligned 512x512 crop
