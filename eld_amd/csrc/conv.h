@@ -29,6 +29,9 @@ struct ConvArgs {
     int lrelu;          // EPI_FWD: apply max(0.2v, v)
     void* out0;         // EPI_FWD/CONVT: destination.  EPI_GRAD: channels [0, split)
     void* out1;         // EPI_GRAD: channels [split, Nout)
+    int ksplit;         // conv_x3d_kernel, small problems: > 1 = split the K (input-channel chunk) range of every tile over this many workgroups; the
+    float* kpart;       //   partial sums go to kpart[ksplit][N][H][W][Nout] (fp32) and x3_splitk_finish_kernel adds them in a fixed order and runs the
+    size_t kpart_floats;//   epilogue.  kpart_floats = capacity of kpart (0: no split).  Set by the U-Net orchestration only.
     void* pool_out;     // EPI_FWD, optional: also write the 2x2/stride-2 max-pool of the output ([N, H/2, W/2, Nout]; H, W even) -- honoured by the
                         // three-piece 3x3 kernels (conv_x3.hip) only; other launchers return ELD_ENOTSUP when it is set
     int split;

@@ -395,7 +395,11 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
     const int m = lane & 31, hi = lane >> 5;
     const int NB = a.Nout / BN;
     const int Cin = a.C0 + a.C1, NCH = Cin / CK;
-    const int total_tiles = a.tiles_x * a.tiles_y * a.N * NB;
+    // work item = (tile, K part): with a.ksplit > 1 (small problems) the chunk range of a tile is shared out over ksplit workgroups that write raw
+    // partial sums; x3_splitk_finish_kernel adds them in a fixed order and runs the epilogue
+    constexpr bool SPLITK = WAVES == 4;                                     // only the small-tile variant carries the split (the 8-wave kernels have no register to spare)
+    const int KS = SPLITK && a.ksplit > 1 ? a.ksplit : 1;
+    const int total_tiles = a.tiles_x * a.tiles_y * a.N * NB * KS;          // work items
     const int Cs0 = a.C0;
 
     constexpr int A_UNITS = A_PIX * 4;
@@ -457,20 +461,23 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
         }
     };
 
+    auto chunk_begin = [&](int t) { return ((t % KS) * NCH) / KS; };
+    auto chunk_end = [&](int t) { return ((t % KS + 1) * NCH) / KS; };
     int t = blockIdx.x;
     if (t >= total_tiles) return;
-    setup_load(t);
-    load_A(0);
+    setup_load(t / KS);
+    load_A(chunk_begin(t) * CK);
     int buf = 0;
     {
         int nb0, i0, y00, x00;
-        decode(t, nb0, i0, y00, x00);
-        dma_B(0, nb0, 0, 0);
+        decode(t / KS, nb0, i0, y00, x00);
+        dma_B(0, nb0, chunk_begin(t), 0);
     }
     for (;;) {
         int nb, img, y0, x0;
-        decode(t, nb, img, y0, x0);
+        decode(t / KS, nb, img, y0, x0);
         const int t_next = t + gridDim.x;
+        const int c_begin = chunk_begin(t), c_end = chunk_end(t);
         f32x16 acc[RPW][NT];
 #pragma unroll
         for (int r = 0; r < RPW; ++r)
@@ -479,8 +486,8 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[r][tt][i] = 0.f;
 
-        for (int chunk = 0; chunk < NCH; ++chunk) {
-            const bool last_chunk = chunk + 1 >= NCH;
+        for (int chunk = c_begin; chunk < c_end; ++chunk) {
+            const bool last_chunk = chunk + 1 >= c_end;
 #pragma unroll 1
             for (int ky = 0; ky < 3; ++ky) {
                 __builtin_amdgcn_s_setprio(3);   // the short staging section goes ahead of co-resident waves' MFMA streams
@@ -492,10 +499,10 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
                 }
                 if (ky < 2) dma_B(buf ^ 1, nb, chunk, ky + 1);
                 else if (!last_chunk) dma_B(buf ^ 1, nb, chunk + 1, 0);
-                else if (t_next < total_tiles) dma_B(buf ^ 1, t_next % NB, 0, 0);
+                else if (t_next < total_tiles) dma_B(buf ^ 1, (t_next / KS) % NB, chunk_begin(t_next), 0);
                 if (ky == 0) {                   // the halo tile of the next chunk / next tile has three stages to arrive
                     if (!last_chunk) load_A((chunk + 1) * CK);
-                    else if (t_next < total_tiles) { setup_load(t_next); load_A(0); }
+                    else if (t_next < total_tiles) { setup_load(t_next / KS); load_A(chunk_begin(t_next) * CK); }
                 }
                 __builtin_amdgcn_s_setprio(0);
                 const float* lb = ldsB + buf * B_WORDS;
@@ -554,7 +561,21 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
         }
 
         // ---- epilogue: lane (m, hi) owns pixel x0+m and channels 8q+4hi..+3 of each 32-block (as conv_x3_kernel) ----
-        {
+        if (KS > 1) {                            // split K: raw partial sums of this K part, [part][image][y][x][Nout]
+            const int x = x0 + m;
+            float* pbase = a.kpart + (size_t)(t % KS) * ((size_t)a.N * a.H * a.W * a.Nout);
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int y = y0 + wave * RPW + r;
+                if (y >= a.H || x >= a.W) continue;
+                float* prow = pbase + ((size_t)(img * a.H + y) * a.W + x) * a.Nout + nb * BN + 4 * hi;
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4*>(prow + tt * 32 + 8 * q) = make_float4(acc[r][tt][4 * q], acc[r][tt][4 * q + 1], acc[r][tt][4 * q + 2], acc[r][tt][4 * q + 3]);
+            }
+        } else {
             const int x = x0 + m;
             const bool xok = x < a.W;
 #pragma unroll
@@ -611,7 +632,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
                 }
             }
         }
-        if (a.epi == EPI_FWD && a.pool_out != nullptr) pool_epilogue<RPW, NT, BN>(a, acc, img, nb, y0 + wave * RPW, x0 + m, hi);
+        if (KS == 1 && a.epi == EPI_FWD && a.pool_out != nullptr) pool_epilogue<RPW, NT, BN>(a, acc, img, nb, y0 + wave * RPW, x0 + m, hi);
         if (t_next >= total_tiles) break;
         t = t_next;
     }
@@ -811,6 +832,66 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv_x3_gemm_k
     }
 }
 
+// ---- split-K finish: out = epilogue(sum over the K parts, in a fixed order) ---------------------------------------------------------
+// One thread per (pixel or 2x2 pixel block, channel quad).  The epilogues are those of the conv kernels: EPI_FWD bias + LeakyReLU (+ the fused
+// 2x2 max-pool when pool_out is set: the thread then owns a whole pooling window), EPI_GRAD LeakyReLU slope of the saved activation and the
+// channel split of virtual concats.
+template <bool POOL>
+__global__ __launch_bounds__(256) void x3_splitk_finish_kernel(const ConvArgs a) {
+    const int Q = a.Nout >> 2;
+    const int Wb = POOL ? a.W >> 1 : a.W, Hb = POOL ? a.H >> 1 : a.H;
+    const size_t total = (size_t)a.N * Hb * Wb * Q;
+    const size_t plane = (size_t)a.N * a.H * a.W * a.Nout;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int q = (int)(i % Q);
+        size_t p = i / Q;
+        const int xb = (int)(p % Wb); p /= Wb;
+        const int yb = (int)(p % Hb);
+        const int img = (int)(p / Hb);
+        const int n = 4 * q;
+        float4 pooled = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int w = 0; w < (POOL ? 4 : 1); ++w) {
+            const int y = POOL ? 2 * yb + (w >> 1) : yb, x = POOL ? 2 * xb + (w & 1) : xb;
+            const size_t pix = (size_t)(img * a.H + y) * a.W + x;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int ks = 0; ks < a.ksplit; ++ks) {
+                const float4 t = *reinterpret_cast<const float4*>(a.kpart + (size_t)ks * plane + pix * a.Nout + n);
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+            if (a.epi == EPI_FWD) {
+                const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
+                v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+                if (a.lrelu) { v.x = fmaxf(0.2f * v.x, v.x); v.y = fmaxf(0.2f * v.y, v.y); v.z = fmaxf(0.2f * v.z, v.z); v.w = fmaxf(0.2f * v.w, v.w); }
+                *reinterpret_cast<float4*>(static_cast<float*>(a.out0) + pix * a.Nout + n) = v;
+                if (POOL) pooled = w == 0 ? v : make_float4(fmaxf(pooled.x, v.x), fmaxf(pooled.y, v.y), fmaxf(pooled.z, v.z), fmaxf(pooled.w, v.w));
+            } else {
+                const bool lo = n < a.split;
+                const int C = lo ? a.split : a.Nout - a.split;
+                const size_t idx = pix * C + (lo ? n : n - a.split);
+                const float* act = static_cast<const float*>(lo ? a.act0 : a.act1);
+                if (act) {
+                    const float4 s_ = *reinterpret_cast<const float4*>(act + idx);
+                    v.x *= lrelu_slope(s_.x); v.y *= lrelu_slope(s_.y); v.z *= lrelu_slope(s_.z); v.w *= lrelu_slope(s_.w);
+                }
+                *reinterpret_cast<float4*>(static_cast<float*>(lo ? a.out0 : a.out1) + idx) = v;
+            }
+        }
+        if (POOL) *reinterpret_cast<float4*>(static_cast<float*>(a.pool_out) + ((size_t)(img * Hb + yb) * Wb + xb) * a.Nout + n) = pooled;
+    }
+}
+
+int launch_x3_splitk_finish(const ConvArgs& a, hipStream_t st) {
+    const bool pool = a.epi == EPI_FWD && a.pool_out != nullptr;
+    const size_t total = (size_t)a.N * (pool ? a.H / 2 : a.H) * (pool ? a.W / 2 : a.W) * (a.Nout / 4);
+    if (!total) return 0;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (pool) { ELD_LAUNCH(x3_splitk_finish_kernel<true>, dim3(grid), dim3(256), 0, st, a); }
+    else { ELD_LAUNCH(x3_splitk_finish_kernel<false>, dim3(grid), dim3(256), 0, st, a); }
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int BN, int RPW, bool DB>
 int launch_x3(ConvArgs a, hipStream_t st) {
     constexpr int TH = 4 * RPW;
@@ -839,8 +920,20 @@ int launch_x3d(ConvArgs a, hipStream_t st) {
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + TH - 1) / TH;
     const size_t lds_bytes = (size_t)(TH + 2) * (TW + 2) * PX * sizeof(float) + 2 * (size_t)((3 * BN * PX * 4 + 1023) / 1024 * 1024);
-    const long long tiles = (long long)a.tiles_x * a.tiles_y * a.N * (a.Nout / BN);
+    long long tiles = (long long)a.tiles_x * a.tiles_y * a.N * (a.Nout / BN);
     if (tiles <= 0) return 0;
+    // split K where the smallest tiles still leave most of the chip idle (single patches: conv5_x of a 512 x 512 input is 32 workgroups) and the
+    // caller provided room for the partial sums
+    a.ksplit = 1;
+    if (WAVES == 4 && a.kpart != nullptr) {
+        const int nch = (a.C0 + a.C1) / 16;
+        const size_t plane = (size_t)a.N * a.H * a.W * a.Nout;
+        int ks = (int)(eld_num_cus() / tiles);
+        if (ks > nch / 2) ks = nch / 2;                       // at least two chunks per part
+        if (ks > 16) ks = 16;
+        while (ks > 1 && (size_t)ks * plane > a.kpart_floats) --ks;
+        if (ks >= 2) { a.ksplit = ks; tiles *= ks; }
+    }
     if (tiles > 0x7fffffffLL) return ELD_ENOTSUP;
     auto kern = conv_x3d_kernel<BN, RPW, WAVES, DB>;
     static EldAttrOnce once;
@@ -852,6 +945,7 @@ int launch_x3d(ConvArgs a, hipStream_t st) {
     if (grid > tiles) grid = tiles;
     ELD_LAUNCH(kern, dim3((unsigned)grid), dim3(64 * WAVES), lds_bytes, st, a);
     ELD_LAUNCH_CHECK();
+    if (a.ksplit > 1) return launch_x3_splitk_finish(a, st);
     return 0;
 }
 

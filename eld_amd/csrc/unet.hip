@@ -94,6 +94,11 @@ WgradGeom wgrad_geom(int mode, int CA, int CB, int N, int H, int W, int algo) {
 // consumed (and cleared) by it.  Slots are device floats in the workspace.
 struct Amax { const float* in0 = nullptr; const float* in1 = nullptr; const float* w = nullptr; float* out0 = nullptr; float* out1 = nullptr; };
 thread_local Amax g_am;
+// scratch for the split-K partial sums of small problems (conv_x3.hip): the plan's weight-gradient partial region, free while a conv runs;
+// set for the duration of a U-Net entry point
+struct KPart { float* p = nullptr; size_t floats = 0; };
+thread_local KPart g_kp;
+struct KPartScope { KPart prev; KPartScope(float* p, size_t n) : prev(g_kp) { g_kp.p = p; g_kp.floats = n; } ~KPartScope() { g_kp = prev; } };
 thread_local int g_algo = -1;      // fp32 product scheme of the entry point being executed on this thread (-1: process default)
 struct AlgoScope { int prev; explicit AlgoScope(int a) : prev(g_algo) { g_algo = resolve_algo(a); } ~AlgoScope() { g_algo = prev; } };
 inline void take_amax(ConvArgs& a) { a.algo = g_algo; a.amax_in0 = g_am.in0; a.amax_in1 = g_am.in1; a.amax_w = g_am.w; a.amax_out0 = g_am.out0; a.amax_out1 = g_am.out1; g_am = Amax(); }
@@ -105,6 +110,7 @@ int conv_fwd(const float* in0, int C0, const float* in1, int C1, const float* wp
     a.pool_out = pool_out;
     a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1; a.wp = wp; a.N = N; a.H = H; a.W = W; a.Nout = Cout;
     a.epi = EPI_FWD; a.bias = bias; a.lrelu = lrelu; a.out0 = out;
+    a.kpart = g_kp.p; a.kpart_floats = g_kp.floats;
     take_amax(a);
     return launch_conv(a, CONV_3X3, st);
 }
@@ -115,6 +121,7 @@ int conv_bwd_data(const float* g, const float* wb, float* out0, float* out1, int
     ConvArgs a = {};
     a.in0 = g; a.C0 = Cout; a.wp = wb; a.N = N; a.H = H; a.W = W; a.Nout = Cin;
     a.epi = EPI_GRAD; a.out0 = out0; a.out1 = out1; a.split = split; a.act0 = act0; a.act1 = act1;
+    a.kpart = g_kp.p; a.kpart_floats = g_kp.floats;
     take_amax(a);
     return launch_conv(a, CONV_3X3, st);
 }
@@ -180,7 +187,7 @@ struct Plan {
     // offsets in floats
     size_t wp_fwd[NLAYERS], wp_bwd[NLAYERS];
     size_t x16, ea[NLEV], eb[NLEV], pool[NLEV - 1], up[NLEV - 1], da[NLEV - 1], db[NLEV - 1];
-    size_t gA, gB, skip[NLEV - 1], part, amax;
+    size_t gA, gB, skip[NLEV - 1], part, part_floats, amax;
     size_t total;     // floats
 };
 
@@ -234,7 +241,24 @@ int make_plan(Plan& P, int N, int H, int W, int in_ch, int out_ch) {
         } else if (d.kind == 1) f = wgrad_geom(CONV_GATHER2X2, d.cin, d.cout, N, P.Hl[lev + 1], P.Wl[lev + 1], 0).floats;
         pmax = f > pmax ? f : pmax;
     }
+    // split-K partial sums of small problems share this region: up to 16 parts of the largest 3x3 output that can take the split
+    for (int i = 0; i < NLAYERS; ++i) {
+        const LayerDef& d = P.L[i];
+        if (d.kind != 0) continue;
+        int lev;
+        if (i <= L_E4B) lev = i / 2; else lev = 3 - (i - L_UP3) / 3;
+        const long long px8 = (long long)((P.Wl[lev] + 31) / 32) * ((P.Hl[lev] + 7) / 8) * N;
+        for (int dir = 0; dir < 2; ++dir) {
+            const int nout = dir ? d.cin : d.cout, k = dir ? d.cout : d.cin;
+            if (nout % 64 || k % 32) continue;
+            long long ks = eld_num_cus() / (px8 * (nout / 64));
+            if (ks > k / 32) ks = k / 32;
+            if (ks > 16) ks = 16;
+            if (ks >= 2) { const size_t f = (size_t)ks * N * P.Hl[lev] * P.Wl[lev] * nout; pmax = f > pmax ? f : pmax; }
+        }
+    }
     P.part = take(pmax);
+    P.part_floats = pmax;
     P.amax = take(S_COUNT);
     P.total = off;
     return 0;
@@ -295,6 +319,7 @@ struct BucketMarks {
 
 int unet_forward(const Plan& P, const float* x, const float* prm, float* out, float* ws, hipStream_t st) {
     const int N = P.N;
+    KPartScope kp(ws + P.part, P.part_floats);
     const bool h2 = g_algo == 2;                                 // operand bounds ride along in the workspace
     float* am = ws + P.amax;
     auto AM = [&](int in0, int in1, int w, int out0) {
@@ -394,6 +419,7 @@ int unet_forward_bf16(const Plan& P, const float* x, const float* prm, float* ou
 
 int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd, float* ws, hipStream_t st, BucketMarks& marks) {
     const int N = P.N;
+    KPartScope kp(ws + P.part, P.part_floats);
     const bool h2 = g_algo == 2;
     float* am = ws + P.amax;
     if (h2 && hipMemsetAsync(am + S_GA, 0, (S_COUNT - S_GA) * sizeof(float), st) != hipSuccess) return (int)hipGetLastError();
