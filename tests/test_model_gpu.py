@@ -383,3 +383,53 @@ def test_l2_loss_training_step(eld_lib, tmp_path):
     got = m.netG.state_dict()
     for k, v in params.items():
         assert float(((got[k].cpu() - sd[k]) - (v.detach() - sd[k])).abs().max()) < 2e-5, k
+
+
+def test_unet_step_is_hipgraph_capturable(eld_lib):
+    """include/eld_amd.h promises entry points without allocation or synchronisation: a forward + backward + Adam chain recorded into a HIP graph
+    (torch.cuda.CUDAGraph = hipGraph on ROCm) replays to the same bits as the eager calls, also after the inputs change in place."""
+    from eld_amd import _lib as L
+    from eld_amd.unet import UNetSeeInDark
+    torch.manual_seed(21)
+    net = UNetSeeInDark(4, 4).cuda()
+    g = torch.Generator(device='cuda').manual_seed(5)
+    shape = (2, 4, 64, 96)
+    x = torch.rand(*shape, device='cuda', generator=g)
+    dout = torch.randn(*shape, device='cuda', generator=g) / x.numel()
+    nparam = net._offsets[-1]
+    lib = L.lib()
+
+    def step(xin, dg, params, m, v, grads):
+        out, key, _ = net._engine_forward(xin, save=True)
+        net._engine_backward(dg, key, tuple(xin.shape), grads=grads)
+        L.check(lib.eld_adam_step(L.dptr(params), L.dptr(grads), L.dptr(m), L.dptr(v), nparam, 1e-4, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, L.cur_stream()), 'eld_adam_step')
+        return out
+
+    p0 = net.flat_params.detach().clone()
+    # eager reference (also the warm-up that sets kernel attributes and per-device caches before the capture)
+    grads_e = torch.empty(nparam, device='cuda'); m_e = torch.zeros(nparam, device='cuda'); v_e = torch.zeros(nparam, device='cuda')
+    out_e = step(x, dout, net.flat_params, m_e, v_e, grads_e).clone()
+    p_e = net.flat_params.detach().clone()
+    net.flat_params.data.copy_(p0)
+    torch.cuda.synchronize()
+    # capture the same chain
+    grads_g = torch.empty(nparam, device='cuda'); m_g = torch.zeros(nparam, device='cuda'); v_g = torch.zeros(nparam, device='cuda')
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out_g = step(x, dout, net.flat_params, m_g, v_g, grads_g)
+    net.flat_params.data.copy_(p0); m_g.zero_(); v_g.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_g, out_e) and torch.equal(grads_g, grads_e) and torch.equal(net.flat_params.detach(), p_e)
+    # second replay on new data written in place: equals a fresh eager step from the same state
+    x2 = torch.rand(*shape, device='cuda', generator=g)
+    p1, m1, v1 = net.flat_params.detach().clone(), m_g.clone(), v_g.clone()
+    x.copy_(x2)
+    graph.replay()
+    torch.cuda.synchronize()
+    out_r, grads_r, p_r = out_g.clone(), grads_g.clone(), net.flat_params.detach().clone()
+    net.flat_params.data.copy_(p1)
+    grads_e2 = torch.empty(nparam, device='cuda')
+    out_e2 = step(x2, dout, net.flat_params, m1, v1, grads_e2)
+    torch.cuda.synchronize()
+    assert torch.equal(out_r, out_e2) and torch.equal(grads_r, grads_e2) and torch.equal(net.flat_params.detach(), p_r)
