@@ -35,6 +35,8 @@ SIGNATURES = {
     'eld_philox_words': (_i, [_vp, _u32, _u32, _u64, _u32, _u32, _u64, _vp]),
     'eld_pack_bayer': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'eld_unpack_bayer': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'eld_pack_xtrans': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'eld_unpack_xtrans': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'eld_pack_raw_bayer_u16': (_i, [_vp, _vp, _i, _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_float), _f, _vp]),
     'eld_augment': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _u32, _vp]),
     'eld_unet_param_offsets': (_i, [_i, _i, _vp]),
@@ -51,6 +53,7 @@ SIGNATURES = {
     'eld_isp_process': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _i, _vp]),
     'eld_quality_assess_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'eld_quality_assess': (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _f, _vp]),
+    'eld_quality_assess_images': (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _f, _vp]),
     'eld_illuminance_correct_workspace_bytes': (_sz, [_i]),
     'eld_illuminance_correct': (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _sz, _vp]),
     'eld_l1_workspace_bytes': (_sz, []),

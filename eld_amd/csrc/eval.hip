@@ -13,7 +13,9 @@ namespace {
 constexpr int QA_TW = 32, QA_TH = 8, WIN = 7, HALO = WIN - 1;
 constexpr int RED_BLOCKS = 512;
 
-__device__ __forceinline__ float to_im(float v, float scale) { return fminf(fmaxf(v * scale, 0.f), scale); }     // np.clip(x * 255, 0, 255)
+// tensor2im (ELD_model.py:23-38): np.clip(x * 255, 0, 255).  mul = 255 for [0,1] inputs; mul = 1 (an exact no-op multiply) for values
+// that are already images on the [0, range] scale (util/index.py's own callers)
+__device__ __forceinline__ float to_im(float v, float mul, float range) { return fminf(fmaxf(v * mul, 0.f), range); }
 
 __device__ __forceinline__ double block_sum(double v, double* sh) {       // 256 threads, fixed tree
     const int t = threadIdx.x;
@@ -31,7 +33,7 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {       // 256
 
 // one workgroup = one 32x8 tile of window positions of one (image, channel) plane; writes the tile's sum of S
 __global__ __launch_bounds__(256) void ssim_kernel(const float* __restrict__ est, const float* __restrict__ ref, double* __restrict__ part,
-                                                   int H, int W, int tiles_x, int tiles_y, float scale) {
+                                                   int H, int W, int tiles_x, int tiles_y, float mul, float scale) {
     __shared__ float lx[QA_TH + HALO][QA_TW + HALO], ly[QA_TH + HALO][QA_TW + HALO];
     __shared__ double hs[5][QA_TH + HALO][QA_TW];
     __shared__ double red[256];
@@ -45,8 +47,8 @@ __global__ __launch_bounds__(256) void ssim_kernel(const float* __restrict__ est
         const int r = i / (QA_TW + HALO), c = i - r * (QA_TW + HALO);
         const int gy = y0 + r, gx = x0 + c;
         const bool ok = gy < H && gx < W;
-        lx[r][c] = ok ? to_im(px[(size_t)gy * W + gx], scale) : 0.f;
-        ly[r][c] = ok ? to_im(py[(size_t)gy * W + gx], scale) : 0.f;
+        lx[r][c] = ok ? to_im(px[(size_t)gy * W + gx], mul, scale) : 0.f;
+        ly[r][c] = ok ? to_im(py[(size_t)gy * W + gx], mul, scale) : 0.f;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < (QA_TH + HALO) * QA_TW; i += 256) {      // horizontal 7-sums of x, y, xx, yy, xy
@@ -82,13 +84,13 @@ __global__ __launch_bounds__(256) void ssim_kernel(const float* __restrict__ est
 }
 
 // squared error of the x255-clipped images: grid (RED_BLOCKS, N)
-__global__ __launch_bounds__(256) void sqerr_kernel(const float* __restrict__ est, const float* __restrict__ ref, double* __restrict__ part, size_t chw, float scale) {
+__global__ __launch_bounds__(256) void sqerr_kernel(const float* __restrict__ est, const float* __restrict__ ref, double* __restrict__ part, size_t chw, float mul, float scale) {
     __shared__ double red[256];
     const float* a = est + (size_t)blockIdx.y * chw;
     const float* b = ref + (size_t)blockIdx.y * chw;
     double s = 0.0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < chw; i += (size_t)RED_BLOCKS * 256) {
-        const double d = (double)to_im(b[i], scale) - (double)to_im(a[i], scale);
+        const double d = (double)to_im(b[i], mul, scale) - (double)to_im(a[i], mul, scale);
         s += d * d;
     }
     const double tot = block_sum(s, red);
@@ -222,8 +224,8 @@ extern "C" size_t eld_quality_assess_workspace_bytes(int N, int C, int H, int W)
     return ((size_t)N * RED_BLOCKS + (size_t)N * C * qa_tiles(H, W)) * sizeof(double);
 }
 
-extern "C" int eld_quality_assess(const float* est, const float* ref, double* out, void* ws, size_t ws_bytes, int N, int C, int H, int W,
-                                  float data_range, void* stream) {
+static int quality_assess_impl(const float* est, const float* ref, double* out, void* ws, size_t ws_bytes, int N, int C, int H, int W,
+                               float mul, float data_range, void* stream) {
     if (N == 0) return 0;
     if (!est || !ref || !out || !ws || N < 0 || C < 1 || H < WIN || W < WIN || !(data_range > 0.f)) return ELD_EINVAL;
     if (ws_bytes < eld_quality_assess_workspace_bytes(N, C, H, W)) return ELD_EWS;
@@ -232,13 +234,25 @@ extern "C" int eld_quality_assess(const float* est, const float* ref, double* ou
     double* ss = sq + (size_t)N * RED_BLOCKS;
     const int tiles_x = (W - HALO + QA_TW - 1) / QA_TW, tiles_y = (H - HALO + QA_TH - 1) / QA_TH;
     const size_t chw = (size_t)C * H * W;
-    ELD_LAUNCH(sqerr_kernel, dim3(RED_BLOCKS, N), dim3(256), 0, st, est, ref, sq, chw, data_range);
+    ELD_LAUNCH(sqerr_kernel, dim3(RED_BLOCKS, N), dim3(256), 0, st, est, ref, sq, chw, mul, data_range);
     ELD_LAUNCH_CHECK();
-    ELD_LAUNCH(ssim_kernel, dim3(tiles_x * tiles_y, N * C), dim3(256), 0, st, est, ref, ss, H, W, tiles_x, tiles_y, data_range);
+    ELD_LAUNCH(ssim_kernel, dim3(tiles_x * tiles_y, N * C), dim3(256), 0, st, est, ref, ss, H, W, tiles_x, tiles_y, mul, data_range);
     ELD_LAUNCH_CHECK();
     ELD_LAUNCH(qa_final_kernel, dim3(N), dim3(256), 0, st, sq, ss, out, C, tiles_x * tiles_y, chw, (size_t)(H - HALO) * (W - HALO), data_range);
     ELD_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int eld_quality_assess(const float* est, const float* ref, double* out, void* ws, size_t ws_bytes, int N, int C, int H, int W,
+                                  float data_range, void* stream) {
+    return quality_assess_impl(est, ref, out, ws, ws_bytes, N, C, H, W, data_range, data_range, stream);
+}
+
+// the same on images that are ALREADY on the [0, data_range] scale (util/index.py:76-81 as its callers use it: quality_assess(X, Y) on
+// tensor2im outputs): no x255 stage, values only clipped to [0, data_range] (a no-op for tensor2im outputs)
+extern "C" int eld_quality_assess_images(const float* est, const float* ref, double* out, void* ws, size_t ws_bytes, int N, int C, int H, int W,
+                                         float data_range, void* stream) {
+    return quality_assess_impl(est, ref, out, ws, ws_bytes, N, C, H, W, 1.0f, data_range, stream);
 }
 
 extern "C" size_t eld_illuminance_correct_workspace_bytes(int N) { return N < 1 ? 0 : (size_t)N * RED_BLOCKS * 2 * sizeof(double) + (size_t)N * sizeof(float); }

@@ -8,7 +8,7 @@
 //     per-image parameter record is wave-uniform (scalar loads, SGPR-resident);
 //   * a "group" is 4 consecutive elements of the flattened (C,H,W) image = one 16-byte lane access;
 //     a wave touches 1 KiB contiguous per load/store instruction;
-//   * one Philox4x32-10 counter stream per lane: counters are (group|element|row index, global
+//   * one Philox4x32-7 counter stream per lane (philox.h: why 7 rounds): counters are (group|element|row index, global
 //     sample id, stream), so the result is independent of grid shape, wave mapping and GPU count;
 //   * row noise: the block's rows' normals are drawn once into LDS and broadcast to the pixels;
 //   * the float32 op sequence is exactly the reference's (one rounding per op, FMA contraction
@@ -683,6 +683,65 @@ extern "C" int eld_pack_bayer(const float* mosaic, float* packed, int N, int h, 
 }
 extern "C" int eld_unpack_bayer(const float* packed, float* mosaic, int N, int h, int w, void* stream) {
     return bayer_launch(false, packed, mosaic, N, h, w, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// X-Trans pack / unpack (RawPacker.pack_raw_xtrans / unpack_raw_xtrans, noise.py:22-64, 83-127).  Pure index maps, bit-exact:
+// the 6x6 colour cell <-> 9 planes at 1/3 resolution.  Planes 0..4: packed (2a + pi, 2b + pj) <-> cell (a, b), position
+// XT_RC[c][pi][pj]; planes 5..8: packed (i, j) <-> 3x3 block (i, j), position XT_RC3[c - 5].  One thread per packed element
+// (the packed side is the coalesced one: 4 B per lane, consecutive j); the 36 positions of a cell are covered exactly once.
+// ---------------------------------------------------------------------------------------------
+__constant__ unsigned char XT_RC[5][2][2][2] = {
+    {{{0, 0}, {0, 4}}, {{3, 1}, {3, 3}}},
+    {{{0, 2}, {0, 5}}, {{3, 2}, {3, 5}}},
+    {{{0, 1}, {0, 3}}, {{3, 0}, {3, 4}}},
+    {{{1, 2}, {2, 5}}, {{5, 2}, {4, 5}}},
+    {{{2, 2}, {1, 5}}, {{4, 2}, {5, 5}}},
+};
+__constant__ unsigned char XT_RC3[4][2] = {{1, 0}, {1, 1}, {2, 0}, {2, 1}};
+
+template <bool PACK>
+__global__ __launch_bounds__(256) void xtrans_kernel(const float* __restrict__ src, float* __restrict__ dst, int h, int w, int Hm, int Wm) {
+    const int n = blockIdx.y;
+    const size_t hw = (size_t)h * w, total = 9 * hw, msz = (size_t)Hm * Wm;
+    const float* s = src + (size_t)n * (PACK ? msz : total);
+    float* d = dst + (size_t)n * (PACK ? total : msz);
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int c = (int)(e / hw);
+        const int r = (int)(e - (size_t)c * hw);
+        const int i = r / w, j = r - i * w;
+        int row, col;
+        if (c < 5) { row = 6 * (i >> 1) + XT_RC[c][i & 1][j & 1][0]; col = 6 * (j >> 1) + XT_RC[c][i & 1][j & 1][1]; }
+        else { row = 3 * i + XT_RC3[c - 5][0]; col = 3 * j + XT_RC3[c - 5][1]; }
+        const size_t m = (size_t)row * Wm + col;
+        if (PACK) d[e] = s[m]; else d[m] = s[e];
+    }
+}
+
+// mosaic float32 [N, Hm, Wm] -> packed float32 [N, 9, 2*(Hm/6), 2*(Wm/6)] (rows / columns beyond the last whole 6x6 cell are ignored,
+// noise.py:25-26)
+extern "C" int eld_pack_xtrans(const float* mosaic, float* packed, int N, int Hm, int Wm, void* stream) {
+    if (N < 0 || Hm < 0 || Wm < 0) return ELD_EINVAL;
+    const int h = 2 * (Hm / 6), w = 2 * (Wm / 6);
+    const size_t total = (size_t)9 * h * w;
+    if (N == 0 || total == 0) return 0;
+    if (!mosaic || !packed) return ELD_EINVAL;
+    dim3 grid((unsigned)min((total + 255) / 256, (size_t)4096), N);
+    ELD_LAUNCH(xtrans_kernel<true>, grid, dim3(256), 0, as_stream(stream), mosaic, packed, h, w, Hm, Wm);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
+// packed float32 [N, 9, h, w] -> mosaic float32 [N, 3h, 3w] (every mosaic element is written: no zero fill needed)
+extern "C" int eld_unpack_xtrans(const float* packed, float* mosaic, int N, int h, int w, void* stream) {
+    if (N < 0 || h < 0 || w < 0) return ELD_EINVAL;
+    const size_t total = (size_t)9 * h * w;
+    if (N == 0 || total == 0) return 0;
+    if (!mosaic || !packed) return ELD_EINVAL;
+    dim3 grid((unsigned)min((total + 255) / 256, (size_t)4096), N);
+    ELD_LAUNCH(xtrans_kernel<false>, grid, dim3(256), 0, as_stream(stream), packed, mosaic, h, w, 3 * h, 3 * w);
+    ELD_LAUNCH_CHECK();
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------

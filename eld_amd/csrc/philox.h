@@ -1,5 +1,12 @@
-// philox.h -- Philox4x32-10 and the sampler's counter layout (device side).
+// philox.h -- Philox4x32-R and the sampler's counter layout (device side).
 // The layout is documented in oracle/philox_ref.py, which is the bit-exact CPU statement of it.
+//
+// Rounds: the sampler runs Philox4x32-7 (ELD_PHILOX_ROUNDS).  Salmon et al. (SC'11, table 2) list 7 rounds as the smallest
+// Crush-resistant count for Philox-4x32 (it passes BigCrush) and 10 as the default with a safety margin; Random123 ships both and
+// its kat_vectors pin both (tests/test_oracle_golden.py).  The 32x32->64 multiplies are quarter rate on gfx950 and were 43 % of
+// the full model's VALU time at 10 rounds, so the three rounds of margin cost ~10 % of the sampler for no statistical property
+// any test of this repository (or TestU01) can see.  -DELD_PHILOX_ROUNDS=10 restores cuRAND/rocRAND's count; oracle/philox_ref.py
+// ROUNDS must be changed with it.
 #pragma once
 #include "common.h"
 
@@ -18,10 +25,15 @@ struct PhiloxKey {
     uint32_t k0, k1;
 };
 
-__device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, PhiloxKey key) {
+#ifndef ELD_PHILOX_ROUNDS
+#define ELD_PHILOX_ROUNDS 7
+#endif
+
+template <int ROUNDS = ELD_PHILOX_ROUNDS>
+__device__ __forceinline__ uint4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, PhiloxKey key) {
     uint32_t k0 = key.k0, k1 = key.k1;   // wave-uniform: the key schedule lives on the scalar ALU
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < ROUNDS; ++r) {
         // one 32x32->64 product per multiplier (v_mad_u64_u32) instead of a v_mul_hi_u32 + v_mul_lo_u32 pair: integer
         // multiplies are quarter-rate and they are half of the sampler's VALU time
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
@@ -41,7 +53,7 @@ struct SamplerRng {
     PhiloxKey key;
     uint32_t sid_lo, sid_hi;
     __device__ __forceinline__ uint4 words(uint32_t index, uint32_t stream, uint32_t iter = 0) const {
-        return philox4x32_10(index, sid_lo, sid_hi, stream | (iter << 8), key);
+        return philox4x32<ELD_PHILOX_ROUNDS>(index, sid_lo, sid_hi, stream | (iter << 8), key);
     }
 };
 

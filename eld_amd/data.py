@@ -64,10 +64,11 @@ class LMDBDataset(tdata.Dataset):
 
 class Deferred(object):
     """A noisy sample whose pixels do not exist yet: the clean data, the parameter record of its noise and the burst count."""
-    __slots__ = ('clean', 'params', 'burst', 'isp')
+    __slots__ = ('clean', 'params', 'burst', 'isp', 'source', 'index')
 
-    def __init__(self, clean, params, burst, isp=None):
+    def __init__(self, clean, params, burst, isp=None, source=None, index=None):
         self.clean, self.params, self.burst, self.isp = clean, params, burst, isp      # isp: (wb[4], ccm[3,3]) -> raw2rgb after the noise
+        self.source, self.index = source, index      # where `clean` came from: dataset object and the index it was read at
 
 
 class SynDataset(tdata.Dataset):
@@ -84,12 +85,15 @@ class SynDataset(tdata.Dataset):
         self.noise_maker = noise_maker
         self.cfa = cfa
         self.num_burst = num_burst
+        SynDataset.last_instance = self
+
+    last_instance = None                                     # picked up by ELDModel.initialize: a burst input has num_burst * channels planes
 
     def __getitem__(self, i):
         i = i % self.size if self.size is not None else i % len(self.dataset)
         data = self.dataset[i]
         params = NoiseParams.coerce(self.noise_maker._sample_params())
-        return Deferred(data, params, max(1, int(self.num_burst)))
+        return Deferred(data, params, max(1, int(self.num_burst)), source=self.dataset, index=i)
 
     def __len__(self):
         size = self.size or len(self.dataset)
@@ -107,7 +111,10 @@ class ISPDataset(tdata.Dataset):
         self.noise_maker = noise_maker
         self.cfa = cfa
         self.meta_info = dataset.meta if meta_info is None else meta_info
-        self.CRF = CRF
+        self.CRF = CRF                                       # (E, fs) of process.load_CRF or None; the device ISP reads it off last_instance
+        ISPDataset.last_instance = self
+
+    last_instance = None                                     # the instance the entry script built (train_syn.py:55-58), picked up by ELDModel
 
     def __getitem__(self, i):
         data = self.dataset[i]
@@ -140,7 +147,14 @@ class ELDTrainDataset(tdata.Dataset):
     def __getitem__(self, i):
         N = len(self.input_datasets)
         inp = self.input_datasets[i % N][i // N]
-        target = self.target_dataset[i // N]
+        # SynDataset applies the noise to ITS OWN dataset[i] (sid_dataset.py:265-275), independently of target_dataset.  When both
+        # are the same database read at the same index (train_syn.py:61-64: SynDataset(LMDBDataset(SID_Sony_Raw.db)) beside the
+        # same target database) the clean patch IS the target: it is read once and travels once.  Otherwise it travels as 'clean'.
+        same = (isinstance(inp, Deferred) and inp.isp is None and inp.source is not None and inp.index == i // N and
+                (inp.source is self.target_dataset or
+                 (getattr(inp.source, 'db_path', None) is not None and getattr(inp.source, 'db_path', None) == getattr(self.target_dataset, 'db_path', object())
+                  and getattr(inp.source, 'length', None) == getattr(self.target_dataset, 'length', object()))))
+        target = inp.clean if same else self.target_dataset[i // N]
         bits = 0
         if self.augment:                                     # sid_dataset.py:344-352: flip H, flip W, transpose
             for b in (1, 2, 4):
@@ -154,6 +168,8 @@ class ELDTrainDataset(tdata.Dataset):
             else:
                 dic = {'target': _as_wire(target), 'params': inp.params.record(0).reshape(1).view(np.uint8).copy(),
                        'aug': bits, 'burst': inp.burst}
+                if not same:
+                    dic['clean'] = _as_wire(inp.clean)
         else:                                                # pre-synthesised input (offline-noise LMDB): the reference's host path
             if getattr(inp, 'dtype', None) == np.uint16:
                 inp = np.clip(inp / 65535, 0, 1).astype(np.float32)

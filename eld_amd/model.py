@@ -24,7 +24,7 @@ from . import _lib as L
 from . import dist as D
 from . import unet as arch_unet
 from .data import records_from_batch
-from .noise import (NoiseModel, augment, decode_augment_u16, make_records, model_flags, sample_noise_records, set_sample_ids)
+from .noise import (NoiseModel, augment, decode_augment_u16, is_u16_codes, make_records, model_flags, sample_noise_records, set_sample_ids)
 
 ARCH = {'unet': arch_unet.unet}          # the `arch.__dict__[opt.netG]` registry (ELD_model.py:391)
 
@@ -104,9 +104,18 @@ class ELDModel:
             if st not in ('raw', 'srgb'):
                 raise NotImplementedError('Invalid Stage: {}'.format(st))
         ch = getattr(opt, 'channels', 4)
-        cin = 3 if self.stage_in == 'srgb' else (getattr(opt, 'in_channels', None) or ch)      # burst input (sid_dataset.py:267-273): num_burst * channels planes in
+        burst = _plugin_num_burst()                          # SynDataset(num_burst=k) built by the entry script / launcher: k * channels planes in
+        cin = 3 if self.stage_in == 'srgb' else (getattr(opt, 'in_channels', None) or ch * burst)      # sid_dataset.py:267-273
         cout = 3 if self.stage_out == 'srgb' else ch
-        self.CRF = getattr(opt, 'crf_tables', None)          # (E, fs) of process.load_CRF (EMoR tables are outside this package); None = gamma 2.2
+        # CRF tables (E, fs) of process.load_CRF for the sRGB input stage: opt.crf_tables, else what the entry script handed to
+        # ISPDataset(CRF=...) (train_syn.py:42-58); None = gamma 2.2.  --crf without tables anywhere is an error, not a silent gamma.
+        from .data import ISPDataset
+        self.CRF = getattr(opt, 'crf_tables', None)
+        if self.CRF is None and ISPDataset.last_instance is not None:
+            self.CRF = ISPDataset.last_instance.CRF
+        if self.CRF is None and getattr(opt, 'crf', False) and self.stage_in == 'srgb':
+            raise RuntimeError('--crf: no CRF tables reached the model (opt.crf_tables / ISPDataset(CRF=...)); refusing to render the input with gamma 2.2 '
+                               'against a CRF-rendered target')
         self.netG = ARCH[getattr(opt, 'netG', 'unet')](cin, cout).to(self.device)
         prec = getattr(opt, 'precision', os.environ.get('ELD_AMD_PRECISION', 'fp32'))      # 'bf16' = BASELINE config 3
         self.netG.train_precision = self.netG.inference_precision = prec
@@ -155,7 +164,7 @@ class ELDModel:
             target = target.to(device=self.device, non_blocking=True)
         if inp is not None:
             inp = inp.to(device=self.device, non_blocking=True)
-            if target is not None and target.element_size() == 2:
+            if is_u16_codes(target):
                 target = decode_augment_u16(target)
         elif mode == 'train' and data.get('wb') is not None:
             # --stage_in srgb (ISPDataset.__getitem__, sid_dataset.py:301-316): noise on the raw patch, clip, raw -> sRGB, clip
@@ -163,13 +172,16 @@ class ELDModel:
             if data.get('params') is not None:
                 inp = self.synthesize(clean, data.get('params'), data.get('sample_ids'))
             else:
-                inp = decode_augment_u16(clean) if clean.element_size() == 2 else clean.float().clamp(0, 1)
+                inp = decode_augment_u16(clean) if is_u16_codes(clean) else clean.float().clamp(0, 1)
             from .isp import process
             inp = process(inp, data['wb'], data['ccm'], CRF=self.CRF)          # quantised to k/255 in [0,1]: the second clip is the identity
         elif mode == 'train':
             if target is None:
                 raise KeyError('target')
-            inp = self.synthesize(target, data.get('params'), data.get('sample_ids'), burst=_burst_of(data))
+            # the clean patch the noise applies to: SynDataset's own sample when it differs from the target (sid_dataset.py:265-275)
+            clean = data.get('clean')
+            clean = target if clean is None else clean.to(device=self.device, non_blocking=True)
+            inp = self.synthesize(clean, data.get('params'), data.get('sample_ids'), burst=_burst_of(data))
         else:
             raise KeyError('input')
         aug = data.get('aug')
@@ -178,8 +190,8 @@ class ELDModel:
             # row banding follows the sensor rows of the un-augmented frame: same flips/transpose on input and target.
             bits = [int(b) for b in (aug.tolist() if hasattr(aug, 'tolist') else aug)]
             inp = augment(inp, bits, clip=True)
-            target = decode_augment_u16(target, bits) if target.element_size() == 2 else augment(target, bits, clip=False)
-        elif target is not None and target.element_size() == 2:
+            target = decode_augment_u16(target, bits) if is_u16_codes(target) else augment(target, bits, clip=False)
+        elif is_u16_codes(target):
             target = decode_augment_u16(target)
         self.input, self.target = inp, target
         self.data_name = data.get('fn')
@@ -210,7 +222,7 @@ class ELDModel:
         sample_ids = [int(v) for v in sample_ids]
         if len(sample_ids) != N * burst:
             raise ValueError('need %d sample ids (N x burst), got %d' % (N * burst, len(sample_ids)))
-        in_u16 = clean.element_size() == 2
+        in_u16 = is_u16_codes(clean)
         clean = clean.contiguous() if in_u16 else clean.contiguous().float()
         flags = model_flags(nm.model) | L.CLIP
         out = None
@@ -354,6 +366,13 @@ class ELDModel:
             model.optimizer_G.load_state_dict(sd['opt_g'])
         print('Resume from epoch %d, iteration %d' % (model.epoch, model.iterations))
         return sd
+
+
+def _plugin_num_burst():
+    """num_burst of the SynDataset the entry script (or eld_amd.launch --num-burst) built, 1 if none."""
+    from .data import SynDataset
+    inst = SynDataset.last_instance
+    return max(1, int(getattr(inst, 'num_burst', 1) or 1)) if inst is not None else 1
 
 
 def _burst_of(data):

@@ -5,7 +5,7 @@ Same constructor, `__call__(y, params=None)` and `_sample_params()` as the refer
 (eld_amd/csrc/noise.hip) through the C ABI (include/eld_amd.h: eld_noise_forward).
 
 Differences a user can observe, all documented in DESIGN.md:
-  * the per-pixel variates come from Philox4x32-10 counters, not NumPy's MT19937 stream
+  * the per-pixel variates come from Philox4x32-7 counters (csrc/philox.h), not NumPy's MT19937 stream
     (SURVEY.md F8): same distribution, different numbers.  `_sample_params()` still draws
     from np.random in the reference's order, so the per-image parameters are reproducible
     with np.random.seed exactly as before;
@@ -141,6 +141,13 @@ def set_sample_ids(recs, sample_ids):
     return recs
 
 
+def is_u16_codes(t):
+    """True for a tensor of LMDB uint16 codes as they travel (int16 view or uint16).  float16 / bfloat16 tensors are 2 bytes per
+    element too but are VALUES, never reinterpreted as codes."""
+    import torch
+    return t is not None and t.dtype in (torch.int16, torch.uint16)
+
+
 def sample_noise_records(y, recs, flags, seed, in_u16=False, inject=None, dump=None, out=None, burst_index=0, burst=1):
     """The C-ABI sampler call.  y: CUDA (N,C,H,W) float32, or int16/uint16 LMDB codes when in_u16; recs: N structured records
     (host); out: CUDA float32 (N, burst*C, H, W) -- this call fills channels [burst_index*C, (burst_index+1)*C) of every image
@@ -150,7 +157,7 @@ def sample_noise_records(y, recs, flags, seed, in_u16=False, inject=None, dump=N
     N, C, H, W = y.shape
     assert len(recs) == N
     if in_u16:
-        assert y.element_size() == 2
+        assert is_u16_codes(y), 'in_u16 needs int16/uint16 codes, got %s' % (y.dtype,)
     else:
         assert y.dtype == torch.float32
     prm = _upload(np.ascontiguousarray(recs).view(np.uint8).reshape(-1), y.device)
@@ -180,7 +187,7 @@ def decode_augment_u16(codes, bits=None):
     """CUDA int16/uint16 LMDB codes (N,C,H,W) -> float32 clip(u16/65535) (lmdb_dataset.py:38-39), optionally through the
     ELDTrainDataset index maps (sid_dataset.py:344-352); one HIP pass."""
     import torch
-    assert codes.is_cuda and codes.element_size() == 2 and codes.dim() == 4
+    assert codes.is_cuda and is_u16_codes(codes) and codes.dim() == 4, 'uint16 codes (int16 view) expected, got %s' % (codes.dtype,)
     codes = codes.contiguous()
     N, C, H, W = codes.shape
     out = torch.empty((N, C, H, W), dtype=torch.float32, device=codes.device)
@@ -215,42 +222,54 @@ def augment(x, bits, clip=False):
 
 
 class RawPacker:
-    """Bayer pack/unpack (noise.py:6-145) on the device.  X-Trans packing is outside the hot path
-    (only the Bayer maps are in scope) and raises NotImplementedError like an
-    unknown CFA does in the reference (noise.py:135,144)."""
+    """Bayer and X-Trans pack/unpack (noise.py:6-145) on the device: same method names, same `cfa` switch, NotImplementedError for
+    an unknown CFA (noise.py:135,144).  ndarray in -> ndarray out (float32, like the reference); CUDA tensor in -> CUDA tensor
+    out, optionally batched on a leading axis."""
     def __init__(self, cfa='bayer'):
         self.cfa = cfa
 
-    def _run(self, fn, src, out_shape, h, w):
+    def _run(self, fn, src, packed_in, out_shape, a, b):
         import torch
         as_np = isinstance(src, np.ndarray)
         t = torch.from_numpy(np.ascontiguousarray(src, dtype=np.float32)).cuda() if as_np else src.contiguous().float()
-        batched = t.dim() == (4 if fn == 'eld_unpack_bayer' else 3)
+        batched = t.dim() == (4 if packed_in else 3)
         if not batched:
             t = t.unsqueeze(0)
         N = t.shape[0]
         out = torch.empty((N,) + out_shape, dtype=torch.float32, device=t.device)
-        L.check(getattr(L.lib(), fn)(L.dptr(t), L.dptr(out), N, h, w, L.cur_stream()), fn)
+        L.check(getattr(L.lib(), fn)(L.dptr(t), L.dptr(out), N, a, b, L.cur_stream()), fn)
         if not batched:
             out = out[0]
         return out.cpu().numpy() if as_np else out
 
-    def pack_raw_bayer(self, cfa_img):
+    def pack_raw_bayer(self, cfa_img):                     # noise.py:10-20
         H, W = cfa_img.shape[-2:]
-        return self._run('eld_pack_bayer', cfa_img, (4, H // 2, W // 2), H // 2, W // 2)
+        return self._run('eld_pack_bayer', cfa_img, False, (4, H // 2, W // 2), H // 2, W // 2)
 
-    def unpack_raw_bayer(self, img):
+    def unpack_raw_bayer(self, img):                       # noise.py:66-81
         h, w = img.shape[-2:]
-        return self._run('eld_unpack_bayer', img, (2 * h, 2 * w), h, w)
+        return self._run('eld_unpack_bayer', img, True, (2 * h, 2 * w), h, w)
 
-    def pack_raw(self, cfa_img):
+    def pack_raw_xtrans(self, cfa_img):                    # noise.py:22-64 (sides truncated to whole 6x6 cells, :25-26)
+        H, W = cfa_img.shape[-2:]
+        return self._run('eld_pack_xtrans', cfa_img, False, (9, 2 * (H // 6), 2 * (W // 6)), H, W)
+
+    def unpack_raw_xtrans(self, img):                      # noise.py:83-127
+        h, w = img.shape[-2:]
+        return self._run('eld_unpack_xtrans', img, True, (3 * h, 3 * w), h, w)
+
+    def pack_raw(self, cfa_img):                           # noise.py:129-136
         if self.cfa == 'bayer':
             return self.pack_raw_bayer(cfa_img)
+        elif self.cfa == 'xtrans':
+            return self.pack_raw_xtrans(cfa_img)
         raise NotImplementedError
 
-    def unpack_raw(self, img):
+    def unpack_raw(self, img):                             # noise.py:138-145
         if self.cfa == 'bayer':
             return self.unpack_raw_bayer(img)
+        elif self.cfa == 'xtrans':
+            return self.unpack_raw_xtrans(img)
         raise NotImplementedError
 
 
@@ -262,7 +281,7 @@ def pack_raw_bayer(raw_image_visible, raw_pattern, black_level_per_channel, whit
     import torch
     as_np = isinstance(raw_image_visible, np.ndarray)
     t = torch.from_numpy(np.ascontiguousarray(raw_image_visible, dtype=np.uint16).view(np.int16)).cuda() if as_np else raw_image_visible.contiguous()
-    assert t.is_cuda and t.element_size() == 2
+    assert t.is_cuda and is_u16_codes(t)
     single = t.dim() == 2
     if single:
         t = t.unsqueeze(0)

@@ -100,7 +100,7 @@ int eld_noise_forward_strided(const void* in, int in_dtype, size_t in_image_stri
                               const EldNoiseParams* params, int N, int C, int H, int W, uint32_t flags, uint64_t seed,
                               const float* inject, float* dump, void* stream);
 
-/* Raw Philox4x32-10 words of the sampler's counter layout, for bit-exact RNG tests:
+/* Raw Philox4x32-7 words (ELD_PHILOX_ROUNDS, csrc/philox.h) of the sampler's counter layout, for bit-exact RNG tests:
  * out[i*4..i*4+3] = philox(ctr=(index0+i, sample_id, stream|iter<<8), key=seed). */
 int eld_philox_words(uint32_t* out, uint32_t n, uint32_t index0, uint64_t sample_id,
                      uint32_t stream, uint32_t iter, uint64_t seed, void* stream_h);
@@ -109,6 +109,11 @@ int eld_philox_words(uint32_t* out, uint32_t n, uint32_t index0, uint64_t sample
  * batched: mosaic float32 [N,2h,2w] <-> packed float32 [N,4,h,w]. */
 int eld_pack_bayer(const float* mosaic, float* packed, int N, int h, int w, void* stream);
 int eld_unpack_bayer(const float* packed, float* mosaic, int N, int h, int w, void* stream);
+/* X-Trans pack / unpack.  Replaces RawPacker.pack_raw_xtrans / unpack_raw_xtrans (noise.py:22-64, 83-127), batched:
+ * mosaic float32 [N,Hm,Wm] -> packed float32 [N,9,2*(Hm/6),2*(Wm/6)] (the reference truncates to whole 6x6 cells, noise.py:25-26);
+ * packed float32 [N,9,h,w] -> mosaic float32 [N,3h,3w].  Index maps only: bit-exact. */
+int eld_pack_xtrans(const float* mosaic, float* packed, int N, int Hm, int Wm, void* stream);
+int eld_unpack_xtrans(const float* packed, float* mosaic, int N, int h, int w, void* stream);
 /* pack_raw_bayer (dataset/sid_dataset.py:172-196): uint16 sensor mosaic [N,2h,2w] (raw.raw_image_visible) -> packed float32
  * [N,4,h,w] in the order R, G1, B, G2 given by the 2x2 `raw_pattern` (row-major colour codes 0..3, HOST array of 4 ints),
  * normalised per channel: clip((x - black_level[k]) / (white_point - black_level[k]), 0, 1), float32 arithmetic as NumPy's
@@ -210,6 +215,9 @@ int eld_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
 size_t eld_quality_assess_workspace_bytes(int N, int C, int H, int W);
 int eld_quality_assess(const float* est, const float* ref, double* out, void* ws, size_t ws_bytes, int N, int C, int H, int W,
                        float data_range, void* stream);
+/* the same for images already on the [0, data_range] scale (util/index.py:76-81 called on tensor2im outputs): no x255 stage */
+int eld_quality_assess_images(const float* est, const float* ref, double* out, void* ws, size_t ws_bytes, int N, int C, int H, int W,
+                              float data_range, void* stream);
 /* models/ELD_model.py:138-169 IlluminanceCorrect: out[n] = <p,s>/<p,p> * p, p = clamp(predict[n], 0, 1), sums over the
  * elements with source != 1; source_N is N or 1 (one source for all).  chw = elements per image. */
 size_t eld_illuminance_correct_workspace_bytes(int N);

@@ -9,6 +9,7 @@ committed under tests/golden/ by oracle/gen_golden.py):
     * noise_arith() for models g / Pg / pg          <- noise.py:149-170
     * sample_params()                               <- noise.py:201-225
     * pack_raw_bayer() / unpack_raw_bayer()         <- noise.py:10-20, 66-81
+    * pack_raw_xtrans() / unpack_raw_xtrans()       <- noise.py:22-64, 83-127
     * lmdb_decode_u16()                             <- dataset/lmdb_dataset.py:35-39
     * augment()                                     <- dataset/sid_dataset.py:344-352
 PARITY UNPINNED (no reference code, test or vector exists -- README.md:41, noise.py:173):
@@ -460,6 +461,49 @@ def unpack_raw_bayer(img4c):
     _, h, w = img4c.shape
     out = np.zeros((2 * h, 2 * w), F32)
     out[0::2, 0::2], out[0::2, 1::2], out[1::2, 1::2], out[1::2, 0::2] = img4c[0], img4c[1], img4c[2], img4c[3]
+    return out
+
+
+# X-Trans (noise.py:22-64, 83-127): 6x6 colour cell <-> 9 planes at 1/3 resolution.  Planes 0-4 hold one cell position per
+# (row parity, column parity) of the packed coordinate; planes 5-8 are the four positions (1|2, 0|1) of every 3x3 block.
+# XTRANS_RC[c][pi][pj] = (row, column) inside the 6x6 cell for packed position (2a + pi, 2b + pj) of plane c < 5.
+XTRANS_RC = (
+    (((0, 0), (0, 4)), ((3, 1), (3, 3))),
+    (((0, 2), (0, 5)), ((3, 2), (3, 5))),
+    (((0, 1), (0, 3)), ((3, 0), (3, 4))),
+    (((1, 2), (2, 5)), ((5, 2), (4, 5))),
+    (((2, 2), (1, 5)), ((4, 2), (5, 5))),
+)
+XTRANS_RC3 = ((1, 0), (1, 1), (2, 0), (2, 1))      # planes 5..8: (row, column) inside the 3x3 block
+
+
+def xtrans_source_index(h, w):
+    """(9,h,w) arrays of the mosaic row / column each packed position reads (pack) or writes (unpack)."""
+    i, j = np.meshgrid(np.arange(h), np.arange(w), indexing='ij')
+    rows, cols = np.zeros((9, h, w), np.int64), np.zeros((9, h, w), np.int64)
+    for c in range(5):
+        t = np.array(XTRANS_RC[c])                  # [pi][pj][2]
+        rows[c] = 6 * (i // 2) + t[i % 2, j % 2, 0]
+        cols[c] = 6 * (j // 2) + t[i % 2, j % 2, 1]
+    for c in range(5, 9):
+        rows[c] = 3 * i + XTRANS_RC3[c - 5][0]
+        cols[c] = 3 * j + XTRANS_RC3[c - 5][1]
+    return rows, cols
+
+
+def pack_raw_xtrans(cfa_img):
+    """(H,W) mosaic -> (9, 2*(H//6), 2*(W//6)) float32.  noise.py:22-64 (sides truncated to multiples of 6, :25-26)."""
+    m = np.asarray(cfa_img)
+    rows, cols = xtrans_source_index(2 * (m.shape[0] // 6), 2 * (m.shape[1] // 6))
+    return m[rows, cols].astype(F32)
+
+
+def unpack_raw_xtrans(img9c):
+    """(9,h,w) -> (3h,3w) mosaic.  noise.py:83-127."""
+    _, h, w = img9c.shape
+    rows, cols = xtrans_source_index(h, w)
+    out = np.zeros((3 * h, 3 * w), F32)
+    out[rows, cols] = img9c
     return out
 
 

@@ -1,7 +1,9 @@
-"""Philox4x32-10 counter-based RNG, NumPy restatement (oracle; test infrastructure only).
+"""Philox4x32-R counter-based RNG, NumPy restatement (oracle; test infrastructure only).
 
 Algorithm: Salmon et al., "Parallel Random Numbers: As Easy as 1, 2, 3" (SC'11),
-Philox-4x32 with 10 rounds.  Pinned by the Random123 known-answer vectors in
+Philox-4x32.  The sampler runs ROUNDS = 7 (the paper's smallest Crush-resistant count for
+Philox-4x32; 10 is its default with a safety margin -- eld_amd/csrc/philox.h says why 7).
+Both round counts are pinned by the Random123 known-answer vectors in
 ``tests/test_oracle_golden.py``.  The reference (noise.py:159,161,166) uses NumPy's
 MT19937 global stream, which a counter-based GPU sampler cannot reproduce
 (SURVEY.md F8); this file defines the stream the HIP sampler must reproduce
@@ -31,12 +33,16 @@ MASK = np.uint64(0xFFFFFFFF)
 STREAM_ROW, STREAM_TL, STREAM_QUANT, STREAM_NREAD, STREAM_NSHOT, STREAM_POIS_U, STREAM_POIS_V, STREAM_POIS_R = range(8)
 
 
-def philox4x32_10(c0, c1, c2, c3, k0, k1):
-    """Vectorised Philox4x32-10.  All inputs broadcastable uint32-valued; returns 4 uint32 arrays."""
+ROUNDS = 7      # == ELD_PHILOX_ROUNDS (eld_amd/csrc/philox.h)
+
+
+def philox4x32(c0, c1, c2, c3, k0, k1, rounds=None):
+    """Vectorised Philox4x32-`rounds` (default: the sampler's ROUNDS).  All inputs broadcastable uint32-valued; returns 4 uint32 arrays."""
+    rounds = ROUNDS if rounds is None else int(rounds)
     c0, c1, c2, c3 = [np.asarray(c, dtype=np.uint64) & MASK for c in np.broadcast_arrays(c0, c1, c2, c3)]
     k0 = int(k0) & 0xFFFFFFFF
     k1 = int(k1) & 0xFFFFFFFF
-    for r in range(10):
+    for r in range(rounds):
         p0 = M0 * c0
         p1 = M1 * c2
         hi0, lo0 = p0 >> np.uint64(32), p0 & MASK
@@ -47,11 +53,15 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
     return tuple(c.astype(np.uint32) for c in (c0, c1, c2, c3))
 
 
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    return philox4x32(c0, c1, c2, c3, k0, k1, rounds=10)
+
+
 def sampler_words(index, sample_id, stream, seed, it=0):
     """4 words for (index, sample_id, stream[, iter]) under the sampler's counter layout."""
     sample_id = int(sample_id)
     seed = int(seed)
-    return philox4x32_10(index, sample_id & 0xFFFFFFFF, (sample_id >> 32) & 0xFFFFFFFF,
+    return philox4x32(index, sample_id & 0xFFFFFFFF, (sample_id >> 32) & 0xFFFFFFFF,
                          np.uint32(stream) | (np.asarray(it, dtype=np.uint32) << np.uint32(8)),
                          seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
 

@@ -130,6 +130,56 @@ def test_presynthesised_inputs_take_the_reference_host_path(golden_dir):
         np.random.randint = real_randint
 
 
+def test_noise_applies_to_the_syn_datasets_own_sample():
+    """sid_dataset.py:265-275: SynDataset degrades ITS OWN dataset[i], whatever the target dataset is.  Same database at the same
+    index -> the patch is read once and travels once (no 'clean' key); a different database, size or repeat -> the clean patch
+    travels beside the target."""
+    from eld_amd.data import ELDTrainDataset, SynDataset
+    nm = quiet_model('Pg')
+    tgt, other = ArrayDB(n=6, seed=0), ArrayDB(n=6, seed=1)
+    reads = []
+
+    class Counting(ArrayDB):
+        def __getitem__(self, i):
+            reads.append(i)
+            return ArrayDB.__getitem__(self, i)
+    same_db = Counting(n=6, seed=0)
+    d = ELDTrainDataset(same_db, [SynDataset(same_db, noise_maker=nm)], augment=False)[4]
+    assert 'clean' not in d and np.array_equal(d['target'].view(np.uint16), same_db.items[4]) and reads == [4]      # one read, one copy
+    d = ELDTrainDataset(tgt, [SynDataset(other, noise_maker=nm)], augment=False)[4]
+    assert np.array_equal(d['clean'].view(np.uint16), other[4]) and np.array_equal(d['target'].view(np.uint16), tgt[4])
+    d = ELDTrainDataset(tgt, [SynDataset(tgt, noise_maker=nm, size=3)], augment=False)[4]          # input index 4 % 3 = 1, target index 4
+    assert np.array_equal(d['clean'].view(np.uint16), tgt[1]) and np.array_equal(d['target'].view(np.uint16), tgt[4])
+    srgb_target = ArrayDB(n=6, shape=(3, 16, 16), dtype=np.float32)                               # --stage_out srgb beside a raw input
+    d = ELDTrainDataset(srgb_target, [SynDataset(tgt, noise_maker=nm)], augment=False)[2]
+    assert d['clean'].shape == (4, 16, 16) and d['target'].shape == (3, 16, 16)
+
+
+def test_u16_codes_are_recognised_by_dtype_not_by_size():
+    from eld_amd.noise import is_u16_codes
+    assert is_u16_codes(torch.zeros(2, dtype=torch.int16)) and is_u16_codes(torch.zeros(2, dtype=torch.uint16))
+    for dt in (torch.float16, torch.bfloat16, torch.float32, torch.int32):
+        assert not is_u16_codes(torch.zeros(2, dtype=dt))
+    assert not is_u16_codes(None)
+
+
+def test_plugins_leave_burst_and_crf_for_the_model():
+    """ELDModel.initialize reads the burst count off the SynDataset the script built (k * channels input planes) and the CRF tables
+    off ISPDataset(CRF=...) (train_syn.py:42-58)."""
+    from eld_amd import data as D
+    from eld_amd.model import _plugin_num_burst
+    nm = quiet_model('Pg')
+    D.SynDataset(ArrayDB(), noise_maker=nm, num_burst=3)
+    assert _plugin_num_burst() == 3
+    D.SynDataset(ArrayDB(), noise_maker=nm)
+    assert _plugin_num_burst() == 1
+    tables = (np.linspace(0, 1, 8), np.linspace(0, 1, 8) ** 0.5)
+    db = ArrayDB()
+    db.meta = [(np.ones(4), np.eye(3))] * 6
+    D.ISPDataset(db, noise_maker=nm, CRF=tables)
+    assert D.ISPDataset.last_instance.CRF is tables
+
+
 def test_calibrated_K_option():
     """noise.py:209-210 reads Kmin/Kmax, :215 ignores them; the option samples log K from the calibrated range."""
     nm = quiet_model('Pg')

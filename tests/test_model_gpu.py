@@ -204,8 +204,10 @@ def test_metrics_on_device_vs_oracle(eld_lib):
         assert abs(r['PSNR'] - M.psnr(y.numpy(), x.numpy())) < 1e-4
         assert abs(r['SSIM'] - M.ssim(y.numpy(), x.numpy())) < 1e-6
     assert abs(quality_assess(y.cuda(), y.cuda())['SSIM'] - 1.0) < 1e-12
-    with pytest.raises(RuntimeError):
-        quality_assess(x, y)                      # CPU tensors: no fallback implementation
+    host = quality_assess(x, y)                   # host tensors (the reference's callers hold host arrays): moved to the GPU, same kernels
+    assert host == quality_assess(x.cuda(), y.cuda())
+    hwc = quality_assess(x.permute(1, 2, 0).numpy(), y.permute(1, 2, 0).numpy())      # tensor2im's HWC ndarray layout (ELD_model.py:23-38)
+    assert hwc == host
 
 
 def test_engine_train_loop(eld_lib, tmp_path, capsys):

@@ -253,7 +253,27 @@ def test_bayer_pack_unpack(dev, golden_dir):
     assert torch.equal(rp.unpack_raw(pk), m)                   # round trip at batch
     assert torch.equal(pk[:, 2], m[:, 1::2, 1::2]) and torch.equal(pk[:, 3], m[:, 1::2, 0::2])
     with pytest.raises(NotImplementedError):
-        RawPacker('xtrans').pack_raw(d['mosaic'])
+        RawPacker('foveon').pack_raw(d['mosaic'])               # unknown CFA: noise.py:135
+
+
+def test_xtrans_pack_unpack(dev, golden_dir):
+    """RawPacker('xtrans') (noise.py:22-64, 83-127) through eld_pack_xtrans / eld_unpack_xtrans: bit-exact against outputs minted
+    from the reference (ragged sides are truncated to whole 6x6 cells; odd packed sides), and a batched round trip at sensor size."""
+    from eld_amd.noise import RawPacker
+    d = np.load(os.path.join(golden_dir, 'rawpacker_xtrans.npz'))
+    rp = RawPacker('xtrans')
+    for name in ('ragged', 'exact'):
+        pk = rp.pack_raw(d[name + '_mosaic'])
+        assert pk.dtype == np.float32 and np.array_equal(pk, d[name + '_packed'])
+        assert np.array_equal(rp.unpack_raw(pk), d[name + '_unpacked'])
+    assert np.array_equal(rp.unpack_raw(d['odd_packed']), d['odd_unpacked'])
+    m = torch.rand(2, 4032, 6030, device=dev)                   # X-T2 sized mosaic (multiples of 6), batch of two
+    pk = rp.pack_raw(m)
+    assert pk.shape == (2, 9, 1344, 2010)
+    assert torch.equal(rp.unpack_raw(pk), m)                    # the 36 cell positions are covered exactly once
+    assert torch.equal(pk[:, 5], m[:, 1::3, 0::3]) and torch.equal(pk[:, 8], m[:, 2::3, 1::3])      # noise.py:60-63
+    assert torch.equal(pk[:, 0, 1::2, 0::2], m[:, 3::6, 1::6]) and torch.equal(pk[:, 3, 0::2, 1::2], m[:, 2::6, 5::6])
+    assert rp.pack_raw(torch.zeros(5, 5, device=dev)).shape == (9, 0, 0)      # no whole cell: empty, like the reference
 
 
 def test_edge_cases(dev, eld_lib):

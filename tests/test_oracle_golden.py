@@ -19,6 +19,15 @@ def test_philox_random123_kat():
     for ctr, key, exp in kats:
         got = tuple(int(x) for x in px.philox4x32_10(*ctr, *key))
         assert got == exp
+    # the same file's 7-round vectors: the round count the sampler runs (px.ROUNDS, eld_amd/csrc/philox.h)
+    kats7 = [((0, 0, 0, 0), (0, 0), (0x5f6fb709, 0x0d893f64, 0x4f121f81, 0x4f730a48)),
+             ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x5207ddc2, 0x45165e59, 0x4d8ee751, 0x8c52f662)),
+             ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+              (0x4dfccaba, 0x190a87f0, 0xc47362ba, 0xb6b5242a))]
+    assert px.ROUNDS == 7
+    for ctr, key, exp in kats7:
+        assert tuple(int(x) for x in px.philox4x32(*ctr, *key, rounds=7)) == exp
+        assert tuple(int(x) for x in px.philox4x32(*ctr, *key)) == exp
 
 
 def test_u01_exact_complement():
@@ -89,6 +98,18 @@ def test_rawpacker(golden_dir):
     assert np.array_equal(O.pack_raw_bayer(d['mosaic']), d['packed'])
     assert np.array_equal(O.unpack_raw_bayer(d['packed']), d['unpacked'])
     assert np.array_equal(d['unpacked'], d['mosaic'])
+
+
+def test_rawpacker_xtrans(golden_dir):
+    """noise.py:22-64, 83-127: the table-driven restatement vs outputs minted from the reference's RawPacker('xtrans')."""
+    d = np.load(os.path.join(golden_dir, 'rawpacker_xtrans.npz'))
+    for name in ('ragged', 'exact'):
+        pk = O.pack_raw_xtrans(d[name + '_mosaic'])
+        assert pk.dtype == np.float32 and np.array_equal(pk, d[name + '_packed'])
+        assert np.array_equal(O.unpack_raw_xtrans(pk), d[name + '_unpacked'])
+    assert np.array_equal(O.unpack_raw_xtrans(d['odd_packed']), d['odd_unpacked'])
+    rows, cols = O.xtrans_source_index(4, 6)                    # every cell position is hit exactly once
+    assert len(set(zip(rows.ravel().tolist(), cols.ravel().tolist()))) == 9 * 4 * 6 == 12 * 18
     rows = O.sensor_row_index(4, 5)
     assert rows[0].tolist() == [0, 2, 4, 6, 8] and rows[1].tolist() == rows[0].tolist()
     assert rows[2].tolist() == [1, 3, 5, 7, 9] and rows[3].tolist() == rows[2].tolist()
