@@ -66,6 +66,50 @@ def timed_events(fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
+def unet_roofline(model, B, Hh, Ww, precision, dev, traffic):
+    """Roofline of the U-Net launches of one step, timed live with HIP events on the launch stream: eld_unet_forward + eld_unet_backward
+    over the model's current input.  achieved = SURVEY.md 8(d)'s 276,300 FLOP per raw pixel x the pixels of one pass / that time."""
+    import eld_amd
+    net, x = model.netG, model.input
+    dout = torch.ones(B, 4, Hh, Ww, device=dev) / (B * 4.0 * Hh * Ww)
+    state = {}
+
+    def fwd():
+        state['k'] = net._engine_forward(x, save=True, bf16=precision == 'bf16')[1]
+
+    def bwd():
+        net._engine_backward(dout, state['k'], tuple(x.shape), grads=model.optimizer_G.grads)
+    fwd(); bwd(); torch.cuda.synchronize()
+    t_f = timed_events(fwd, 3)
+    t_b = timed_events(bwd, 3)
+    full_frame = (Hh, Ww) == (H_FULL, W_FULL)
+    flop_step = FLOP_STEP_PER_PIX * B * 4.0 * Hh * Ww
+    ach = flop_step / ((t_f + t_b) * 1e-3) / 1e12
+    # fp32 step: with eld_conv_fp32_algo = 1 every fp32 product is six bf16 MFMA products (csrc/conv_x3.hip), so the pipe
+    # that bounds the kernels is the bf16 MFMA and its fp32-equivalent peak is 2500 / 6; algo 0 runs on the fp32 MFMA.
+    x3 = precision == 'fp32' and eld_amd.load_library().eld_conv_fp32_algo(-1) == 1
+    peak = PEAK_BF16_MFMA_TF if precision == 'bf16' else (PEAK_BF16_MFMA_TF / 6.0 if x3 else PEAK_F32_MFMA_TF)
+    key = 'unet_conv_bytes_per_pass' if precision == 'fp32' else 'unet_conv_bytes_per_pass_bf16'
+    tr = None
+    if traffic and full_frame and key in traffic:
+        tr = round(traffic[key] * B / traffic.get('frames_per_pass', 1))
+    if precision == 'bf16':
+        kern = 'conv_bfd_kernel / conv_igemm_kernel<bf16> fwd + bwd-data, wgrad8_kernel<bf16>: bf16 operands, v_mfma_f32_32x32x16_bf16, fp32 accumulate'
+        note = 'bf16 dense MFMA peak 2500 TFLOP/s (MI355X_MICROARCH.md)'
+    elif x3:
+        kern = 'conv_x3d_kernel / conv_x3_kernel fwd + bwd-data, wgrad8_kernel: fp32 operands as 3 bf16 pieces, 6 x v_mfma_f32_32x32x16_bf16 per k-block'
+        note = ('bf16 dense MFMA peak 2500 TFLOP/s / 6 piece products per fp32 product: the work runs on the bf16 pipe; against the native fp32 MFMA peak '
+                '(157.3 TFLOP/s) the same figure is %.2fx' % (ach / PEAK_F32_MFMA_TF))
+    else:
+        kern, note = 'conv_igemm_kernel fwd/bwd-data + wgrad_kernel', 'dense fp32 MFMA peak'
+    return {'bound': 'mfma', 'kernel': 'U-Net convolution launches of one step (%s), timed as eld_unet_forward + eld_unet_backward' % kern,
+            'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'peak_note': note,
+            'traffic': tr, 'traffic_source': ('profiles/traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, scaled to the '
+                                              'frames of this run; not re-measured in this run)' if tr is not None else None),
+            'fwd_ms': round(t_f, 3), 'bwd_ms': round(t_b, 3),
+            'fwd_tflops': round(FLOP_FWD_PER_PIX * B * 4.0 * Hh * Ww / (t_f * 1e-3) / 1e12, 2)}, peak, x3
+
+
 def _cpu_sampler_worker(args):
     """One forked DataLoader-style worker: the NumPy sampler port on one image (its own NumPy stream, like worker_init_fn)."""
     y, model, seed = args
@@ -112,16 +156,22 @@ def cpu_baseline(h, w, seed=2018):
         opt.step()
         loss.item()                      # the reference reads loss.item() every iteration (ELD_model.py:480)
         return time.time() - t0
-    cpu_step(torch.from_numpy(y[None, :, :min(512, h), :min(512, w)].copy()))      # warm-up (thread pool, oneDNN primitives)
-    t_unet = cpu_step(torch.from_numpy(y[None].copy()))
+    x512 = torch.from_numpy(y[None, :, :min(512, h), :min(512, w)].copy())
+    cpu_step(x512)                                           # warm-up (thread pool, oneDNN primitives)
+    t_512 = min(cpu_step(x512) for _ in range(2))            # the reference's own training shape (BASELINE.md sec. 2 quotes this one)
+    xf = torch.from_numpy(y[None].copy())
+    t_unet = min(cpu_step(xf) for _ in range(2))             # full frame, min of 2
     npx = 4.0 * h * w
+    npx512 = 4.0 * min(512, h) * min(512, w)
     per_pix = t_full / npx + t_unet / npx
     return {'value': round(1e-6 / per_pix, 4), 'unit': 'raw MPix/s', 'cores': cores, 'kind': 'port',
             'sample': 'one 4x%dx%d frame: NumPy sampler port PGRU %.2f s (1 thread, min of 2), Pg %.2f s (1 thread), 8 forked workers x 1 Pg image '
-                      '%.2f s wall; torch-CPU fp32 U-Net train step (fwd, L1, bwd, Adam, loss.item()) on the full frame %.2f s (%d threads, after a '
-                      '512x512 warm-up step); value = PGRU sampler + U-Net step per pixel' % (h, w, t_full, t_pg, t_pool, t_unet, cores),
+                      '%.2f s wall; torch-CPU fp32 U-Net train step (fwd, L1, bwd, Adam, loss.item()) on the full frame %.2f s (%d threads, min of 2, after '
+                      '512x512 warm-up steps) and on one 4x512x512 crop %.3f s (min of 2); value = PGRU sampler + full-frame U-Net step per pixel' % (
+                          h, w, t_full, t_pg, t_pool, t_unet, cores, t_512),
             'sampler_mpix_s': round(npx / t_full / 1e6, 3), 'sampler_Pg_mpix_s': round(npx / t_pg / 1e6, 3),
             'sampler_Pg_8workers_mpix_s': round(workers * npx / t_pool / 1e6, 3), 'unet_step_mpix_s': round(npx / t_unet / 1e6, 4),
+            'unet_step_512_mpix_s': round(npx512 / t_512 / 1e6, 4), 'unet_step_512_s': round(t_512, 3),
             'os_cpu_count': os.cpu_count()}
 
 
@@ -232,35 +282,8 @@ def main():
         res['allreduce'] = exchange
     if rank == 0:
         # ---- roofline of the dominant kernels, measured live with HIP events on the launch stream ----------------------
-        net = model.netG
-        x = model.input
-        dout = torch.ones(B, 4, Hh, Ww, device=dev) / (B * 4.0 * Hh * Ww)
-        state = {}
-
-        def fwd():
-            state['k'] = net._engine_forward(x, save=True, bf16=args.precision == 'bf16')[1]
-
-        def bwd():
-            net._engine_backward(dout, state['k'], tuple(x.shape), grads=model.optimizer_G.grads)
-        fwd(); bwd(); torch.cuda.synchronize()
-        t_f = timed_events(fwd, 3)
-        t_b = timed_events(bwd, 3)
         traffic = load_traffic()
-        full_frame = (Hh, Ww) == (H_FULL, W_FULL)
-        flop_step = FLOP_STEP_PER_PIX * B * 4.0 * Hh * Ww
-        ach = flop_step / ((t_f + t_b) * 1e-3) / 1e12
-        # fp32 step: with eld_conv_fp32_algo = 1 every fp32 product is six bf16 MFMA products (csrc/conv_x3.hip), so the pipe
-        # that bounds the kernels is the bf16 MFMA and its fp32-equivalent peak is 2500 / 6; algo 0 runs on the fp32 MFMA.
-        x3 = args.precision == 'fp32' and eld_amd.load_library().eld_conv_fp32_algo(-1) == 1
-        peak = 2500.0 if args.precision == 'bf16' else (PEAK_BF16_MFMA_TF / 6.0 if x3 else PEAK_F32_MFMA_TF)
-        res['roofline'] = {'bound': 'mfma', 'kernel': 'U-Net convolution launches of one step (%s), timed as eld_unet_forward + eld_unet_backward' % (
-                               'conv_x3d_kernel / conv_x3_kernel fwd + bwd-data, wgrad8_kernel: fp32 operands as 3 bf16 pieces, 6 x v_mfma_f32_32x32x16_bf16 per k-block'
-                               if x3 else 'conv_igemm_kernel fwd/bwd-data + wgrad_kernel'),
-                           'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                           'peak_note': ('bf16 dense MFMA peak 2500 TFLOP/s / 6 piece products per fp32 product' if x3 else 'dense MFMA peak of the dtype'),
-                           'traffic': (round(traffic['unet_conv_bytes_per_pass'] * B / traffic.get('frames_per_pass', 1)) if traffic and full_frame and args.precision == 'fp32' and 'unet_conv_bytes_per_pass' in traffic else None),
-                           'fwd_ms': round(t_f, 3), 'bwd_ms': round(t_b, 3),
-                           'fwd_tflops': round(FLOP_FWD_PER_PIX * B * 4.0 * Hh * Ww / (t_f * 1e-3) / 1e12, 2)}
+        res['roofline'], peak, x3 = unet_roofline(model, B, Hh, Ww, args.precision, dev, traffic)
         # one launch of the dominant kernel, timed live: conv7_1's forward (256 -> 128 channels at 1/4 resolution, the step's
         # median 3x3 layer) through the single-layer entry point -- conv_x3d_kernel<128,2,8> (or conv_igemm_kernel<float,0,64,2>)
         if args.precision == 'fp32' and Hh % 4 == 0 and Ww % 4 == 0:
@@ -300,6 +323,48 @@ def main():
                                                       'same parity tests and tolerances as the default; not the headline because a product is good to 2^-22, not 2^-24'}
             finally:
                 lib2.eld_conv_fp32_algo(1)
+        # the sampler's duration INSIDE the step (right behind the previous step's Adam: clocks and caches as the step leaves them), beside
+        # the standalone launch timed below
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t_in = []
+        for i in range(3):
+            ids = [((total_steps + 8 + i) * world * B) + rank + world * k for k in range(B)]
+            e0.record()
+            model.set_input({'target': clean, 'params': plists[i % len(plists)], 'sample_ids': ids}, 'train')
+            e1.record()
+            model.optimize_parameters()
+            torch.cuda.synchronize()
+            t_in.append(e0.elapsed_time(e1))
+        sampler_in_step_ms = min(t_in)
+        # BASELINE.json configs[2] (bf16 U-Net with MFMA convs, batch 8) beside the headline: the same step with the bf16 engine, its own
+        # roofline against the 2.5 PF/s bf16 peak.  `value` above stays on configs[1] (fp32).
+        if args.precision == 'fp32' and world == 1 and not args.no_alt:
+            model_b = ELDModel()
+            model_b.initialize(make_opt(local, 'bf16'))
+            model_b.set_noise_model(nm)
+
+            def step_b(i):
+                ids = [(i * world * B) + rank + world * k for k in range(B)]
+                model_b.set_input({'target': clean, 'params': plists[i % len(plists)], 'sample_ids': ids}, 'train')
+                model_b.optimize_parameters()
+                return model_b.get_current_errors()['Pixel']
+            for i in range(2):
+                step_b(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            nb16 = 5
+            for i in range(nb16):
+                loss_b = step_b(2 + i)
+            torch.cuda.synchronize()
+            dtb = (time.perf_counter() - t0) / nb16
+            rb, _, _ = unet_roofline(model_b, B, Hh, Ww, 'bf16', dev, traffic)
+            res['alt_bf16'] = {'value': round(pix_per_step / dtb / 1e6, 3), 'unit': 'raw MPix/s', 'ms_per_step': round(dtb * 1e3, 3), 'steps': nb16, 'warmup': 2,
+                               'dtype': 'bf16', 'final_loss': loss_b, 'roofline': rb,
+                               'config': {'workload': 'BASELINE.json configs[2]: the same noise model and frames, bf16 U-Net train step (bf16 activations / '
+                                                      'gradients / packed weights on v_mfma_f32_32x32x16_bf16, fp32 accumulation, master weights, '
+                                                      'parameter gradients and Adam), %d frames per GPU' % B}}
+            del model_b
+            torch.cuda.empty_cache()
         # sampler alone (HBM-bound: 8 B per raw pixel), batch of 8 resident images
         nb = 8
         yb = synth_clean(nb, Hh, Ww, dev, seed=99)
@@ -315,7 +380,12 @@ def main():
         res['roofline_sampler'] = {'bound': 'hbm', 'kernel': 'noise_kernel (%s+clip), %d images per launch, K=2.288 ratio=208.98' % (args.noise, nb),
                                    'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
                                    'traffic': (round(traffic['sampler_bytes_per_pixel'] * yb.numel()) if traffic and 'sampler_bytes_per_pixel' in traffic else None),
-                                   'algorithmic_bytes': 8 * yb.numel(), 'ms_per_launch': round(t_s, 4), 'mpix_s': round(yb.numel() / (t_s * 1e-3) / 1e6, 1)}
+                                   'traffic_source': 'profiles/traffic.json (committed PMC pass; not re-measured in this run)',
+                                   'algorithmic_bytes': 8 * yb.numel(), 'ms_per_launch': round(t_s, 4), 'mpix_s': round(yb.numel() / (t_s * 1e-3) / 1e6, 1),
+                                   'in_step_ms': round(sampler_in_step_ms, 4),
+                                   'in_step_note': 'the same kernel on the step\'s own %d frames, HIP events around the synthesis call inside a full step '
+                                                   '(clock and caches as the preceding Adam / MFMA kernels leave them); in-step frac %.4f' % (
+                                                       B, 8.0 * B * 4 * Hh * Ww / (sampler_in_step_ms * 1e-3) / 1e9 / PEAK_HBM_GBS)}
         # the other model strings of the reference (noise.py:158-166: 'Pg', 'pg', 'g'), same launch shape: achieved GB/s and fraction per model
         per_model = {}
         for ms_ in ('Pg', 'pg', 'g'):

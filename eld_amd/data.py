@@ -19,6 +19,7 @@ Samples whose input dataset is an ordinary array dataset (offline-noise LMDBs, t
 path below unchanged (index maps and a clip -- the same arithmetic as sid_dataset.py:344-356).
 """
 import pickle
+import weakref
 from os.path import join
 
 import numpy as np
@@ -85,9 +86,14 @@ class SynDataset(tdata.Dataset):
         self.noise_maker = noise_maker
         self.cfa = cfa
         self.num_burst = num_burst
-        SynDataset.last_instance = self
+        SynDataset._last = weakref.ref(self)
 
-    last_instance = None                                     # picked up by ELDModel.initialize: a burst input has num_burst * channels planes
+    _last = None      # weak reference to the instance the entry script built (alive as long as its DataLoader is): ELDModel.initialize reads
+                      # num_burst off it -- a burst input has num_burst * channels planes
+
+    @classmethod
+    def last(cls):
+        return cls._last() if cls._last is not None else None
 
     def __getitem__(self, i):
         i = i % self.size if self.size is not None else i % len(self.dataset)
@@ -111,10 +117,14 @@ class ISPDataset(tdata.Dataset):
         self.noise_maker = noise_maker
         self.cfa = cfa
         self.meta_info = dataset.meta if meta_info is None else meta_info
-        self.CRF = CRF                                       # (E, fs) of process.load_CRF or None; the device ISP reads it off last_instance
-        ISPDataset.last_instance = self
+        self.CRF = CRF                                       # (E, fs) of process.load_CRF or None; the device ISP reads it off ISPDataset.last()
+        ISPDataset._last = weakref.ref(self)
 
-    last_instance = None                                     # the instance the entry script built (train_syn.py:55-58), picked up by ELDModel
+    _last = None      # weak reference to the instance the entry script built (train_syn.py:55-58), picked up by ELDModel for its CRF tables
+
+    @classmethod
+    def last(cls):
+        return cls._last() if cls._last is not None else None
 
     def __getitem__(self, i):
         data = self.dataset[i]

@@ -111,8 +111,8 @@ class ELDModel:
         # ISPDataset(CRF=...) (train_syn.py:42-58); None = gamma 2.2.  --crf without tables anywhere is an error, not a silent gamma.
         from .data import ISPDataset
         self.CRF = getattr(opt, 'crf_tables', None)
-        if self.CRF is None and ISPDataset.last_instance is not None:
-            self.CRF = ISPDataset.last_instance.CRF
+        if self.CRF is None and ISPDataset.last() is not None:
+            self.CRF = ISPDataset.last().CRF
         if self.CRF is None and getattr(opt, 'crf', False) and self.stage_in == 'srgb':
             raise RuntimeError('--crf: no CRF tables reached the model (opt.crf_tables / ISPDataset(CRF=...)); refusing to render the input with gamma 2.2 '
                                'against a CRF-rendered target')
@@ -371,7 +371,7 @@ class ELDModel:
 def _plugin_num_burst():
     """num_burst of the SynDataset the entry script (or eld_amd.launch --num-burst) built, 1 if none."""
     from .data import SynDataset
-    inst = SynDataset.last_instance
+    inst = SynDataset.last()
     return max(1, int(getattr(inst, 'num_burst', 1) or 1)) if inst is not None else 1
 
 

@@ -169,15 +169,19 @@ def test_plugins_leave_burst_and_crf_for_the_model():
     from eld_amd import data as D
     from eld_amd.model import _plugin_num_burst
     nm = quiet_model('Pg')
-    D.SynDataset(ArrayDB(), noise_maker=nm, num_burst=3)
+    keep = D.SynDataset(ArrayDB(), noise_maker=nm, num_burst=3)
     assert _plugin_num_burst() == 3
-    D.SynDataset(ArrayDB(), noise_maker=nm)
+    del keep                                       # weak reference: a dataset that no longer exists says nothing about the next model
+    assert _plugin_num_burst() == 1
+    keep = D.SynDataset(ArrayDB(), noise_maker=nm)
     assert _plugin_num_burst() == 1
     tables = (np.linspace(0, 1, 8), np.linspace(0, 1, 8) ** 0.5)
     db = ArrayDB()
     db.meta = [(np.ones(4), np.eye(3))] * 6
-    D.ISPDataset(db, noise_maker=nm, CRF=tables)
-    assert D.ISPDataset.last_instance.CRF is tables
+    isp = D.ISPDataset(db, noise_maker=nm, CRF=tables)
+    assert D.ISPDataset.last() is isp and D.ISPDataset.last().CRF is tables
+    del isp
+    assert D.ISPDataset.last() is None
 
 
 def test_calibrated_K_option():

@@ -326,6 +326,6 @@ def test_noise_applies_to_syn_datasets_own_patch_and_crf_reaches_the_isp(eld_lib
     gamma = I.process(noisy, batch['wb'].numpy(), batch['ccm'].numpy())
     got = m.input.cpu().numpy()
     assert float(np.mean(got != want)) < 1e-4 and float(np.mean(want != gamma)) > 0.5      # the CRF render, not gamma 2.2 (isolated quantiser flips: oracle/isp_ref.py)
-    datasets.ISPDataset.last_instance = None
+    del isp_ds, ds, batch                                                 # the tables die with the dataset (weak reference)
     with pytest.raises(RuntimeError, match='crf'):
         Engine(make_opt(tmp_path, stage_in='srgb', stage_out='srgb', crf=True))

@@ -12,10 +12,12 @@ Tolerance (north_star: fp32 within 1e-5).  The pinned oracle is torch-CPU float3
 3 million products in different orders each sit some distance from the exact value, so for gradients (sums over every
 pixel of the frame) the bound is DERIVED, not asserted: the same oracle function is also evaluated in float64, and a tensor
 passes if    |ours - cpu32| <= 1e-5 * (1 + max|ref|)                                    (the plain north_star bound)
-       or    |ours - f64|   <= 1e-5 * (1 + max|ref|)  or  <= 2 x |cpu32 - f64|         (at least as close to the exact
-                                                                                        value as the reference's own fp32 path).
-Every measured number lands in gpurun_out/r02_parity_<case>.json; tools/parity_report.py turns those into
-profiles/r02_parity.md.
+       or    |ours - f64|   <= 1e-5 * (1 + max|ref|)                                    (the same bound against the exact value: the
+                                                                                        float32 ORACLE is what is off on those rows).
+Round 3 adds the bench's own shape (8 x 4 x 1424 x 2128: batch gradients == mean of the eight single-frame gradients, each of which
+is oracle-pinned by the full-frame case) and BASELINE configs[2] (bf16 engine against the float64 oracle at frame size).
+Every measured number lands in gpurun_out/r03_parity_<case>.json; tools/parity_report.py turns those into
+profiles/r03_parity.md.
 """
 import json
 import os
@@ -100,7 +102,7 @@ def compare(tag, lib, shape, algo, want_f64=True):
             e64 = float((got.double() - ref64).abs().max())
             c64 = float((ref32.double() - ref64).abs().max())
             row.update(err_vs_f64=e64, cpu32_vs_f64=c64)
-            ok = ok or e64 <= bound or e64 <= 2.0 * c64
+            ok = ok or e64 <= bound
         row['ok'] = bool(ok)
         rec['tensors'].append(row)
         if not ok:
@@ -114,7 +116,7 @@ def compare(tag, lib, shape, algo, want_f64=True):
         check('grad ' + name, grads[a:b].view_as(ref), ref, r64[2][name] if r64 else None)
     try:
         os.makedirs(OUT, exist_ok=True)
-        with open(os.path.join(OUT, 'r02_parity_%s.json' % tag), 'w') as f:
+        with open(os.path.join(OUT, 'r03_parity_%s.json' % tag), 'w') as f:
             json.dump(rec, f, indent=1)
     except OSError:
         pass
@@ -152,3 +154,119 @@ def test_full_frame_batch_is_image_independent(lib):
         one0 = net(x[:1].contiguous())
         one1 = net(x[1:].contiguous())
     assert torch.equal(both[0], one0[0]) and torch.equal(both[1], one1[0])
+
+
+def _dump(tag, rec):
+    try:
+        os.makedirs(OUT, exist_ok=True)
+        with open(os.path.join(OUT, 'r03_parity_%s.json' % tag), 'w') as f:
+            json.dump(rec, f, indent=1)
+    except OSError:
+        pass
+
+
+def test_bench_shape_batch8_gradients_are_the_mean_of_single_frames(lib):
+    """bench.py's own configuration: 8 x 4 x 1424 x 2128 in one launch chain (default fp32 scheme).  The loss is the mean over the
+    global batch (ELD_model.py:415-416), so the batch gradient must equal the MEAN of the eight single-frame gradient buffers --
+    each single frame is the oracle-pinned case above -- to 1e-5 * (1 + max|ref|) per tensor, and the outputs must be the single-frame
+    outputs bit for bit.  Covers what only the 8-frame backward exercises: weight-gradient partial counts (psplit), tile -> image
+    decoding in wgrad8_kernel, per-image buffer resources, the 8-frame pool/skip buffers."""
+    from eld_amd.unet import UNetSeeInDark, param_offsets
+    torch.manual_seed(2018)
+    net = UNetSeeInDark(4, 4).cuda()
+    N, H, W = 8, 1424, 2128
+    g = torch.Generator(device='cuda').manual_seed(23)
+    x = torch.floor(65535.0 * torch.rand(N, 4, H, W, device='cuda', generator=g) ** 2.2) / 65535.0
+    t = torch.rand(N, 4, H, W, device='cuda', generator=g)
+    out8, loss8, g8 = engine_step(net, lib, x, t)
+    g8 = g8.double().cpu()
+    out8 = out8.cpu()
+    acc = torch.zeros_like(g8)
+    losses = []
+    for i in range(N):
+        o1, l1, g1 = engine_step(net, lib, x[i:i + 1].contiguous(), t[i:i + 1].contiguous())
+        assert torch.equal(o1.cpu()[0], out8[i]), 'frame %d: batched output differs from the single-frame output' % i
+        acc += g1.double().cpu()
+        losses.append(l1)
+    mean = acc / N
+    offs = param_offsets(4, 4)
+    names = [n for n, _ in net.named_parameters()]
+    rec = {'case': 'bench_batch8', 'shape': [N, 4, H, W], 'algo': int(lib.eld_conv_fp32_algo(-1)), 'loss8': loss8, 'mean_single_loss': sum(losses) / N, 'tensors': []}
+    fails = []
+    for name, a, b in zip(names, offs[:-1], offs[1:]):
+        ref, got = mean[a:b], g8[a:b]
+        rmax = float(ref.abs().max())
+        err = float((got - ref).abs().max())
+        row = {'name': 'grad ' + name, 'ref_max': rmax, 'err_vs_mean_of_single_frames': err, 'bound_1e5': 1e-5 * (1 + rmax), 'ok': err <= 1e-5 * (1 + rmax)}
+        rec['tensors'].append(row)
+        if not row['ok']:
+            fails.append(row)
+    _dump('bench_batch8', rec)
+    assert abs(loss8 - sum(losses) / N) <= 1e-6 * (1 + abs(loss8)), (loss8, losses)
+    assert not fails, fails
+
+
+def test_bf16_full_frame_step_vs_f64_oracle(lib):
+    """BASELINE configs[2] at frame size: the bf16 engine (conv_bfd_kernel, wgrad8_kernel<bf16>, bf16 transposed convs, fused pools)
+    against the FLOAT64 oracle -- not against the fp32 engine.  bf16 activations carry 8 significant bits, so the bound is not 1e-5:
+    output PSNR >= 60 dB, loss within 1e-3 relative, and per gradient tensor cosine >= 0.995 with relative L2
+    error <= 0.10; the measured per-tensor figures go to the parity table."""
+    from eld_amd import _lib as L
+    from eld_amd.unet import UNetSeeInDark, param_offsets
+    torch.manual_seed(2018)
+    net = UNetSeeInDark(4, 4)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    shape = (1, 4, 1424, 2128)
+    g = torch.Generator().manual_seed(11)
+    x = torch.floor(65535.0 * torch.rand(*shape, generator=g) ** 2.2) / 65535.0
+    t = torch.rand(*shape, generator=g)
+    net = net.cuda()
+    xc, tc = x.cuda(), t.cuda()
+    out, key, _ = net._engine_forward(xc, save=True, bf16=True)
+    dout = torch.empty_like(out)
+    loss = torch.zeros(1, device='cuda')
+    ws = torch.empty(lib.eld_l1_workspace_bytes(), dtype=torch.uint8, device='cuda')
+    L.check(lib.eld_l1_loss(L.dptr(out), L.dptr(tc), L.dptr(dout), L.dptr(loss), L.dptr(ws), out.numel(), 1.0, L.cur_stream()), 'eld_l1_loss')
+    grads = net._engine_backward(dout, key, tuple(xc.shape))
+    torch.cuda.synchronize()
+    out, grads, loss = out.double().cpu(), grads.double().cpu(), float(loss.item())
+    del net
+    torch.cuda.empty_cache()
+    r64 = oracle_f64(sd, x, t)
+    assert r64 is not None, 'float64 oracle unavailable'
+    o64, l64, g64 = r64
+    mse = float(torch.mean((out * 255 - o64 * 255) ** 2))
+    psnr = 10 * float(torch.log10(torch.tensor(255.0 ** 2 / mse)))
+    rec = {'case': 'bf16_frame1424x2128', 'shape': list(shape), 'loss': loss, 'loss_f64': l64, 'output_psnr_db': psnr, 'tensors': []}
+    offs = param_offsets(4, 4)
+    fails = []
+    for (name, ref), a, b in zip(g64.items(), offs[:-1], offs[1:]):
+        r, q = ref.reshape(-1).double(), grads[a:b]
+        cos = float(torch.dot(r, q) / (r.norm() * q.norm() + 1e-300))
+        rel = float((q - r).norm() / (r.norm() + 1e-300))
+        row = {'name': 'grad ' + name, 'ref_max': float(r.abs().max()), 'cosine': cos, 'rel_l2': rel, 'max_abs_err': float((q - r).abs().max()),
+               'ok': cos >= 0.995 and rel <= 0.10}
+        rec['tensors'].append(row)
+        if not row['ok']:
+            fails.append(row)
+    _dump('bf16_frame1424x2128', rec)
+    assert psnr >= 60.0, psnr
+    assert abs(loss - l64) <= 1e-3 * abs(l64), (loss, l64)
+    assert not fails, fails
+
+
+def test_sampler_batch8_equals_single_image_launches(lib):
+    """The sampler at the bench's launch shape: 8 full frames in one launch == eight single-image launches with the same global
+    sample ids, bit for bit (E-3: geometry / batching independence), full model PGRU + clip, per-image parameters."""
+    from eld_amd import _lib as L
+    from eld_amd.noise import NoiseParams, model_flags, sample_noise
+    N, H, W = 8, 1424, 2128
+    g = torch.Generator(device='cuda').manual_seed(31)
+    y = torch.floor(65535.0 * torch.rand(N, 4, H, W, device='cuda', generator=g) ** 2.2) / 65535.0
+    ps = [NoiseParams(0.5 + 0.7 * i, 2.0 + i, 15583, 100.0 + 25 * i, tl_lambda=-0.14285714 + 0.04 * i, tl_scale=1.0 + 0.5 * i, row_scale=0.2 * (i + 1)) for i in range(N)]
+    fl = model_flags('PGRU') | L.CLIP
+    ids = [1000 + 3 * i for i in range(N)]
+    z = sample_noise(y, ps, fl, 2018, ids)
+    for i in range(N):
+        zi = sample_noise(y[i:i + 1].contiguous(), [ps[i]], fl, 2018, [ids[i]])
+        assert torch.equal(zi[0], z[i]), i

@@ -15,7 +15,7 @@ E=$(date +%s.%N)
 # the progress bar rewrites its line with \r: keep the last state of every line
 tr '\r' '\n' < $O.raw | grep -v '^\s*$' | awk 'length($0) < 400' > $O.lines
 ( echo "# python -m eld_amd.launch --ref <staged reference> --plugins noise,arch,model,data --stop-after-epochs $EP --max-iters-per-epoch $IT -- --name t --include 4 --noise PGRU --no-log"
-  echo "# exit code $RC, wall $(echo "$E - $S" | bc) s (includes python start-up, library load, first-touch)"
+  echo "# exit code $RC, wall $(python -c "print(round($E - $S, 1))") s (includes python start-up, library load, first-touch)"
   grep -n "eld_amd\|\[i\]\|Epoch\|epoch\|Time\|learning rate\|Traceback\|Error" $O.lines | head -60
   echo "# --- last lines"; tail -12 $O.lines ) > $O.log
 python - $O.raw <<'PY' >> $O.log
