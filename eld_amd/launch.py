@@ -36,7 +36,9 @@ import types
 import numpy as np
 
 
-def install_shims(synthetic_lmdb=True, patches=16, patch_hw=(512, 512)):
+def install_shims(synthetic_lmdb=True, patches=16, patch_hw=(512, 512), entries=None):
+    """entries: what the in-memory LMDB stand-in reports as its record count (default: `patches`); record i is patch i % patches, so an
+    epoch can have the reference's length (1288 samples, train_syn.py:40) over a handful of synthetic patches."""
     def mod(name, **attrs):
         m = types.ModuleType(name)
         m.__dict__.update(attrs)
@@ -80,7 +82,7 @@ def install_shims(synthetic_lmdb=True, patches=16, patch_hw=(512, 512)):
                     return False
 
                 def stat(self):
-                    return {'entries': len(recs)}
+                    return {'entries': int(entries) if entries else len(recs)}
 
                 def get(self, key):
                     return recs[int(key.decode('ascii')) % len(recs)]
@@ -157,6 +159,7 @@ def main(argv=None):
     ap.add_argument('--online-noise', dest='online_noise', action='store_true', default=None, help='data plugin: synthesise the input on the fly even if an offline-noise LMDB exists')
     ap.add_argument('--offline-noise', dest='online_noise', action='store_false', help='data plugin: read the offline-noise LMDB (train_syn.py as shipped)')
     ap.add_argument('--num-burst', type=int, default=1, help='data plugin: burst frames per sample (sid_dataset.py:267-273)')
+    ap.add_argument('--lmdb-entries', type=int, default=0, help='synthetic LMDB stand-in: reported record count (0 = the 16 synthetic patches); 1288 = an epoch of the reference\'s length')
     ap.add_argument('--script', default='train_syn.py')
     ap.add_argument('--cwd', default=None, help='scratch working directory (default: $TMPDIR/eld_amd_run)')
     ap.add_argument('--stop-after-epochs', type=int, default=0, help='harness: leave the script cleanly after this many Engine.train calls (train_syn.py:100 loops to epoch 200)')
@@ -168,7 +171,7 @@ def main(argv=None):
     prepare_cwd(ref, cwd)
     os.chdir(cwd)
     sys.path.insert(0, ref)
-    install_shims()
+    install_shims(entries=args.lmdb_entries or None)
     which = [] if args.plugins == 'none' else [p.strip() for p in args.plugins.split(',') if p.strip()]
     install_plugins(which, online_noise=args.online_noise, num_burst=args.num_burst)
     if args.stop_after_epochs > 0 or args.max_iters_per_epoch > 0:
