@@ -325,16 +325,15 @@ def main():
                 lib2.eld_conv_fp32_algo(1)
         # the sampler's duration INSIDE the step (right behind the previous step's Adam: clocks and caches as the step leaves them), beside
         # the standalone launch timed below
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t_in = []
-        for i in range(3):
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(4)]
+        for i, (e0, e1) in enumerate(evs):          # no host sync inside: the host runs ahead, so e0 -> e1 spans only the queued synthesis work
             ids = [((total_steps + 8 + i) * world * B) + rank + world * k for k in range(B)]
             e0.record()
             model.set_input({'target': clean, 'params': plists[i % len(plists)], 'sample_ids': ids}, 'train')
             e1.record()
             model.optimize_parameters()
-            torch.cuda.synchronize()
-            t_in.append(e0.elapsed_time(e1))
+        torch.cuda.synchronize()
+        t_in = [e0.elapsed_time(e1) for e0, e1 in evs[1:]]
         sampler_in_step_ms = min(t_in)
         # BASELINE.json configs[2] (bf16 U-Net with MFMA convs, batch 8) beside the headline: the same step with the bf16 engine, its own
         # roofline against the 2.5 PF/s bf16 peak.  `value` above stays on configs[1] (fp32).

@@ -86,6 +86,18 @@ __device__ __forceinline__ float4 unpack_bf4(uint2 p) {
     return make_float4(__uint_as_float(p.x << 16), __uint_as_float(p.x & 0xFFFF0000u), __uint_as_float(p.y << 16), __uint_as_float(p.y & 0xFFFF0000u));
 }
 
+// Widened bf16 epilogue store (cdna_hip_programming.md T21).  After a 32x32 MFMA run as D[channel][pixel], lane (m, hi) holds, for each
+// 8-channel group q of a 32-channel block, channels 8q + 4hi .. +3 of pixel m: packed, that is 8 bytes per lane and group -- a row-per-lane
+// dwordx2 store, which is store-ISSUE bound (~7 B/clk/CU).  One v_permlane32_swap per dword exchanges the halves of a group PAIR (2j, 2j+1):
+// afterwards lanes hi = 0 hold all 8 channels of group 2j and lanes hi = 1 all 8 of group 2j+1 -> one 16-byte store per lane and pair, at
+// channel offset 8 * (2j + hi) of the block.  a = this lane's packed group 2j, b = its packed group 2j+1.  Both lanes of a pair (m, m+32) must
+// be active (they are the same pixel: bounds tests depend on m only).
+__device__ __forceinline__ uint4 bf16_pair_swap(uint2 a, uint2 b) {
+    const auto r0 = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+    return make_uint4(r0[0], r1[0], r0[1], r1[1]);
+}
+
 int launch_conv(const ConvArgs& a, int mode, hipStream_t st);
 // fp32 3x3 convolutions: 0 = exact-fp32 MFMA (conv_igemm.hip), 1 = three-piece bf16 split on the bf16 MFMA (conv_x3.hip).
 // set < 0 only queries.  Initial value from env ELD_FP32_CONV (mfma | x3).  Returns the value in force before the call.
@@ -105,6 +117,10 @@ int launch_conv_x3_gemm(const ConvArgs& a, int mode, hipStream_t st);
 int bfd_slab_bn(int Nout, int K, int N, int H, int W);
 __host__ __device__ inline size_t bfd_slab_bytes(int BN) { return (size_t)3 * BN * 64; }
 int launch_conv_bfd(const ConvArgs& a, hipStream_t st);      // transposed-conv directions; ELD_ENOTSUP if not covered
+// bf16 3x3 layers with exactly 32 output channels and K = 32 / 64 (conv_bfs.hip: weights resident in LDS, three-deep activation ring); they take
+// their weights in conv_bfd's slab layout at BN = 32 (bfd_slab_bn returns 32 for them)
+bool bfs_takes(int Nout, int K, int N, int H, int W);
+int launch_conv_bfs(const ConvArgs& a, hipStream_t st);
 
 // dW-type reduction:  P[tap][i][j] = sum_pixels G[pixel][i] * X[pixel (+) tap][j]
 struct WgradArgs {

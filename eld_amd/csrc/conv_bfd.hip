@@ -268,8 +268,13 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
                     }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(v[q].x), "+v"(v[q].y), "+v"(v[q].z), "+v"(v[q].w));
+                    // 16-byte stores (conv.h bf16_pair_swap): dst[q] points at this lane's 4 channels of group q; after the exchange the lane owns
+                    // the whole group 2j + hi
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(dst[q]) = pack_bf4(v[q]);
+                    for (int j = 0; j < 2; ++j) {
+                        const uint4 w = bf16_pair_swap(pack_bf4(v[2 * j]), pack_bf4(v[2 * j + 1]));
+                        *reinterpret_cast<uint4*>(dst[2 * j] + 4 * hi) = w;      // = start of group 2j + hi (dst[q] = block base + 8 q + 4 hi)
+                    }
                 }
             }
             // fused nn.MaxPool2d(2) (Unet.py:51-63): vertical pair in the lane's own rows, horizontal pair in lane ^ 1; pooled from the
@@ -299,10 +304,12 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
                             }
                             pk[q] = pack_bf4(make_float4(u[0], u[1], u[2], u[3]));
                         }
+                        // (every lane takes part in the exchange; even pixels store)
+                        const uint4 w0 = bf16_pair_swap(pk[0], pk[1]), w1 = bf16_pair_swap(pk[2], pk[3]);
                         if (!(x & 1)) {
-                            bf16_t* dp = static_cast<bf16_t*>(a.pool_out) + ((size_t)(img * Hp + (y >> 1)) * Wp + (x >> 1)) * a.Nout + nbase;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(dp + 8 * q) = pk[q];
+                            bf16_t* dp = static_cast<bf16_t*>(a.pool_out) + ((size_t)(img * Hp + (y >> 1)) * Wp + (x >> 1)) * a.Nout + nb * BN + tt * 32 + 8 * hi;
+                            *reinterpret_cast<uint4*>(dp) = w0;
+                            *reinterpret_cast<uint4*>(dp + 16) = w1;
                         }
                     }
                 }
@@ -341,6 +348,7 @@ int launch_bfd(ConvArgs a, hipStream_t st) {
 // launches that stay on conv_igemm_kernel<bf16_t> (32-channel layers; small problems, where its 8-row tiles with two 4-wave workgroups per CU
 // spread the work over more CUs).
 int bfd_slab_bn(int Nout, int K, int N, int H, int W) {
+    if (bfs_takes(Nout, K, N, H, W)) return 32;      // conv_bfs.hip: the same slab layout at BN = 32
     if (K % 32 || Nout % 64) return 0;
     const long long px_tiles = (long long)((W + TW - 1) / TW) * ((H + 15) / 16) * N;
     const int cus = eld_num_cus();
@@ -353,6 +361,7 @@ int launch_conv_bfd(const ConvArgs& a, hipStream_t st) {
     if ((size_t)a.H * a.W * a.C0 * 2 >= 0xFFFFFFF0ull) return ELD_ENOTSUP;
     if (a.pool_out && (a.epi != EPI_FWD || (a.H & 1) || (a.W & 1))) return ELD_EINVAL;
     const int bn = bfd_slab_bn(a.Nout, a.C0 + a.C1, a.N, a.H, a.W);
+    if (bn == 32) return launch_conv_bfs(a, st);
     if (bn == 128) return launch_bfd<128, 2, 8>(a, st);
     if (bn == 64) return launch_bfd<64, 2, 8>(a, st);
     return ELD_ENOTSUP;

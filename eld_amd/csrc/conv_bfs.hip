@@ -1,0 +1,297 @@
+// conv_bfs.hip -- bf16 3x3 convolution for the 32-OUTPUT-CHANNEL layers of the U-Net (full resolution: conv1_2, conv9_1, conv9_2 forward; the
+// backward-data of conv9_2, conv1_2 and conv2_1), gfx950.  Same contract and arithmetic as conv_bfd_kernel (conv_bfd.hip): bf16 NHWC activations,
+// fp32 accumulation on v_mfma_f32_32x32x16_bf16, bias / LeakyReLU / slope / fused 2x2 max-pool epilogues -- models/arch/Unet.py:11-12,44-46,49-51,83-88
+// and their autograd backward-data.
+//
+// These launches are HBM-bound, not MFMA-bound: 32 output channels give 144 flop per activation byte (72 per byte for the 64-channel input of
+// conv9_1) against a machine balance of ~400 -- one 16 x 32 pixel tile moves 39 KB in and 32 KB out for 36 MFMAs per wave.  So the kernel is built
+// around the activation stream instead of the matrix pipe:
+//   * the WHOLE packed weight tensor of the layer (9 taps x 32 x K <= 36 KB, conv_bfd's slab layout at BN = 32, laid out by the pack kernel as the
+//     exact LDS image) is copied into LDS once per workgroup and stays there: no weight stream, and the only LDS-DMA traffic of the main loop is
+//     the activation halo tile;
+//   * halo tiles (18 x 34 pixels x one 32-channel chunk = 39 KB, conv_bfd's XOR-swizzled landing order) run through a ring of THREE buffers: the
+//     tiles of work items j+1 and j+2 are in flight while item j is being multiplied -- 78 KB of loads outstanding per CU, what it takes to cover
+//     the ~2.7 us DMA round trip at ~25 GB/s per CU.  A work item is (tile, 32-channel chunk); the ring runs across tiles, so the pipeline never
+//     drains inside a launch;
+//   * one barrier per work item (all nine taps of a chunk: 36 MFMAs per wave) instead of one per kernel row;
+//   * each wave waits for its own pieces with a counted s_waitcnt: at the top of item j at most the A_IT pieces of item j+1 may be outstanding.
+//     The count is deliberately the conservative one: it does not rely on loads and stores retiring in one common order (the epilogue's stores
+//     sit between two tiles' pieces in the queue) -- "at most A_IT operations outstanding" implies "at most A_IT loads outstanding" either way.
+#include <stdlib.h>
+#include "conv.h"
+
+#define TW 32
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ void bfs_dma16(i32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_dst) {      // as conv_bfd.hip::bfd_dma16
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_dst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void bfs_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ float hmax1s(float f) {       // max with lane ^ 1 (horizontal neighbour pixel): quad_perm [1,0,3,2]
+    return fmaxf(f, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(f), 0xB1, 0xF, 0xF, true)));
+}
+
+constexpr int BFS_NAB = 3;                               // activation ring depth
+constexpr int BFS_WCHUNK = 9 * 32 * 64;                  // packed weights of one 32-channel chunk: 18 DMA pieces
+
+template <int RPW, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void conv_bfs_kernel(const ConvArgs a) {
+    constexpr int TH = WAVES * RPW, HW2 = TW + 2, A_PIX = (TH + 2) * HW2;
+    constexpr int A_UNITS = A_PIX * 4, A_PIECES = (A_UNITS + 63) / 64, A_BYTES = A_PIECES * 1024;
+    constexpr int A_IT = (A_PIECES + WAVES - 1) / WAVES;
+    extern __shared__ __attribute__((aligned(16))) char lds[];           // [A0][A1][A2][W chunk 0][W chunk 1]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31, hi = lane >> 5;
+    const int Cin = a.C0 + a.C1, NCH = Cin >> 5, NCH0 = a.C0 >> 5;       // NCH = 1 or 2
+    const int tiles_img = a.tiles_x * a.tiles_y;
+    const int total_tiles = tiles_img * a.N;
+    const int Cs0 = a.C0;
+
+    const unsigned lds_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(__attribute__((address_space(3))) char*)lds);
+    const unsigned ldsW_addr = lds_base + BFS_NAB * A_BYTES;
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+
+    // ---- the layer's weights: 18 * NCH linear 1 KiB pieces, dealt round-robin (a duplicate piece rewrites identical bytes) -------------------
+    {
+        const unsigned long long wbase = (unsigned long long)a.wp;
+        const i32x4 rsrc_w = {(int)(unsigned)wbase, (int)((unsigned)(wbase >> 32) & 0xFFFFu), NCH * BFS_WCHUNK, 0x00020000};
+        const int wpieces = 18 * NCH;
+#pragma unroll
+        for (int it = 0; it < 5; ++it) {                                  // ceil(36 / 8) = 5; with NCH = 1 the later ones repeat earlier pieces
+            const int piece = (wave + it * WAVES) % wpieces;
+            bfs_dma16(rsrc_w, (unsigned)lane * 16u, (unsigned)(piece * 1024), ldsW_addr + (unsigned)(piece * 1024));
+        }
+    }
+
+    // ---- activation DMA: which (halo pixel, octet) lands in this lane's slot of piece wave + it*WAVES --------------------------------------
+    int a_hy[A_IT], a_hx[A_IT];
+    unsigned a_oct[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int piece = (wave + it * WAVES) % A_PIECES;
+        const int u = piece * 64 + lane;
+        const int P = u >> 2;
+        const int hr = P / HW2, hc = P - hr * HW2;
+        a_hy[it] = u < A_UNITS ? hr - 1 : -1000;
+        a_hx[it] = hc - 1;
+        a_oct[it] = (unsigned)((u & 3) ^ ((hc >> 2) & 3)) * 16u;
+    }
+    unsigned a_voff[A_IT];
+    int l_tile = -1, l_img = 0;
+    auto decode = [&](int t, int& img, int& y0, int& x0) {
+        img = t / tiles_img;
+        const int r = t - img * tiles_img;
+        const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+        y0 = ty * TH; x0 = tx * TW;
+    };
+    auto setup_load = [&](int t) {
+        int y0, x0;
+        decode(t, l_img, y0, x0);
+        l_tile = t;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int gy = y0 + a_hy[it], gx = x0 + a_hx[it];
+            const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            a_voff[it] = ok ? (unsigned)(gy * a.W + gx) * (unsigned)(Cs0 * 2) + a_oct[it] : OOB;
+        }
+    };
+    const int first = blockIdx.x, stride = gridDim.x;
+    if (first >= total_tiles) return;
+    const int my_tiles = (total_tiles - first + stride - 1) / stride;
+    const int n_items = my_tiles * NCH;
+    // item j = (tile first + (j / NCH) * stride, chunk j % NCH); its halo tile lives in ring slot j % 3
+    auto issue_A = [&](int j) {
+        const int k = NCH == 2 ? (j >> 1) : j, chunk = NCH == 2 ? (j & 1) : 0;
+        const int t = first + k * stride;
+        if (t != l_tile) setup_load(t);
+        const char* src = static_cast<const char*>(chunk < NCH0 ? a.in0 : a.in1);
+        const int cs = chunk < NCH0 ? chunk : chunk - NCH0;
+        const size_t img_bytes = (size_t)a.H * a.W * Cs0 * 2;
+        const unsigned long long ab = (unsigned long long)(src + (size_t)l_img * img_bytes);
+        const i32x4 rsrc_a = {(int)(unsigned)ab, (int)((unsigned)(ab >> 32) & 0xFFFFu), (int)img_bytes, 0x00020000};
+        const int buf = j % BFS_NAB;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int piece = (wave + it * WAVES) % A_PIECES;
+            bfs_dma16(rsrc_a, a_voff[it], (unsigned)(cs * 64), lds_base + (unsigned)(buf * A_BYTES + piece * 1024));
+        }
+    };
+
+    // ---- fragment addresses -----------------------------------------------------------------------------------------------------------------
+    unsigned fx_off[3][2], fw_off[2];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int hc = m + kx;
+            fx_off[kx][kb] = (unsigned)(hc * 64 + (((kb * 2 + hi) ^ ((hc >> 2) & 3)) * 16));
+        }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) fw_off[kb] = (unsigned)(m * 64 + (((kb * 2 + hi) ^ ((m >> 2) & 3)) * 16));
+    const char* ldsW = lds + BFS_NAB * A_BYTES;
+
+    // bias of this lane's 16 channels, loaded once (a load inside the loop's epilogue would drain the DMA queue ahead of it: vmcnt is in order)
+    float4 bs[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bs[q] = a.epi == EPI_FWD ? *reinterpret_cast<const float4*>(a.bias + 4 * hi + 8 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    issue_A(0);
+    if (n_items > 1) issue_A(1);
+
+    f32x16 acc[RPW];
+    for (int j = 0; j < n_items; ++j) {
+        const int k = NCH == 2 ? (j >> 1) : j, chunk = NCH == 2 ? (j & 1) : 0;
+        const int t = first + k * stride;
+        // this wave's pieces of item j (and, the first time, of the weights) have landed; item j+1's may still fly
+        if (j + 1 < n_items) bfs_wait_vm<A_IT>(); else bfs_wait_vm<0>();
+        __syncthreads();                         // ... and everybody else's; everybody is done reading ring slot (j - 1) % 3 = (j + 2) % 3
+        if (j + 2 < n_items) issue_A(j + 2);
+        if (chunk == 0) {
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
+        }
+        const char* la0 = lds + (j % BFS_NAB) * A_BYTES + (wave * RPW) * (HW2 * 64);
+        const char* lw0 = ldsW + (NCH == 2 ? chunk : 0) * 6144;             // slab(ky, chunk) at (ky * NCH + chunk) * 6144
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const char* la = la0 + ky * (HW2 * 64);
+            const char* lw = lw0 + ky * NCH * 6144;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    uint4 fx[RPW];
+#pragma unroll
+                    for (int r = 0; r < RPW; ++r) fx[r] = *reinterpret_cast<const uint4*>(la + r * (HW2 * 64) + fx_off[kx][kb]);
+                    const uint4 fw = *reinterpret_cast<const uint4*>(lw + kx * (32 * 64) + fw_off[kb]);
+#pragma unroll
+                    for (int r = 0; r < RPW; ++r)
+                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw), __builtin_bit_cast(bf16x8, fx[r]), acc[r], 0, 0, 0);      // D[channel][pixel]
+                }
+        }
+        if (chunk + 1 < NCH) continue;
+
+        // ---- epilogue of tile t: lane (m, hi) owns pixel x0 + m and channels 8q + 4hi .. +3 (as conv_bfd.hip) ---------------------------------
+        int img, y0, x0;
+        decode(t, img, y0, x0);
+        const int x = x0 + m;
+        const bool xok = x < a.W;
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int y = y0 + wave * RPW + r;
+            if (y >= a.H || !xok) continue;
+            const size_t pix = (size_t)(img * a.H + y) * a.W + x;
+            const int nbase = 4 * hi;
+            float4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = make_float4(acc[r][4 * q], acc[r][4 * q + 1], acc[r][4 * q + 2], acc[r][4 * q + 3]);
+            bf16_t* dst0;                                                   // this lane's 4 channels of group 0
+            if (a.epi == EPI_FWD) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[q].x += bs[q].x; v[q].y += bs[q].y; v[q].z += bs[q].z; v[q].w += bs[q].w;
+                    if (a.lrelu) {
+                        v[q].x = fmaxf(0.2f * v[q].x, v[q].x); v[q].y = fmaxf(0.2f * v[q].y, v[q].y);
+                        v[q].z = fmaxf(0.2f * v[q].z, v[q].z); v[q].w = fmaxf(0.2f * v[q].w, v[q].w);
+                    }
+                }
+                dst0 = static_cast<bf16_t*>(a.out0) + pix * 32 + nbase;
+            } else {                                                        // EPI_GRAD: all 32 channels go to out0 (split == 32)
+                dst0 = static_cast<bf16_t*>(a.out0) + pix * 32 + nbase;
+                if (a.act0 != nullptr) {
+                    const bf16_t* act = static_cast<const bf16_t*>(a.act0) + pix * 32 + nbase;
+                    float4 s[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) s[q] = unpack_bf4(*reinterpret_cast<const uint2*>(act + 8 * q));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        v[q].x *= lrelu_slope(s[q].x); v[q].y *= lrelu_slope(s[q].y);
+                        v[q].z *= lrelu_slope(s[q].z); v[q].w *= lrelu_slope(s[q].w);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2)
+                *reinterpret_cast<uint4*>(dst0 + 16 * j2 + 4 * hi) = bf16_pair_swap(pack_bf4(v[2 * j2]), pack_bf4(v[2 * j2 + 1]));
+        }
+        // fused nn.MaxPool2d(2) (Unet.py:51): vertical pair in the lane's own rows, horizontal pair in lane ^ 1, pooled from the bf16-ROUNDED
+        // values (max commutes with the monotone rounding)
+        if (a.epi == EPI_FWD && a.pool_out != nullptr && xok) {
+            const int Hp = a.H >> 1, Wp = a.W >> 1;
+#pragma unroll
+            for (int rp = 0; rp < RPW / 2; ++rp) {
+                const int y = y0 + wave * RPW + 2 * rp;
+                if (y >= a.H) continue;
+                uint2 pk[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float bq[4] = {bs[q].x, bs[q].y, bs[q].z, bs[q].w};
+                    float u[4];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        float p0 = acc[2 * rp][4 * q + jj] + bq[jj], p1 = acc[2 * rp + 1][4 * q + jj] + bq[jj];
+                        if (a.lrelu) { p0 = fmaxf(0.2f * p0, p0); p1 = fmaxf(0.2f * p1, p1); }
+                        u[jj] = hmax1s(fmaxf(p0, p1));
+                    }
+                    pk[q] = pack_bf4(make_float4(u[0], u[1], u[2], u[3]));
+                }
+                const uint4 w0 = bf16_pair_swap(pk[0], pk[1]), w1 = bf16_pair_swap(pk[2], pk[3]);
+                if (!(x & 1)) {
+                    bf16_t* dp = static_cast<bf16_t*>(a.pool_out) + ((size_t)(img * Hp + (y >> 1)) * Wp + (x >> 1)) * 32 + 8 * hi;
+                    *reinterpret_cast<uint4*>(dp) = w0;
+                    *reinterpret_cast<uint4*>(dp + 16) = w1;
+                }
+            }
+        }
+    }
+}
+
+template <int RPW, int WAVES>
+int launch_bfs(ConvArgs a, hipStream_t st) {
+    constexpr int TH = WAVES * RPW;
+    a.tiles_x = (a.W + TW - 1) / TW;
+    a.tiles_y = (a.H + TH - 1) / TH;
+    constexpr size_t A_BYTES = (size_t)(((TH + 2) * (TW + 2) * 4 + 63) / 64) * 1024;
+    const int NCH = (a.C0 + a.C1) >> 5;
+    const size_t lds_bytes = BFS_NAB * A_BYTES + (size_t)NCH * BFS_WCHUNK;
+    const long long tiles = (long long)a.tiles_x * a.tiles_y * a.N;
+    if (tiles <= 0) return 0;
+    if (tiles > 0x3fffffffLL) return ELD_ENOTSUP;
+    auto kern = conv_bfs_kernel<RPW, WAVES>;
+    static EldAttrOnce once;
+    { const int rc = once.ensure(kern, BFS_NAB * A_BYTES + 2 * (size_t)BFS_WCHUNK); if (rc) return rc; }
+    long long grid = (long long)eld_num_cus();
+    if (grid > tiles) grid = tiles;
+    ELD_LAUNCH(kern, dim3((unsigned)grid), dim3(64 * WAVES), lds_bytes, st, a);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+// Layers this kernel takes: bf16 3x3 with exactly 32 output channels (GEMM N), K = 32 or 64 input channels (one tensor, or the virtual concat of two
+// 32-channel tensors), a single output tensor, on a tile domain that gives every CU a tile; weights in conv_bfd's slab layout at BN = 32.
+bool bfs_takes(int Nout, int K, int N, int H, int W) {
+    if (Nout != 32 || (K != 32 && K != 64)) return false;
+    const long long px_tiles = (long long)((W + TW - 1) / TW) * ((H + 15) / 16) * N;
+    return px_tiles >= eld_num_cus();
+}
+
+int launch_conv_bfs(const ConvArgs& a, hipStream_t st) {
+    if ((size_t)a.H * a.W * a.C0 * 2 >= 0xFFFFFFF0ull) return ELD_ENOTSUP;
+    if (a.pool_out && (a.epi != EPI_FWD || (a.H & 1) || (a.W & 1))) return ELD_EINVAL;
+    if (a.epi == EPI_GRAD && (a.split != 32 || a.out1 != nullptr)) return ELD_ENOTSUP;
+    if (a.epi != EPI_FWD && a.epi != EPI_GRAD) return ELD_ENOTSUP;
+    return launch_bfs<2, 8>(a, st);
+}

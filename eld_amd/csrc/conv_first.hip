@@ -99,12 +99,18 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
                 if (y >= H) continue;
                 TO* dst = out + ((size_t)(img * H + y) * W + xx) * 32 + 4 * hi;
                 const float4 bs[4] = {b0, b1, b2, b3};
+                float4 v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float4 v = make_float4(acc[r][4 * q] + bs[q].x, acc[r][4 * q + 1] + bs[q].y, acc[r][4 * q + 2] + bs[q].z, acc[r][4 * q + 3] + bs[q].w);
-                    if (lrelu) { v.x = fmaxf(0.2f * v.x, v.x); v.y = fmaxf(0.2f * v.y, v.y); v.z = fmaxf(0.2f * v.z, v.z); v.w = fmaxf(0.2f * v.w, v.w); }
-                    if constexpr (sizeof(TO) == 4) *reinterpret_cast<float4*>(dst + 8 * q) = v;
-                    else *reinterpret_cast<uint2*>(dst + 8 * q) = pack_bf4(v);
+                    v[q] = make_float4(acc[r][4 * q] + bs[q].x, acc[r][4 * q + 1] + bs[q].y, acc[r][4 * q + 2] + bs[q].z, acc[r][4 * q + 3] + bs[q].w);
+                    if (lrelu) { v[q].x = fmaxf(0.2f * v[q].x, v[q].x); v[q].y = fmaxf(0.2f * v[q].y, v[q].y); v[q].z = fmaxf(0.2f * v[q].z, v[q].z); v[q].w = fmaxf(0.2f * v[q].w, v[q].w); }
+                }
+                if constexpr (sizeof(TO) == 4) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(dst + 8 * q) = v[q];
+                } else {                                     // bf16: 16-byte stores of whole 8-channel groups (conv.h bf16_pair_swap)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) *reinterpret_cast<uint4*>(dst + 16 * j + 4 * hi) = bf16_pair_swap(pack_bf4(v[2 * j]), pack_bf4(v[2 * j + 1]));
                 }
             }
         }

@@ -355,10 +355,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
                             if (a.epi == EPI_GRAD && nbase + 8 * q >= a.split) tmax1 = fmaxf(tmax1, mq); else tmax0 = fmaxf(tmax0, mq);
                         }
                     }
+                    if constexpr (ES == 4) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        if constexpr (ES == 4) *reinterpret_cast<float4*>(dst[q]) = v[q];
-                        else *reinterpret_cast<uint2*>(dst[q]) = pack_bf4(v[q]);
+                        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(dst[q]) = v[q];
+                    } else {
+                        // bf16: 16-byte stores (conv.h bf16_pair_swap) -- after the exchange the lane owns the whole 8-channel group 2j + hi,
+                        // which starts at dst[2j] + 4 hi (dst[q] = block base + 8 q + 4 hi in every epilogue mode: a 32-channel block never
+                        // straddles the concat split or a transposed-conv tap)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const uint4 w = bf16_pair_swap(pack_bf4(v[2 * j]), pack_bf4(v[2 * j + 1]));
+                            *reinterpret_cast<uint4*>(dst[2 * j] + 4 * hi) = w;
+                        }
                     }
                 }
             }
