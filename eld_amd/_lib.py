@@ -50,6 +50,7 @@ SIGNATURES = {
     'eld_unet_backward_ex': (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     'eld_conv_fp32_algo': (_i, [_i]),
     'eld_debug_conv_prof': (None, [_vp]),
+    'eld_debug_kernel_mask': (_i, [_i]),
     'eld_isp_process': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _i, _vp]),
     'eld_quality_assess_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'eld_quality_assess': (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _f, _vp]),

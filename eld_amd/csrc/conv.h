@@ -119,6 +119,7 @@ __host__ __device__ inline size_t bfd_slab_bytes(int BN) { return (size_t)3 * BN
 int launch_conv_bfd(const ConvArgs& a, hipStream_t st);      // transposed-conv directions; ELD_ENOTSUP if not covered
 // bf16 3x3 layers with exactly 32 output channels and K = 32 / 64 (conv_bfs.hip: weights resident in LDS, three-deep activation ring); they take
 // their weights in conv_bfd's slab layout at BN = 32 (bfd_slab_bn returns 32 for them)
+int debug_kernel_mask(int set);      // eld_debug_kernel_mask: set < 0 only queries
 bool bfs_takes(int Nout, int K, int N, int H, int W);
 int launch_conv_bfs(const ConvArgs& a, hipStream_t st);
 

@@ -282,7 +282,16 @@ int launch_bfs(ConvArgs a, hipStream_t st) {
 
 // Layers this kernel takes: bf16 3x3 with exactly 32 output channels (GEMM N), K = 32 or 64 input channels (one tensor, or the virtual concat of two
 // 32-channel tensors), a single output tensor, on a tile domain that gives every CU a tile; weights in conv_bfd's slab layout at BN = 32.
+int debug_kernel_mask(int set) {
+    static int mask = 0;
+    const int prev = mask;
+    if (set >= 0) mask = set;
+    return prev;
+}
+extern "C" int eld_debug_kernel_mask(int mask) { return debug_kernel_mask(mask < 0 ? 0 : mask); }
+
 bool bfs_takes(int Nout, int K, int N, int H, int W) {
+    if (debug_kernel_mask(-1) & 1) return false;
     if (Nout != 32 || (K != 32 && K != 64)) return false;
     const long long px_tiles = (long long)((W + TW - 1) / TW) * ((H + 15) / 16) * N;
     return px_tiles >= eld_num_cus();

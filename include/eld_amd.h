@@ -233,6 +233,10 @@ int eld_isp_process(const float* bayer, const float* wbs, const float* ccms, flo
 /* Dev tool (tools/conv_phase_profile.py; a no-op unless built with -DELD_DEV_TOOLS=1): device buffer of 8 x 4 x 128 x 6 uint64 that conv_x3_kernel fills with s_memtime
  * stamps of its stage phases (first 8 workgroups, first 128 stages); NULL switches it off (default). */
 void eld_debug_conv_prof(void* buf);
+/* Test hook: route the bf16 launches that normally run on a specialised kernel back to the generic one, so that the parity tests can demand
+ * BIT-IDENTICAL results from the two kernel families on the same inputs (same k order, same MFMA): mask bit 0 = conv_bfs_kernel (32-output-channel
+ * 3x3 layers) off, bit 1 = conv_bfg_kernel (transposed convolutions) off.  Returns the previous mask.  Process-wide; production never calls it. */
+int eld_debug_kernel_mask(int mask);
 
 /* ---- single layers on NHWC float32 tensors with reference-layout weights; used by the parity tests ---- */
 size_t eld_layer_workspace_bytes(int N, int H, int W, int Cin, int Cout);

@@ -438,6 +438,34 @@ def test_unet_bf16_dma_kernels_full_frame(lib):
         assert cos >= 0.995, (n, cos)
 
 
+@pytest.mark.parametrize('shape', [(2, 4, 272, 560), (1, 4, 512, 512)])
+def test_bf16_specialised_kernels_equal_the_generic_kernel_bit_for_bit(lib, shape):
+    """conv_bfs_kernel (32-output-channel bf16 3x3 layers: resident weights, 3-deep LDS-DMA activation ring, fused pool, 16-byte stores)
+    accumulates in the same order on the same MFMA as conv_igemm_kernel<bf16> (chunk -> ky -> kx -> 16-k block), so routing those launches
+    back to the generic kernel (eld_debug_kernel_mask) must reproduce output AND every parameter gradient bit for bit -- ragged right/bottom
+    tiles, two images, the virtual concat of conv9_1, the slope epilogues of the backward-data launches."""
+    from eld_amd.unet import UNetSeeInDark
+    torch.manual_seed(5)
+    net = UNetSeeInDark(4, 4).cuda()
+    net.train_precision = net.inference_precision = 'bf16'
+    g = torch.Generator(device='cuda').manual_seed(9)
+    x = torch.rand(*shape, device='cuda', generator=g)
+    t = torch.rand(*shape, device='cuda', generator=g)
+    res = {}
+    for mask in (0, 3):
+        prev = lib.eld_debug_kernel_mask(mask)
+        try:
+            net.zero_grad()
+            out = net(x)
+            torch.nn.functional.l1_loss(out, t).backward()
+            res[mask] = (out.detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters()})
+        finally:
+            lib.eld_debug_kernel_mask(prev)
+    assert torch.equal(res[0][0], res[3][0])
+    for n in res[0][1]:
+        assert torch.equal(res[0][1][n], res[3][1][n]), n
+
+
 def test_unet_full_frame_properties(lib):
     """BASELINE.json configs[1] size (1 x 4 x 1424 x 2128), where the fp64 oracle is out of reach: size-independent properties.
       * crop consistency: away from the crop border (beyond the receptive field) the output of a 16-aligned 512x512 crop
