@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libeld_amd.so')
+LIB_PATH = os.environ.get('ELD_AMD_LIB') or os.path.join(_HERE, 'libeld_amd.so')      # ELD_AMD_LIB: developer builds (tools/build_dev.sh)
 
 # flags / enums of include/eld_amd.h
 SHOT_POISSON, SHOT_GAUSS, READ_GAUSS, READ_TL, ROW, QUANT, CBIAS, CLIP = 1, 2, 4, 8, 16, 32, 64, 128

@@ -98,6 +98,32 @@ __device__ __forceinline__ uint4 bf16_pair_swap(uint2 a, uint2 b) {
     return make_uint4(r0[0], r1[0], r0[1], r1[1]);
 }
 
+// Full-line variant for a row of 32 pixels x one 32-channel block.  In: pk[q] = this lane's packed channels 8q + 4hi .. +3 of pixel m = lane & 31.
+// Out: two 16-byte values; value i belongs to pixel (lane & 15) + 16 i of the row, channel group bf16_line_group(lane) (8 channels, 16 bytes).
+// Store instruction i of a wave then covers 16 CONSECUTIVE pixels x 64 bytes -- 1 KiB of contiguous memory when the tensor has 32 channels --
+// instead of 32 bytes of each of 32 pixels.  Built from bf16_pair_swap plus one v_permlane16_swap per dword (rows of 16 lanes: row 1 of the first
+// operand <-> row 0 of the second, row 3 <-> row 2).  bf16_line_unswap is the inverse (both networks are involutions): the same two 16-byte values,
+// loaded in the line layout, back to the lane's own quarter-groups -- used for the saved activations of the slope epilogue.
+__device__ __forceinline__ int bf16_line_group(int lane) { return ((lane >> 4) & 1) * 2 + (lane >> 5); }      // rows 0..3 of 16 lanes hold groups 0, 2, 1, 3
+__device__ __forceinline__ void bf16_rows_swap(uint4& g0, uint4& g1) {
+    auto r = __builtin_amdgcn_permlane16_swap(g0.x, g1.x, false, false); g0.x = r[0]; g1.x = r[1];
+    r = __builtin_amdgcn_permlane16_swap(g0.y, g1.y, false, false); g0.y = r[0]; g1.y = r[1];
+    r = __builtin_amdgcn_permlane16_swap(g0.z, g1.z, false, false); g0.z = r[0]; g1.z = r[1];
+    r = __builtin_amdgcn_permlane16_swap(g0.w, g1.w, false, false); g0.w = r[0]; g1.w = r[1];
+}
+__device__ __forceinline__ void bf16_line_swap(const uint2 (&pk)[4], uint4& s0, uint4& s1) {
+    s0 = bf16_pair_swap(pk[0], pk[1]);      // lane (m, hi): group hi
+    s1 = bf16_pair_swap(pk[2], pk[3]);      // lane (m, hi): group 2 + hi
+    bf16_rows_swap(s0, s1);                 // s0: pixels 0..15, s1: pixels 16..31; row r of 16 lanes: group {0, 2, 1, 3}[r]
+}
+__device__ __forceinline__ void bf16_line_unswap(uint4 s0, uint4 s1, uint2 (&pk)[4]) {
+    bf16_rows_swap(s0, s1);                 // back to: s0 = group hi, s1 = group 2 + hi of pixel m (8 channels each)
+    auto r = __builtin_amdgcn_permlane32_swap(s0.x, s0.z, false, false); pk[0].x = r[0]; pk[1].x = r[1];
+    r = __builtin_amdgcn_permlane32_swap(s0.y, s0.w, false, false); pk[0].y = r[0]; pk[1].y = r[1];
+    r = __builtin_amdgcn_permlane32_swap(s1.x, s1.z, false, false); pk[2].x = r[0]; pk[3].x = r[1];
+    r = __builtin_amdgcn_permlane32_swap(s1.y, s1.w, false, false); pk[2].y = r[0]; pk[3].y = r[1];
+}
+
 int launch_conv(const ConvArgs& a, int mode, hipStream_t st);
 // fp32 3x3 convolutions: 0 = exact-fp32 MFMA (conv_igemm.hip), 1 = three-piece bf16 split on the bf16 MFMA (conv_x3.hip).
 // set < 0 only queries.  Initial value from env ELD_FP32_CONV (mfma | x3).  Returns the value in force before the call.

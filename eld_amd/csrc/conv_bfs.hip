@@ -23,6 +23,7 @@
 #define TW 32
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -41,7 +42,9 @@ __device__ __forceinline__ float hmax1s(float f) {       // max with lane ^ 1 (h
 constexpr int BFS_NAB = 3;                               // activation ring depth
 constexpr int BFS_WCHUNK = 9 * 32 * 64;                  // packed weights of one 32-channel chunk: 18 DMA pieces
 
-template <int RPW, int WAVES>
+// ACT: EPI_GRAD with a saved activation (slope epilogue) -- compile time, because the activation loads are hand-issued asm loads whose destination
+// registers must not pass through a phi (cdna_hip_programming.md 5.7 item 1: the compiler may copy them before the data has landed)
+template <int RPW, int WAVES, bool ACT>
 __global__ __launch_bounds__(64 * WAVES) void conv_bfs_kernel(const ConvArgs a) {
     constexpr int TH = WAVES * RPW, HW2 = TW + 2, A_PIX = (TH + 2) * HW2;
     constexpr int A_UNITS = A_PIX * 4, A_PIECES = (A_UNITS + 63) / 64, A_BYTES = A_PIECES * 1024;
@@ -109,10 +112,16 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfs_kernel(const ConvArgs a) 
     const int my_tiles = (total_tiles - first + stride - 1) / stride;
     const int n_items = my_tiles * NCH;
     // item j = (tile first + (j / NCH) * stride, chunk j % NCH); its halo tile lives in ring slot j % 3
+    // Past the last item the same A_IT instructions are issued with out-of-range offsets (zeros land in a ring slot nobody reads again): every
+    // item then has exactly A_IT younger DMA instructions behind it, and every wait of the loop is the same immediate.
     auto issue_A = [&](int j) {
         const int k = NCH == 2 ? (j >> 1) : j, chunk = NCH == 2 ? (j & 1) : 0;
         const int t = first + k * stride;
-        if (t != l_tile) setup_load(t);
+        if (j >= n_items) {
+#pragma unroll
+            for (int it = 0; it < A_IT; ++it) a_voff[it] = OOB;
+            l_tile = -1;
+        } else if (t != l_tile) setup_load(t);
         const char* src = static_cast<const char*>(chunk < NCH0 ? a.in0 : a.in1);
         const int cs = chunk < NCH0 ? chunk : chunk - NCH0;
         const size_t img_bytes = (size_t)a.H * a.W * Cs0 * 2;
@@ -144,17 +153,39 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfs_kernel(const ConvArgs a) 
 #pragma unroll
     for (int q = 0; q < 4; ++q) bs[q] = a.epi == EPI_FWD ? *reinterpret_cast<const float4*>(a.bias + 4 * hi + 8 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
 
+#pragma unroll
+    for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(bs[q].x), "+v"(bs[q].y), "+v"(bs[q].z), "+v"(bs[q].w));      // the loads complete HERE, not at a vmcnt(0) inside the loop
+    static_assert(RPW == 2, "the activation-load wait names ac[2][2]");
+    u32x4 ac[RPW][2];                                      // native vector type: one 128-bit register tuple per asm operand
+
     issue_A(0);
-    if (n_items > 1) issue_A(1);
+    issue_A(1);
 
     f32x16 acc[RPW];
     for (int j = 0; j < n_items; ++j) {
         const int k = NCH == 2 ? (j >> 1) : j, chunk = NCH == 2 ? (j & 1) : 0;
         const int t = first + k * stride;
         // this wave's pieces of item j (and, the first time, of the weights) have landed; item j+1's may still fly
-        if (j + 1 < n_items) bfs_wait_vm<A_IT>(); else bfs_wait_vm<0>();
+        bfs_wait_vm<A_IT>();
         __syncthreads();                         // ... and everybody else's; everybody is done reading ring slot (j - 1) % 3 = (j + 2) % 3
-        if (j + 2 < n_items) issue_A(j + 2);
+        if constexpr (ACT) {                      // (NCH == 1 in these launches: every item ends a tile)
+            // saved activations of this tile's output pixels (slope epilogue), in the line layout; loaded by hand so that the compiler does not
+            // wait for them with a vmcnt that would drain the younger halo DMAs: they are OLDER than item j+2's pieces, so the epilogue's
+            // wait leaves exactly those A_IT pieces in flight.  Out-of-range pixels re-read a valid address (the value is not used).
+            int img, y0, x0;
+            decode(t, img, y0, x0);
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int y = min(y0 + wave * RPW + r, a.H - 1);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int xx = min(x0 + (lane & 15) + 16 * i, a.W - 1);
+                    const bf16_t* p = static_cast<const bf16_t*>(a.act0) + ((size_t)(img * a.H + y) * a.W + xx) * 32 + 8 * bf16_line_group(lane);
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ac[r][i]) : "v"(p) : "memory");
+                }
+            }
+        }
+        if (!(ELD_DBG(a) & 4)) issue_A(j + 2);
         if (chunk == 0) {
 #pragma unroll
             for (int r = 0; r < RPW; ++r)
@@ -163,6 +194,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfs_kernel(const ConvArgs a) 
         }
         const char* la0 = lds + (j % BFS_NAB) * A_BYTES + (wave * RPW) * (HW2 * 64);
         const char* lw0 = ldsW + (NCH == 2 ? chunk : 0) * 6144;             // slab(ky, chunk) at (ky * NCH + chunk) * 6144
+        if (!(ELD_DBG(a) & 2))
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const char* la = la0 + ky * (HW2 * 64);
@@ -181,22 +213,24 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfs_kernel(const ConvArgs a) 
                 }
         }
         if (chunk + 1 < NCH) continue;
-
-        // ---- epilogue of tile t: lane (m, hi) owns pixel x0 + m and channels 8q + 4hi .. +3 (as conv_bfd.hip) ---------------------------------
+        if constexpr (ACT) {                     // the hand-issued activation loads have landed (item j+2's A_IT DMA pieces, issued after them, may still fly)
+            // (whole 128-bit tuples as operands: with sixteen 32-bit operands the compiler shuffled the registers -- v_mov copies of data that had
+            // not landed yet -- to build the statement's operand list)
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ac[0][0]), "+v"(ac[0][1]), "+v"(ac[1][0]), "+v"(ac[1][1]) : "n"(A_IT));
+        }
+        if (ELD_DBG(a) & 1) continue;
+        // ---- epilogue of tile t.  The MFMA leaves lane (m, hi) with channels 8q + 4hi .. +3 of pixel x0 + m; the stores (and the loads of the saved
+        //      activations) use the full-line layout of conv.h bf16_line_swap: instruction i of a wave covers pixels x0 + 16 i .. + 15 completely
+        //      (1 KiB contiguous), lane l holding pixel (l & 15) + 16 i, channel group bf16_line_group(l) ---------------------------------------------
         int img, y0, x0;
         decode(t, img, y0, x0);
-        const int x = x0 + m;
-        const bool xok = x < a.W;
+        const int lp = lane & 15, lg = bf16_line_group(lane);
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             const int y = y0 + wave * RPW + r;
-            if (y >= a.H || !xok) continue;
-            const size_t pix = (size_t)(img * a.H + y) * a.W + x;
-            const int nbase = 4 * hi;
             float4 v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = make_float4(acc[r][4 * q], acc[r][4 * q + 1], acc[r][4 * q + 2], acc[r][4 * q + 3]);
-            bf16_t* dst0;                                                   // this lane's 4 channels of group 0
             if (a.epi == EPI_FWD) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -206,25 +240,26 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfs_kernel(const ConvArgs a) 
                         v[q].z = fmaxf(0.2f * v[q].z, v[q].z); v[q].w = fmaxf(0.2f * v[q].w, v[q].w);
                     }
                 }
-                dst0 = static_cast<bf16_t*>(a.out0) + pix * 32 + nbase;
-            } else {                                                        // EPI_GRAD: all 32 channels go to out0 (split == 32)
-                dst0 = static_cast<bf16_t*>(a.out0) + pix * 32 + nbase;
-                if (a.act0 != nullptr) {
-                    const bf16_t* act = static_cast<const bf16_t*>(a.act0) + pix * 32 + nbase;
-                    float4 s[4];
+            } else if constexpr (ACT) {                                     // EPI_GRAD: times the LeakyReLU slope of the saved activation
+                uint2 sp[4];
+                bf16_line_unswap(make_uint4(ac[r][0][0], ac[r][0][1], ac[r][0][2], ac[r][0][3]), make_uint4(ac[r][1][0], ac[r][1][1], ac[r][1][2], ac[r][1][3]), sp);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) s[q] = unpack_bf4(*reinterpret_cast<const uint2*>(act + 8 * q));
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        v[q].x *= lrelu_slope(s[q].x); v[q].y *= lrelu_slope(s[q].y);
-                        v[q].z *= lrelu_slope(s[q].z); v[q].w *= lrelu_slope(s[q].w);
-                    }
+                for (int q = 0; q < 4; ++q) {
+                    const float4 sv = unpack_bf4(sp[q]);
+                    v[q].x *= lrelu_slope(sv.x); v[q].y *= lrelu_slope(sv.y); v[q].z *= lrelu_slope(sv.z); v[q].w *= lrelu_slope(sv.w);
                 }
             }
+            uint2 pk[4];
 #pragma unroll
-            for (int j2 = 0; j2 < 2; ++j2)
-                *reinterpret_cast<uint4*>(dst0 + 16 * j2 + 4 * hi) = bf16_pair_swap(pack_bf4(v[2 * j2]), pack_bf4(v[2 * j2 + 1]));
+            for (int q = 0; q < 4; ++q) pk[q] = pack_bf4(v[q]);
+            uint4 s0, s1;
+            bf16_line_swap(pk, s0, s1);                                     // every lane takes part; only the stores are predicated
+            bf16_t* row = static_cast<bf16_t*>(a.out0) + ((size_t)(img * a.H + y) * a.W + x0) * 32 + 8 * lg;
+            if (y < a.H && x0 + lp < a.W) *reinterpret_cast<uint4*>(row + lp * 32) = s0;
+            if (y < a.H && x0 + lp + 16 < a.W) *reinterpret_cast<uint4*>(row + (lp + 16) * 32) = s1;
         }
+        const int x = x0 + m;
+        const bool xok = x < a.W;
         // fused nn.MaxPool2d(2) (Unet.py:51): vertical pair in the lane's own rows, horizontal pair in lane ^ 1, pooled from the bf16-ROUNDED
         // values (max commutes with the monotone rounding)
         if (a.epi == EPI_FWD && a.pool_out != nullptr && xok) {
@@ -257,7 +292,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfs_kernel(const ConvArgs a) 
     }
 }
 
-template <int RPW, int WAVES>
+template <int RPW, int WAVES, bool ACT>
 int launch_bfs(ConvArgs a, hipStream_t st) {
     constexpr int TH = WAVES * RPW;
     a.tiles_x = (a.W + TW - 1) / TW;
@@ -268,7 +303,7 @@ int launch_bfs(ConvArgs a, hipStream_t st) {
     const long long tiles = (long long)a.tiles_x * a.tiles_y * a.N;
     if (tiles <= 0) return 0;
     if (tiles > 0x3fffffffLL) return ELD_ENOTSUP;
-    auto kern = conv_bfs_kernel<RPW, WAVES>;
+    auto kern = conv_bfs_kernel<RPW, WAVES, ACT>;
     static EldAttrOnce once;
     { const int rc = once.ensure(kern, BFS_NAB * A_BYTES + 2 * (size_t)BFS_WCHUNK); if (rc) return rc; }
     long long grid = (long long)eld_num_cus();
@@ -302,5 +337,9 @@ int launch_conv_bfs(const ConvArgs& a, hipStream_t st) {
     if (a.pool_out && (a.epi != EPI_FWD || (a.H & 1) || (a.W & 1))) return ELD_EINVAL;
     if (a.epi == EPI_GRAD && (a.split != 32 || a.out1 != nullptr)) return ELD_ENOTSUP;
     if (a.epi != EPI_FWD && a.epi != EPI_GRAD) return ELD_ENOTSUP;
-    return launch_bfs<2, 8>(a, st);
+    if (a.epi == EPI_GRAD && a.act0 != nullptr) {
+        if (a.C0 + a.C1 != 32) return ELD_ENOTSUP;      // the slope variant assumes one chunk per tile (the U-Net's two such launches have K = 32)
+        return launch_bfs<2, 8, true>(a, st);
+    }
+    return launch_bfs<2, 8, false>(a, st);
 }

@@ -90,3 +90,54 @@ def test_plugin_constructor_and_sample_params(golden_dir, capsys):
     np.random.seed(5)
     full = NoiseModel(model='PGRU', include=4)._sample_params()
     assert tuple(base) == tuple(full) and full.tl_scale > 0 and full.row_scale > 0 and -0.25 < full.tl_lambda < 0.25
+
+
+def test_hand_issued_loads_are_not_touched_before_their_wait():
+    """conv_bfs_kernel<.., ACT = true> loads the saved activations with inline-asm global loads that hipcc does not count
+    (cdna_hip_programming.md 5.7 item 1): between such a load and the hand-written `s_waitcnt vmcnt(5)` that retires it the compiler
+    must neither read nor copy nor overwrite the destination registers.  Audit of the generated gfx950 assembly (cross-compiles
+    without a GPU); silent corruption otherwise -- a passing numerical test is not evidence for this hazard."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc')
+    src = os.path.join(ROOT, 'eld_amd', 'csrc', 'conv_bfs.hip')
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, 'bfs.s')
+        subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fhip-fp32-correctly-rounded-divide-sqrt',
+                               '-S', '--cuda-device-only', '-o', out, src], stderr=subprocess.DEVNULL)
+        text = open(out).read()
+    body = text[text.index('conv_bfs_kernelILi2ELi8ELb1EEEv8ConvArgs:'):]
+    body = body[:body.index('.Lfunc_end')]
+    lines = body.split('\n')
+    # asm statements are bracketed by ;;#ASMSTART / ;;#ASMEND
+    in_asm, pending, checked = False, set(), 0
+    for ln in lines:
+        t = ln.strip()
+        if t.startswith(';;#ASMSTART'):
+            in_asm = True
+            continue
+        if t.startswith(';;#ASMEND'):
+            in_asm = False
+            continue
+        if not t or t.startswith(';') or t.startswith('.'):
+            continue
+        if in_asm:
+            m = re.match(r'global_load_dwordx4 v\[(\d+):(\d+)\]', t)
+            if m:
+                pending |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+            elif t.startswith('s_waitcnt vmcnt(5)') and pending:
+                pending.clear()
+                checked += 1
+            continue
+        if pending:
+            code = t.split(';')[0]
+            regs = set(int(r) for r in re.findall(r'\bv(\d+)\b', code))
+            for a_, b_ in re.findall(r'v\[(\d+):(\d+)\]', code):
+                regs |= set(range(int(a_), int(b_) + 1))
+            # the address registers of a later hand-issued load may be REUSED destinations only after that load: any touch is a violation
+            assert not (regs & pending), 'compiler instruction touches an un-waited asm load destination: %s' % t
+    assert checked >= 1
