@@ -43,6 +43,19 @@ __device__ __forceinline__ void bfd_dma16(i32x4 rsrc, unsigned voff, unsigned so
 template <int N>
 __device__ __forceinline__ void bfd_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// the same for a wave-uniform RUNTIME count (the stage behind an epilogue: DMA pieces + the store instructions the epilogue issued); any
+// value below the true count would only wait longer, so counts beyond the table fall back to 0
+__device__ __forceinline__ void bfd_wait_vm_dyn(int n) {
+    switch (n) {
+#define BFD_W(k) case k: bfd_wait_vm<k>(); break;
+        BFD_W(1) BFD_W(2) BFD_W(3) BFD_W(4) BFD_W(5) BFD_W(6) BFD_W(7) BFD_W(8) BFD_W(9) BFD_W(10) BFD_W(11) BFD_W(12) BFD_W(13) BFD_W(14) BFD_W(15) BFD_W(16)
+        BFD_W(17) BFD_W(18) BFD_W(19) BFD_W(20) BFD_W(21) BFD_W(22) BFD_W(23) BFD_W(24) BFD_W(25) BFD_W(26) BFD_W(27) BFD_W(28) BFD_W(29) BFD_W(30) BFD_W(31) BFD_W(32)
+        BFD_W(33) BFD_W(34) BFD_W(35) BFD_W(36) BFD_W(37) BFD_W(38) BFD_W(39) BFD_W(40)
+#undef BFD_W
+        default: bfd_wait_vm<0>(); break;
+    }
+}
+
 __device__ __forceinline__ float hmax1b(float f) {       // max with lane ^ 1 (horizontal neighbour pixel): quad_perm [1,0,3,2]
     return fmaxf(f, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(f), 0xB1, 0xF, 0xF, true)));
 }
@@ -56,7 +69,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
     constexpr int A_IT = (A_PIECES + WAVES - 1) / WAVES, B_IT = (B_PIECES + WAVES - 1) / WAVES;
     static_assert(B_UNITS % 64 == 0, "slab = whole DMA pieces");
     constexpr int NBB = 3;                                               // weight-slab ring
-    extern __shared__ __attribute__((aligned(16))) char lds[];           // [B0][B1][B2][A0][A1]
+    extern __shared__ __attribute__((aligned(16))) char lds[];           // [B0][B1][B2][A0][A1][bias: Nout floats]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -144,6 +157,13 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
 
     int t = blockIdx.x;
     if (t >= total_tiles) return;
+    // bias -> LDS once per workgroup: a global load inside the tile loop's epilogue would be waited for with a vmcnt that also drains every
+    // LDS-DMA piece in flight (the queue retires in order)
+    float* lds_bias = reinterpret_cast<float*>(lds + NBB * B_BYTES + 2 * A_BYTES);
+    if (a.epi == EPI_FWD) {
+        for (int i = tid; i < a.Nout; i += THREADS) lds_bias[i] = a.bias[i];
+    }
+    __syncthreads();                             // (plain loads + ds_write: complete before the first DMA is issued)
     setup_load(t);
     int bufA = 0, bufB = 0;
     // slab of the stage `ahead` stages after (chunk, ky) of tile (nb, t_next): crosses chunk and tile boundaries; false at the end of the work
@@ -181,7 +201,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
                 // this wave's pieces of THIS stage's operands have landed (the younger ones, for later stages, may still fly)
                 if (young == B_IT) bfd_wait_vm<B_IT>();
                 else if (young == B_IT + A_IT) bfd_wait_vm<B_IT + A_IT>();
-                else bfd_wait_vm<0>();
+                else bfd_wait_vm_dyn(young);
                 __syncthreads();                 // ... and everybody else's; the previous stage's fragment reads are done
                 int issued = 0;
                 int b2 = bufB + 2; if (b2 >= NBB) b2 -= NBB;
@@ -215,70 +235,81 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
             bufA ^= 1;
         }
 
-        // ---- epilogue: lane (m, hi) owns pixel x0 + m and channels 8q + 4hi .. +3 of each 32-block (as conv_igemm.hip) -------------
+        // ---- epilogue.  The MFMA leaves lane (m, hi) with channels 8q + 4hi .. +3 of pixel x0 + m in every 32-channel block; stores (and the
+        //      loads of the saved activations) use the full-line layout of conv.h bf16_line_swap: per block, instruction i of a wave covers the
+        //      64 bytes of pixels x0 + 16 i .. + 15, lane l holding pixel (l & 15) + 16 i, channel group bf16_line_group(l).
+        //      ns counts the store instructions this wave really issues (a store whose lanes are all out of range is branched over), so that
+        //      the next stage can leave exactly them -- and the last stage's slab pieces -- in flight -------------------------------------
+        int ns = 0;
         {
+            const int lp = lane & 15, lg = bf16_line_group(lane);
+            const int halves = (x0 + 16 < a.W) ? 2 : 1;                   // x0 < W for every tile
             const int x = x0 + m;
             const bool xok = x < a.W;
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
-                const int y = y0 + wave * RPW + r;
-                if (y >= a.H || !xok) continue;
-                const size_t pix = (size_t)(img * a.H + y) * a.W + x;
+                const int y = y0 + wave * RPW + r;                      // wave-uniform
+                const bool yok = y < a.H;
+                const int yc = yok ? y : a.H - 1;                       // loads of out-of-range rows / columns re-read a valid pixel (result unused)
+                const size_t rowpix = (size_t)(img * a.H + yc) * a.W;
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) {
-                    const int nbase = nb * BN + tt * 32 + 4 * hi;
+                    const int nb32 = nb * BN + tt * 32;
                     float4 v[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = make_float4(acc[r][tt][4 * q], acc[r][tt][4 * q + 1], acc[r][tt][4 * q + 2], acc[r][tt][4 * q + 3]);
-                    bf16_t* dst[4];
+                    bf16_t* drow;                                        // block base of pixel x0 of this row in the destination tensor, + this lane's group
+                    int C;
                     if (a.epi == EPI_FWD) {
-                        float4 bs[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) bs[q] = *reinterpret_cast<const float4*>(a.bias + nbase + 8 * q);
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            v[q].x += bs[q].x; v[q].y += bs[q].y; v[q].z += bs[q].z; v[q].w += bs[q].w;
+                            const float4 bq = *reinterpret_cast<const float4*>(lds_bias + nb32 + 4 * hi + 8 * q);
+                            v[q].x += bq.x; v[q].y += bq.y; v[q].z += bq.z; v[q].w += bq.w;
                             if (a.lrelu) {
                                 v[q].x = fmaxf(0.2f * v[q].x, v[q].x); v[q].y = fmaxf(0.2f * v[q].y, v[q].y);
                                 v[q].z = fmaxf(0.2f * v[q].z, v[q].z); v[q].w = fmaxf(0.2f * v[q].w, v[q].w);
                             }
-                            dst[q] = static_cast<bf16_t*>(a.out0) + pix * a.Nout + nbase + 8 * q;
                         }
+                        C = a.Nout;
+                        drow = static_cast<bf16_t*>(a.out0) + (rowpix + x0) * C + nb32 + 8 * lg;
                     } else {
-                        float4 s[4];
-                        bool has[4];
+                        const bool lo = nb32 < a.split;
+                        C = lo ? a.split : a.Nout - a.split;
+                        const int cb = lo ? nb32 : nb32 - a.split;
+                        drow = static_cast<bf16_t*>(lo ? a.out0 : a.out1) + (rowpix + x0) * C + cb + 8 * lg;
+                        const bf16_t* act = static_cast<const bf16_t*>(lo ? a.act0 : a.act1);
+                        if (act != nullptr) {
+                            const bf16_t* arow = act + rowpix * C + cb + 8 * lg;
+                            const uint4 a0 = *reinterpret_cast<const uint4*>(arow + (size_t)min(x0 + lp, a.W - 1) * C);
+                            const uint4 a1 = *reinterpret_cast<const uint4*>(arow + (size_t)min(x0 + lp + 16, a.W - 1) * C);
+                            uint2 sp[4];
+                            bf16_line_unswap(a0, a1, sp);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int n = nbase + 8 * q;
-                            const bool lo = n < a.split;
-                            const int C = lo ? a.split : a.Nout - a.split;
-                            const size_t idx = pix * C + (lo ? n : n - a.split);
-                            dst[q] = static_cast<bf16_t*>(lo ? a.out0 : a.out1) + idx;
-                            const bf16_t* act = static_cast<const bf16_t*>(lo ? a.act0 : a.act1);
-                            has[q] = act != nullptr;
-                            s[q] = make_float4(1.f, 1.f, 1.f, 1.f);
-                            if (has[q]) s[q] = unpack_bf4(*reinterpret_cast<const uint2*>(act + idx));
-                        }
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if (has[q]) {
-                                v[q].x *= lrelu_slope(s[q].x); v[q].y *= lrelu_slope(s[q].y);
-                                v[q].z *= lrelu_slope(s[q].z); v[q].w *= lrelu_slope(s[q].w);
+                            for (int q = 0; q < 4; ++q) {
+                                const float4 sv = unpack_bf4(sp[q]);
+                                v[q].x *= lrelu_slope(sv.x); v[q].y *= lrelu_slope(sv.y); v[q].z *= lrelu_slope(sv.z); v[q].w *= lrelu_slope(sv.w);
                             }
+                        }
                     }
+                    uint2 pk[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(v[q].x), "+v"(v[q].y), "+v"(v[q].z), "+v"(v[q].w));
-                    // 16-byte stores (conv.h bf16_pair_swap): dst[q] points at this lane's 4 channels of group q; after the exchange the lane owns
-                    // the whole group 2j + hi
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const uint4 w = bf16_pair_swap(pack_bf4(v[2 * j]), pack_bf4(v[2 * j + 1]));
-                        *reinterpret_cast<uint4*>(dst[2 * j] + 4 * hi) = w;      // = start of group 2j + hi (dst[q] = block base + 8 q + 4 hi)
+                    for (int q = 0; q < 4; ++q) pk[q] = pack_bf4(v[q]);
+                    uint4 s0, s1;
+                    bf16_line_swap(pk, s0, s1);                          // every lane takes part; only the stores are predicated
+                    if (yok) {
+                        if (x0 + lp < a.W) *reinterpret_cast<uint4*>(drow + (size_t)lp * C) = s0;
+                        if (halves == 2 && x0 + lp + 16 < a.W) *reinterpret_cast<uint4*>(drow + (size_t)(lp + 16) * C) = s1;
                     }
                 }
+                if (yok) ns += NT * halves;
             }
             // fused nn.MaxPool2d(2) (Unet.py:51-63): vertical pair in the lane's own rows, horizontal pair in lane ^ 1; pooled from the
             // bf16-ROUNDED values (max commutes with the monotone rounding, so this equals pooling the stored tensor)
+            if (a.epi == EPI_FWD && a.pool_out != nullptr) {            // (wave-uniform) two 16-byte stores per block and valid row pair, from the even pixels
+#pragma unroll
+                for (int rp = 0; rp < RPW / 2; ++rp)
+                    if (y0 + wave * RPW + 2 * rp < a.H) ns += 2 * NT;
+            }
             if (a.epi == EPI_FWD && a.pool_out != nullptr && xok) {
                 const int Hp = a.H >> 1, Wp = a.W >> 1;
 #pragma unroll
@@ -286,7 +317,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
                     const int nbase = nb * BN + tt * 32 + 4 * hi;
                     float4 bs[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) bs[q] = *reinterpret_cast<const float4*>(a.bias + nbase + 8 * q);
+                    for (int q = 0; q < 4; ++q) bs[q] = *reinterpret_cast<const float4*>(lds_bias + nbase + 8 * q);
 #pragma unroll
                     for (int rp = 0; rp < RPW / 2; ++rp) {
                         const int y = y0 + wave * RPW + 2 * rp;
@@ -315,7 +346,9 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
                 }
             }
         }
-        young = -1;                              // the epilogue's stores are younger than the DMAs in flight: the next stage waits for all of them
+        // the epilogue's stores are the youngest operations in the queue (loads and stores retire in one common order): the next stage
+        // waits for everything but them and the slab pieces of the last stage
+        young = (young > 0 ? young : 0) + ns;
         if (t_next >= total_tiles) break;
         t = t_next;
     }
@@ -327,7 +360,8 @@ int launch_bfd(ConvArgs a, hipStream_t st) {
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + TH - 1) / TH;
     constexpr size_t A_BYTES = (size_t)(((TH + 2) * (TW + 2) * 4 + 63) / 64) * 1024, B_BYTES = (size_t)3 * BN * 64;
-    const size_t lds_bytes = 2 * A_BYTES + 3 * B_BYTES;
+    if (a.Nout > 1024) return ELD_ENOTSUP;
+    const size_t lds_bytes = 2 * A_BYTES + 3 * B_BYTES + 4096;      // + bias (up to 1024 floats)
     const long long tiles = (long long)a.tiles_x * a.tiles_y * a.N * (a.Nout / BN);
     if (tiles <= 0) return 0;
     if (tiles > 0x7fffffffLL) return ELD_ENOTSUP;
@@ -349,6 +383,7 @@ int launch_bfd(ConvArgs a, hipStream_t st) {
 // spread the work over more CUs).
 int bfd_slab_bn(int Nout, int K, int N, int H, int W) {
     if (bfs_takes(Nout, K, N, H, W)) return 32;      // conv_bfs.hip: the same slab layout at BN = 32
+    if (debug_kernel_mask(-1) & 4) return 0;         // test hook: everything else back on conv_igemm_kernel<bf16>
     if (K % 32 || Nout % 64) return 0;
     const long long px_tiles = (long long)((W + TW - 1) / TW) * ((H + 15) / 16) * N;
     const int cus = eld_num_cus();
