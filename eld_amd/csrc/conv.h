@@ -124,6 +124,23 @@ __device__ __forceinline__ void bf16_line_unswap(uint4 s0, uint4 s1, uint2 (&pk)
     r = __builtin_amdgcn_permlane32_swap(s1.y, s1.w, false, false); pk[2].y = r[0]; pk[3].y = r[1];
 }
 
+// s_waitcnt vmcnt(n) for a wave-uniform RUNTIME n: "at most n of this wave's vector-memory operations outstanding".  The LDS-DMA kernels count
+// what may stay in flight behind the operation they need -- the DMA pieces of later stages AND the store instructions their epilogues issued
+// (loads and stores retire in one common order, so the stores issued after a piece are simply younger entries of the same queue).  Any value
+// below the true count only waits longer; counts beyond the table fall back to 0.
+template <int N>
+__device__ __forceinline__ void eld_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void eld_wait_vmcnt_dyn(int n) {
+    switch (n) {
+#define ELD_W(k) case k: eld_wait_vmcnt<k>(); break;
+        ELD_W(1) ELD_W(2) ELD_W(3) ELD_W(4) ELD_W(5) ELD_W(6) ELD_W(7) ELD_W(8) ELD_W(9) ELD_W(10) ELD_W(11) ELD_W(12) ELD_W(13) ELD_W(14) ELD_W(15) ELD_W(16)
+        ELD_W(17) ELD_W(18) ELD_W(19) ELD_W(20) ELD_W(21) ELD_W(22) ELD_W(23) ELD_W(24) ELD_W(25) ELD_W(26) ELD_W(27) ELD_W(28) ELD_W(29) ELD_W(30) ELD_W(31) ELD_W(32)
+        ELD_W(33) ELD_W(34) ELD_W(35) ELD_W(36) ELD_W(37) ELD_W(38) ELD_W(39) ELD_W(40) ELD_W(41) ELD_W(42) ELD_W(43) ELD_W(44) ELD_W(45) ELD_W(46) ELD_W(47) ELD_W(48)
+#undef ELD_W
+        default: eld_wait_vmcnt<0>(); break;
+    }
+}
+
 int launch_conv(const ConvArgs& a, int mode, hipStream_t st);
 // fp32 3x3 convolutions: 0 = exact-fp32 MFMA (conv_igemm.hip), 1 = three-piece bf16 split on the bf16 MFMA (conv_x3.hip).
 // set < 0 only queries.  Initial value from env ELD_FP32_CONV (mfma | x3).  Returns the value in force before the call.

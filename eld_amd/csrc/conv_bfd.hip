@@ -43,19 +43,6 @@ __device__ __forceinline__ void bfd_dma16(i32x4 rsrc, unsigned voff, unsigned so
 template <int N>
 __device__ __forceinline__ void bfd_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// the same for a wave-uniform RUNTIME count (the stage behind an epilogue: DMA pieces + the store instructions the epilogue issued); any
-// value below the true count would only wait longer, so counts beyond the table fall back to 0
-__device__ __forceinline__ void bfd_wait_vm_dyn(int n) {
-    switch (n) {
-#define BFD_W(k) case k: bfd_wait_vm<k>(); break;
-        BFD_W(1) BFD_W(2) BFD_W(3) BFD_W(4) BFD_W(5) BFD_W(6) BFD_W(7) BFD_W(8) BFD_W(9) BFD_W(10) BFD_W(11) BFD_W(12) BFD_W(13) BFD_W(14) BFD_W(15) BFD_W(16)
-        BFD_W(17) BFD_W(18) BFD_W(19) BFD_W(20) BFD_W(21) BFD_W(22) BFD_W(23) BFD_W(24) BFD_W(25) BFD_W(26) BFD_W(27) BFD_W(28) BFD_W(29) BFD_W(30) BFD_W(31) BFD_W(32)
-        BFD_W(33) BFD_W(34) BFD_W(35) BFD_W(36) BFD_W(37) BFD_W(38) BFD_W(39) BFD_W(40)
-#undef BFD_W
-        default: bfd_wait_vm<0>(); break;
-    }
-}
-
 __device__ __forceinline__ float hmax1b(float f) {       // max with lane ^ 1 (horizontal neighbour pixel): quad_perm [1,0,3,2]
     return fmaxf(f, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(f), 0xB1, 0xF, 0xF, true)));
 }
@@ -201,7 +188,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
                 // this wave's pieces of THIS stage's operands have landed (the younger ones, for later stages, may still fly)
                 if (young == B_IT) bfd_wait_vm<B_IT>();
                 else if (young == B_IT + A_IT) bfd_wait_vm<B_IT + A_IT>();
-                else bfd_wait_vm_dyn(young);
+                else eld_wait_vmcnt_dyn(young);
                 __syncthreads();                 // ... and everybody else's; the previous stage's fragment reads are done
                 int issued = 0;
                 int b2 = bufB + 2; if (b2 >= NBB) b2 -= NBB;
@@ -238,9 +225,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
         // ---- epilogue.  The MFMA leaves lane (m, hi) with channels 8q + 4hi .. +3 of pixel x0 + m in every 32-channel block; stores (and the
         //      loads of the saved activations) use the full-line layout of conv.h bf16_line_swap: per block, instruction i of a wave covers the
         //      64 bytes of pixels x0 + 16 i .. + 15, lane l holding pixel (l & 15) + 16 i, channel group bf16_line_group(l).
-        //      ns counts the store instructions this wave really issues (a store whose lanes are all out of range is branched over), so that
-        //      the next stage can leave exactly them -- and the last stage's slab pieces -- in flight -------------------------------------
-        int ns = 0;
+        //      -------------------------------------------------------------------------------------------------------------------------
         {
             const int lp = lane & 15, lg = bf16_line_group(lane);
             const int halves = (x0 + 16 < a.W) ? 2 : 1;                   // x0 < W for every tile
@@ -301,15 +286,9 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
                         if (halves == 2 && x0 + lp + 16 < a.W) *reinterpret_cast<uint4*>(drow + (size_t)(lp + 16) * C) = s1;
                     }
                 }
-                if (yok) ns += NT * halves;
             }
             // fused nn.MaxPool2d(2) (Unet.py:51-63): vertical pair in the lane's own rows, horizontal pair in lane ^ 1; pooled from the
             // bf16-ROUNDED values (max commutes with the monotone rounding, so this equals pooling the stored tensor)
-            if (a.epi == EPI_FWD && a.pool_out != nullptr) {            // (wave-uniform) two 16-byte stores per block and valid row pair, from the even pixels
-#pragma unroll
-                for (int rp = 0; rp < RPW / 2; ++rp)
-                    if (y0 + wave * RPW + 2 * rp < a.H) ns += 2 * NT;
-            }
             if (a.epi == EPI_FWD && a.pool_out != nullptr && xok) {
                 const int Hp = a.H >> 1, Wp = a.W >> 1;
 #pragma unroll
@@ -346,9 +325,11 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
                 }
             }
         }
-        // the epilogue's stores are the youngest operations in the queue (loads and stores retire in one common order): the next stage
-        // waits for everything but them and the slab pieces of the last stage
-        young = (young > 0 ? young : 0) + ns;
+        // The next stage waits with the same count as if there had been no epilogue ("at most `young` operations outstanding").  The epilogue's
+        // stores are the youngest entries of the queue, so this also waits for all but the last few of them -- measured (same-box A/B,
+        // profiles/r03_ab_notes.md) that is no slower than counting the stores exactly and letting them fly, it needs no assumption about loads
+        // and stores retiring in one common order, and unlike the old full drain (vmcnt(0)) it never waits for the youngest slab pieces.
+        young = young > 0 ? young : 0;
         if (t_next >= total_tiles) break;
         t = t_next;
     }
