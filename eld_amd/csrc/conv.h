@@ -165,6 +165,10 @@ int launch_conv_bfd(const ConvArgs& a, hipStream_t st);      // transposed-conv 
 int debug_kernel_mask(int set);      // eld_debug_kernel_mask: set < 0 only queries
 bool bfs_takes(int Nout, int K, int N, int H, int W);
 int launch_conv_bfs(const ConvArgs& a, hipStream_t st);
+// bf16 transposed convolutions (conv_bfg.hip: both operands by LDS-DMA): column-block width of the packed slabs (bfg_store), 0 = stays on conv_igemm_kernel
+int bfg_slab_bn(bool gather, int Nout, int Cs, int Cout_t, int N, int H, int W);
+__host__ __device__ inline size_t bfg_slab_bytes(int BN) { return (size_t)BN * 64; }
+int launch_conv_bfg(const ConvArgs& a, int mode, hipStream_t st);
 
 // dW-type reduction:  P[tap][i][j] = sum_pixels G[pixel][i] * X[pixel (+) tap][j]
 struct WgradArgs {

@@ -442,6 +442,7 @@ int launch_conv(const ConvArgs& a_in, int mode, hipStream_t st) {
     if (a.epi == EPI_CONVT_FWD && (a.Cout_t % 4)) return ELD_EINVAL;
     if (a.dtype == DT_BF16) {
         if (mode == CONV_3X3 && a.epi != EPI_CONVT_FWD && bfd_slab_bn(a.Nout, Cin, a.N, a.H, a.W)) return launch_conv_bfd(a, st);      // weights in slab layout
+        if (mode != CONV_3X3 && !a.pool_out && bfg_slab_bn(mode == CONV_GATHER2X2, a.Nout, a.C0, a.Cout_t, a.N, a.H, a.W)) return launch_conv_bfg(a, mode, st);      // weights in bfg slab layout
         return a.pool_out ? ELD_ENOTSUP : launch_dt<bf16_t>(a, mode, st);
     }
     const int algo = resolve_algo(a.algo);

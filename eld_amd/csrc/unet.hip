@@ -291,6 +291,10 @@ int pack_weights(const Plan& P, const float* params, float* ws, bool for_backwar
         J.x3bn = (!bf16 && g_algo == 1 && d.kind == 0) ? x3_slab_bn(for_backward ? d.cin : d.cout, P.N, P.Hl[lev], P.Wl[lev]) : 0;
         // bf16: 3x3 layers the DMA kernel takes get its slab layout (GEMM N = Cout forward / Cin backward-data, K the other one)
         J.bfdbn = (bf16 && d.kind == 0) ? (for_backward ? bfd_slab_bn(d.cin, d.cout, P.N, P.Hl[lev], P.Wl[lev]) : bfd_slab_bn(d.cout, J.Cinp, P.N, P.Hl[lev], P.Wl[lev])) : 0;
+        // bf16 transposed convs on conv_bfg_kernel take its slab layout (forward: GEMM N = 4 Cout, K = Cin on the input-resolution domain of level lev+1;
+        // backward-data: N = Cin, K = 4 Cout)
+        J.bfgbn = (bf16 && d.kind == 1) ? (for_backward ? bfg_slab_bn(true, d.cin, d.cout, 0, P.N, P.Hl[lev + 1], P.Wl[lev + 1])
+                                                        : bfg_slab_bn(false, 4 * d.cout, d.cin, d.cout, P.N, P.Hl[lev + 1], P.Wl[lev + 1])) : 0;
         jobs.job[jobs.n++] = J;
     }
     return launch_pack_all(jobs, params, ws, st, amax);

@@ -369,6 +369,15 @@ __device__ __forceinline__ void bfd_store(float* dst, int t, int n, int c, int N
     reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(dst) + slab * bfd_slab_bytes(BN))[slot * 8 + (c & 7)] = f2bf(v);
 }
 
+// Slab layout of conv_bfg_kernel (conv_bfg.hip): element (GEMM column n of N, k index c of K) of the logical packed weight B[n][c] as bf16 at
+//   slab(c/32, n/BN) + slot * 16 B + (c%8) * 2 B,   slot = 4 n' + (octet ^ ((n' >> 2) & 3)),  n' = n % BN, octet = (c%32)/8
+__device__ __forceinline__ void bfg_store(float* dst, int n, int c, int N, int K, int BN, float v) {
+    const int NB = N / BN, np = n % BN;
+    const size_t slab = (size_t)(c >> 5) * NB + n / BN;
+    const int slot = 4 * np + (((c & 31) >> 3) ^ ((np >> 2) & 3));
+    reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(dst) + slab * bfg_slab_bytes(BN))[slot * 8 + (c & 7)] = f2bf(v);
+}
+
 __global__ void pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int kind, int Cout, int Cin, int Cinp, int T, int x3bn) {
     size_t total;
     if (kind == PACK_CONV_FWD) total = (size_t)T * Cout * Cinp; else total = (size_t)T * Cout * Cin;
@@ -448,6 +457,8 @@ __global__ void pack_all_kernel(const PackJobs jobs, const float* __restrict__ p
     if (live) {
         if (J.bf16 && J.bfdbn && J.kind == PACK_CONV_FWD) bfd_store(dst, (int)(i / ((size_t)Cinp * Cout)), (int)((i / Cinp) % Cout), (int)(i % Cinp), Cout, Cinp, J.bfdbn, v);
         else if (J.bf16 && J.bfdbn && J.kind == PACK_CONV_BWD) bfd_store(dst, (int)(i / ((size_t)Cout * Cin)), (int)((i / Cout) % Cin), (int)(i % Cout), Cin, Cout, J.bfdbn, v);
+        else if (J.bf16 && J.bfgbn && J.kind == PACK_CONVT_FWD) bfg_store(dst, (int)(i / Cin), (int)(i % Cin), T * Cout, Cin, J.bfgbn, v);          // n = tap*Cout + co, k = ci
+        else if (J.bf16 && J.bfgbn && J.kind == PACK_CONVT_BWD) bfg_store(dst, (int)((i / Cout) % Cin), (int)(i / ((size_t)Cout * Cin)) * Cout + (int)(i % Cout), Cin, T * Cout, J.bfgbn, v);      // n = ci, k = tap*Cout + co
         else if (J.bf16) reinterpret_cast<bf16_t*>(dst)[i] = f2bf(v);
         else if (J.x3bn && J.kind == PACK_CONV_FWD) x3_store(dst, (int)(i / ((size_t)Cinp * Cout)), (int)((i / Cinp) % Cout), (int)(i % Cinp), Cout, Cinp, J.x3bn, v);
         else if (J.x3bn && J.kind == PACK_CONV_BWD) x3_store(dst, (int)(i / ((size_t)Cout * Cin)), (int)((i / Cout) % Cin), (int)(i % Cout), Cin, Cout, J.x3bn, v);
