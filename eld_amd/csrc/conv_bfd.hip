@@ -108,6 +108,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
         }
     };
     auto dma_A = [&](int buf, int chunk) {
+        if (ELD_DBG(a) & 4) return;
         const char* src = static_cast<const char*>(chunk < NCH0 ? a.in0 : a.in1);
         const int cs = chunk < NCH0 ? chunk : chunk - NCH0;
         const size_t img_bytes = (size_t)a.H * a.W * Cs0 * 2;
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
         }
     };
     auto dma_B = [&](int buf, int nb, int chunk, int ky) {
+        if (ELD_DBG(a) & 8) return;
         const unsigned soff = (unsigned)(((ky * NCH + chunk) * NB + nb) * B_BYTES);
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
@@ -201,6 +203,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
                 __builtin_amdgcn_s_setprio(0);
                 const char* la = ldsA + bufA * A_BYTES + (wave * RPW + ky) * (HW2 * 64);
                 const char* lb = ldsB + bufB * B_BYTES;
+                if (!(ELD_DBG(a) & 2))
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
         //      loads of the saved activations) use the full-line layout of conv.h bf16_line_swap: per block, instruction i of a wave covers the
         //      64 bytes of pixels x0 + 16 i .. + 15, lane l holding pixel (l & 15) + 16 i, channel group bf16_line_group(l).
         //      -------------------------------------------------------------------------------------------------------------------------
-        {
+        if (!(ELD_DBG(a) & 1)) {
             const int lp = lane & 15, lg = bf16_line_group(lane);
             const int halves = (x0 + 16 < a.W) ? 2 : 1;                   // x0 < W for every tile
             const int x = x0 + m;

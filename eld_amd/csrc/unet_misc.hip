@@ -170,8 +170,9 @@ __device__ __forceinline__ float quad_bcast(float v, int src) {
     }
 }
 
-__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ act, const float* __restrict__ w,
-                                                       float* __restrict__ g, float* __restrict__ part, int N, size_t HW, int OC) {
+template <typename T>       // T = float or bf16_t: element type of the saved activation and of the gradient written (math in fp32 either way)
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dout, const T* __restrict__ act, const float* __restrict__ w,
+                                                       T* __restrict__ g, float* __restrict__ part, int N, size_t HW, int OC) {
     __shared__ float red[4][132];
     const int tid = threadIdx.x, cq = tid & 7, o_ld = tid & 3;
     float wq[4][4];                                   // w[o][4cq + j]
@@ -200,7 +201,9 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
 #pragma unroll
         for (int o = 0; o < 4; ++o) d[o] = quad_bcast(dl, o);
         if (!ok) continue;
-        const float4 a = reinterpret_cast<const float4*>(act + pc * 32)[cq];
+        float4 a;
+        if constexpr (sizeof(T) == 4) a = reinterpret_cast<const float4*>(act + pc * 32)[cq];
+        else a = unpack_bf4(reinterpret_cast<const uint2*>(act + pc * 32)[cq]);
         const float av[4] = {a.x, a.y, a.z, a.w};
         float gv[4];
 #pragma unroll
@@ -210,7 +213,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
             for (int o = 0; o < 4; ++o) { s = fmaf(wq[o][j], d[o], s); dw[o][j] = fmaf(d[o], av[j], dw[o][j]); }
             gv[j] = s * lrelu_slope(av[j]);
         }
-        reinterpret_cast<float4*>(g + pc * 32)[cq] = make_float4(gv[0], gv[1], gv[2], gv[3]);
+        if constexpr (sizeof(T) == 4) reinterpret_cast<float4*>(g + pc * 32)[cq] = make_float4(gv[0], gv[1], gv[2], gv[3]);
+        else reinterpret_cast<uint2*>(g + pc * 32)[cq] = pack_bf4(make_float4(gv[0], gv[1], gv[2], gv[3]));
     }
     // block reduction in a fixed order: lanes sharing a channel quad (cq, cq+8, ...) by xor-shuffles, then the 4 waves through LDS
     const int lane = tid & 63, wave = tid >> 6;
@@ -252,7 +256,7 @@ int launch_head_bwd(const float* dout, const float* act, const float* w, float* 
     const size_t total = (size_t)N * H * W;
     if (!total) return 0;
     const int nb = (int)min((total + 31) / 32, (size_t)HEAD_BLOCKS);
-    ELD_LAUNCH(head_bwd_kernel, dim3(nb), dim3(256), 0, st, dout, act, w, g, part, N, (size_t)H * W, OC);
+    ELD_LAUNCH(head_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, dout, act, w, g, part, N, (size_t)H * W, OC);
     ELD_LAUNCH_CHECK();
     ELD_LAUNCH(head_bwd_reduce_kernel, dim3((132 + 15) / 16), dim3(256), 0, st, part, dw, db, nb, OC);
     ELD_LAUNCH_CHECK();
@@ -694,66 +698,13 @@ int launch_maxpool_bwd_bf16(const bf16_t* act, const bf16_t* dp, const bf16_t* s
     return 0;
 }
 
-__global__ __launch_bounds__(256) void head_bwd_bf16_kernel(const float* __restrict__ dout, const bf16_t* __restrict__ act, const float* __restrict__ w,
-                                                            bf16_t* __restrict__ g, float* __restrict__ part, int N, size_t HW, int OC) {
-    __shared__ float sw[128];
-    __shared__ float red[4][132];
-    for (int i = threadIdx.x; i < 128; i += 256) sw[i] = (i / 32 < OC) ? w[i] : 0.f;
-    __syncthreads();
-    float dw[4][32];
-    float db[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int o = 0; o < 4; ++o)
-#pragma unroll
-        for (int c = 0; c < 32; ++c) dw[o][c] = 0.f;
-    const size_t total = (size_t)N * HW;
-    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
-        const size_t n = p / HW, q = p - n * HW;
-        float d[4];
-#pragma unroll
-        for (int o = 0; o < 4; ++o) { d[o] = o < OC ? dout[(n * OC + o) * HW + q] : 0.f; db[o] += d[o]; }
-        const uint2* A = reinterpret_cast<const uint2*>(act + p * 32);
-        uint2* G = reinterpret_cast<uint2*>(g + p * 32);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float4 a = unpack_bf4(A[k]);
-            const float av[4] = {a.x, a.y, a.z, a.w};
-            float gv[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = 4 * k + j;
-                float s = 0.f;
-#pragma unroll
-                for (int o = 0; o < 4; ++o) { s = fmaf(sw[o * 32 + c], d[o], s); dw[o][c] = fmaf(d[o], av[j], dw[o][c]); }
-                gv[j] = s * lrelu_slope(av[j]);
-            }
-            G[k] = pack_bf4(make_float4(gv[0], gv[1], gv[2], gv[3]));
-        }
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {
-#pragma unroll
-        for (int c = 0; c < 32; ++c) {
-            float v = dw[o][c];
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if (lane == 0) red[wave][o * 32 + c] = v;
-        }
-        float v = db[o];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0) red[wave][128 + o] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < 132)
-        part[(size_t)blockIdx.x * 132 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-}
-
+// (the bf16 head backward is head_bwd_kernel<bf16_t>: eight lanes per pixel, 8 bytes each -- a wave reads / writes 8 whole pixels = 512 contiguous bytes per instruction)
 int launch_head_bwd_bf16(const float* dout, const bf16_t* act, const float* w, bf16_t* g, float* dw, float* db, float* part,
                          int N, int H, int W, int OC, hipStream_t st) {
     const size_t total = (size_t)N * H * W;
     if (!total) return 0;
-    const int nb = (int)min((total + 255) / 256, (size_t)HEAD_BLOCKS);
-    ELD_LAUNCH(head_bwd_bf16_kernel, dim3(nb), dim3(256), 0, st, dout, act, w, g, part, N, (size_t)H * W, OC);
+    const int nb = (int)min((total + 31) / 32, (size_t)HEAD_BLOCKS);
+    ELD_LAUNCH(head_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, dout, act, w, g, part, N, (size_t)H * W, OC);
     ELD_LAUNCH_CHECK();
     ELD_LAUNCH(head_bwd_reduce_kernel, dim3((132 + 15) / 16), dim3(256), 0, st, part, dw, db, nb, OC);
     ELD_LAUNCH_CHECK();
