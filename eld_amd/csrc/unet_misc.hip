@@ -698,13 +698,80 @@ int launch_maxpool_bwd_bf16(const bf16_t* act, const bf16_t* dp, const bf16_t* s
     return 0;
 }
 
-// (the bf16 head backward is head_bwd_kernel<bf16_t>: eight lanes per pixel, 8 bytes each -- a wave reads / writes 8 whole pixels = 512 contiguous bytes per instruction)
+// bf16 head backward: FOUR lanes per pixel, eight channels (16 bytes) each -- a wave reads / writes 16 whole pixels = 1 KiB contiguous per
+// instruction (head_bwd_kernel<float>'s eight-lane layout at 8 bytes per lane measured slower than one thread per pixel).  The pixel's four
+// output gradients are read once (lane o of the quad reads plane o) and handed round with quad-permute DPP moves; a lane keeps
+// dW[o][its 8 channels] (32 sums) and db[its plane].
+__global__ __launch_bounds__(256) void head_bwd_bf16_kernel(const float* __restrict__ dout, const bf16_t* __restrict__ act, const float* __restrict__ w,
+                                                            bf16_t* __restrict__ g, float* __restrict__ part, int N, size_t HW, int OC) {
+    __shared__ float red[4][132];
+    const int tid = threadIdx.x, cq = tid & 3;
+    float wq[4][8];                                   // w[o][8cq + j]
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wq[o][j] = o < OC ? w[o * 32 + 8 * cq + j] : 0.f;
+    float dw[4][8];
+    float db = 0.f;                                   // lane cq sums plane cq
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dw[o][j] = 0.f;
+    const size_t total = (size_t)N * HW;
+    const size_t stride = (size_t)gridDim.x * 64;
+    size_t p = (size_t)blockIdx.x * 64 + (tid >> 2);
+    const size_t iters = (total + stride - 1) / stride;               // every lane of a quad runs the same trip count (DPP needs its quad mates)
+    for (size_t itn = 0; itn < iters; ++itn, p += stride) {
+        const bool ok = p < total;
+        const size_t pc = ok ? p : total - 1;
+        const size_t n = pc / HW, q = pc - n * HW;
+        float dl = 0.f;
+        if (ok && cq < OC) dl = dout[(n * OC + cq) * HW + q];
+        db += dl;
+        float d[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) d[o] = quad_bcast(dl, o);
+        if (!ok) continue;
+        const uint4 av4 = reinterpret_cast<const uint4*>(act + pc * 32)[cq];
+        const float4 alo = unpack_bf4(make_uint2(av4.x, av4.y)), ahi = unpack_bf4(make_uint2(av4.z, av4.w));
+        const float av[8] = {alo.x, alo.y, alo.z, alo.w, ahi.x, ahi.y, ahi.z, ahi.w};
+        float gv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) { sacc = fmaf(wq[o][j], d[o], sacc); dw[o][j] = fmaf(d[o], av[j], dw[o][j]); }
+            gv[j] = sacc * lrelu_slope(av[j]);
+        }
+        const uint2 g0 = pack_bf4(make_float4(gv[0], gv[1], gv[2], gv[3])), g1 = pack_bf4(make_float4(gv[4], gv[5], gv[6], gv[7]));
+        reinterpret_cast<uint4*>(g + pc * 32)[cq] = make_uint4(g0.x, g0.y, g1.x, g1.y);
+    }
+    // block reduction in a fixed order: lanes sharing a channel octet (cq, cq+4, ...) by xor-shuffles, then the 4 waves through LDS
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = dw[o][j];
+            for (int off = 4; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+            if (lane < 4) red[wave][o * 32 + 8 * lane + j] = v;
+        }
+    {
+        float v = db;
+        for (int off = 4; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+        if (lane < 4) red[wave][128 + lane] = v;
+    }
+    __syncthreads();
+    if (tid < 132)
+        part[(size_t)blockIdx.x * 132 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
 int launch_head_bwd_bf16(const float* dout, const bf16_t* act, const float* w, bf16_t* g, float* dw, float* db, float* part,
                          int N, int H, int W, int OC, hipStream_t st) {
     const size_t total = (size_t)N * H * W;
     if (!total) return 0;
-    const int nb = (int)min((total + 31) / 32, (size_t)HEAD_BLOCKS);
-    ELD_LAUNCH(head_bwd_kernel<bf16_t>, dim3(nb), dim3(256), 0, st, dout, act, w, g, part, N, (size_t)H * W, OC);
+    const int nb = (int)min((total + 63) / 64, (size_t)HEAD_BLOCKS);
+    ELD_LAUNCH(head_bwd_bf16_kernel, dim3(nb), dim3(256), 0, st, dout, act, w, g, part, N, (size_t)H * W, OC);
     ELD_LAUNCH_CHECK();
     ELD_LAUNCH(head_bwd_reduce_kernel, dim3((132 + 15) / 16), dim3(256), 0, st, part, dw, db, nb, OC);
     ELD_LAUNCH_CHECK();

@@ -3,7 +3,9 @@
 profiles/traffic.json, which bench.py reports as roofline.traffic.
   bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024   -- FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE counts half of a
   wide (16 B/lane) coalesced read stream (MI355X_MICROARCH.md, HBM section), every read in these kernels is 16 B/lane.
-Usage: traffic_from_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [frames per pass = bench.py --batch, default 8]"""
+Usage: traffic_from_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [frames per pass = bench.py --batch, default 8] [bf16]
+With a fifth argument `bf16` the passes are those of `bench.py --precision bf16`: the kernels and the per-pass total are MERGED into an existing
+<out.json> under `kernels_bf16` / `unet_conv_bytes_per_pass_bf16` (bench.py reports it as alt_bf16.roofline.traffic)."""
 import collections
 import csv
 import json
@@ -46,6 +48,21 @@ def main():
         out['unet_passes'] = passes
         out['frames_per_pass'] = int(sys.argv[4]) if len(sys.argv) > 4 else 8
         out['unet_conv_bytes_per_pass'] = sum(2.0 * f[k] * 1024.0 + w.get(k, 0.0) * 1024.0 for k in conv) / passes
+    if len(sys.argv) > 5 and sys.argv[5] == 'bf16':
+        passes = sum(fc[k] for k in f if k.startswith('head_fwd_bf16_kernel'))
+        conv = [k for k in f if any(s_ in k for s_ in ('conv_igemm_kernel', 'conv_bf', 'wgrad8_kernel', 'wgrad_kernel', 'conv_first', 'wgrad_reduce'))]
+        try:
+            base = json.load(open(sys.argv[3]))
+        except Exception:
+            base = {}
+        base['kernels_bf16'] = out['kernels']
+        base['source_bf16'] = out['source'].replace('--no-cpu-baseline', '--precision bf16 --no-cpu-baseline')
+        if passes and conv:
+            base['unet_passes_bf16'] = passes
+            base['unet_conv_bytes_per_pass_bf16'] = sum(2.0 * f[k] * 1024.0 + w.get(k, 0.0) * 1024.0 for k in conv) / passes
+        json.dump(base, open(sys.argv[3], 'w'), indent=1)
+        print(json.dumps({k: v for k, v in base.items() if not k.startswith('kernels')}, indent=1))
+        return
     json.dump(out, open(sys.argv[3], 'w'), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != 'kernels'}, indent=1))
 
