@@ -141,6 +141,34 @@ __device__ __forceinline__ void eld_wait_vmcnt_dyn(int n) {
     }
 }
 
+// fp32 counterpart of the full-line store.  Lane (m, hi) holds, for q = 0..3, channels 8q + 4hi .. +3 of pixel m of a 32-channel block: float4 v[q] is the
+// 16-byte piece 2q + hi of the pixel's 128-byte record.  One v_permlane16_swap per dword re-deals (v[0], v[1]) and (v[2], v[3]) so that a store instruction of
+// the wave covers 16 consecutive pixels x 64 contiguous bytes (whole 64-byte sectors) instead of 16 bytes of each of 64 half-pixels: afterwards
+//   v[0] / v[2] = pieces {0,2,1,3}[lane >> 4] (+ 4 for v[2]) of pixel  lane & 15,       v[1] / v[3] = the same pieces of pixel (lane & 15) + 16.
+// f32_line_store does the exchange (EVERY lane must take part) and the predicated stores.  blk = address of channel 0 of the block at the row's pixel
+// x0; pstride = elements between consecutive pixels of the row in the destination; valid_px = number of in-range pixels of the row from x0 on.
+__device__ __forceinline__ void f32_rows_swap(float4& a, float4& b) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.x), __float_as_uint(b.x), false, false); a.x = __uint_as_float(r[0]); b.x = __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.y), __float_as_uint(b.y), false, false); a.y = __uint_as_float(r[0]); b.y = __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.z), __float_as_uint(b.z), false, false); a.z = __uint_as_float(r[0]); b.z = __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.w), __float_as_uint(b.w), false, false); a.w = __uint_as_float(r[0]); b.w = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void f32_line_store(float4 (&v)[4], float* blk, size_t pstride, int lane, bool row_ok, int valid_px) {
+    f32_rows_swap(v[0], v[1]);
+    f32_rows_swap(v[2], v[3]);
+    const int lp = lane & 15;
+    float* p0 = blk + (size_t)lp * pstride + 4 * bf16_line_group(lane);      // same row -> piece map {0,2,1,3}
+    if (row_ok && lp < valid_px) {
+        *reinterpret_cast<float4*>(p0) = v[0];
+        *reinterpret_cast<float4*>(p0 + 16) = v[2];
+    }
+    if (row_ok && lp + 16 < valid_px) {
+        float* p1 = p0 + 16 * pstride;
+        *reinterpret_cast<float4*>(p1) = v[1];
+        *reinterpret_cast<float4*>(p1 + 16) = v[3];
+    }
+}
+
 int launch_conv(const ConvArgs& a, int mode, hipStream_t st);
 // fp32 3x3 convolutions: 0 = exact-fp32 MFMA (conv_igemm.hip), 1 = three-piece bf16 split on the bf16 MFMA (conv_x3.hip).
 // set < 0 only queries.  Initial value from env ELD_FP32_CONV (mfma | x3).  Returns the value in force before the call.

@@ -289,20 +289,24 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
 
         // ---- epilogue: identical to conv_igemm.hip's (lane (m, hi) owns pixel x0+m and channels 8q+4hi..+3 of each 32-block)
         {
+            // stores in the full-line layout (conv.h f32_line_store: 16 pixels x 64 contiguous bytes per instruction); bias / saved activations are
+            // read in the MFMA layout (own pixel m); every lane computes and takes part in the exchange, only loads and stores are predicated
             const int x = x0 + m;
             const bool xok = x < a.W;
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
-                const int y = y0 + wave * RPW + r;
-                if (y >= a.H || !xok) continue;
-                const size_t pix = (size_t)(img * a.H + y) * a.W + x;
+                const int y = y0 + wave * RPW + r;                      // wave-uniform
+                const bool yok = y < a.H;
+                const size_t rowpix = (size_t)(img * a.H + (yok ? y : 0)) * a.W;
+                const size_t pix = rowpix + (xok ? x : 0);
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) {
-                    const int nbase = nb * BN + tt * 32 + 4 * hi;
+                    const int nb32 = nb * BN + tt * 32, nbase = nb32 + 4 * hi;
                     float4 v[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = make_float4(acc[r][tt][4 * q], acc[r][tt][4 * q + 1], acc[r][tt][4 * q + 2], acc[r][tt][4 * q + 3]);
-                    float* dst[4];
+                    float* blk;
+                    int C;
                     if (a.epi == EPI_FWD) {
                         float4 bs[4];
 #pragma unroll
@@ -314,34 +318,27 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
                                 v[q].x = fmaxf(0.2f * v[q].x, v[q].x); v[q].y = fmaxf(0.2f * v[q].y, v[q].y);
                                 v[q].z = fmaxf(0.2f * v[q].z, v[q].z); v[q].w = fmaxf(0.2f * v[q].w, v[q].w);
                             }
-                            dst[q] = static_cast<float*>(a.out0) + pix * a.Nout + nbase + 8 * q;
                         }
-                    } else {
-                        float4 s[4];
-                        bool has[4];
+                        C = a.Nout;
+                        blk = static_cast<float*>(a.out0) + (rowpix + x0) * C + nb32;
+                    } else {                                            // a 32-channel block never straddles the concat split
+                        const bool lo = nb32 < a.split;
+                        C = lo ? a.split : a.Nout - a.split;
+                        const int cb = lo ? nb32 : nb32 - a.split;
+                        blk = static_cast<float*>(lo ? a.out0 : a.out1) + (rowpix + x0) * C + cb;
+                        const float* act = static_cast<const float*>(lo ? a.act0 : a.act1);
+                        if (act != nullptr) {
+                            float4 s[4];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int n = nbase + 8 * q;
-                            const bool lo = n < a.split;
-                            const int C = lo ? a.split : a.Nout - a.split;
-                            const size_t idx = pix * C + (lo ? n : n - a.split);
-                            dst[q] = static_cast<float*>(lo ? a.out0 : a.out1) + idx;
-                            const float* act = static_cast<const float*>(lo ? a.act0 : a.act1);
-                            has[q] = act != nullptr;
-                            s[q] = make_float4(1.f, 1.f, 1.f, 1.f);
-                            if (has[q]) s[q] = *reinterpret_cast<const float4*>(act + idx);
-                        }
+                            for (int q = 0; q < 4; ++q) s[q] = *reinterpret_cast<const float4*>(act + pix * C + cb + 4 * hi + 8 * q);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if (has[q]) {
+                            for (int q = 0; q < 4; ++q) {
                                 v[q].x *= lrelu_slope(s[q].x); v[q].y *= lrelu_slope(s[q].y);
                                 v[q].z *= lrelu_slope(s[q].z); v[q].w *= lrelu_slope(s[q].w);
                             }
+                        }
                     }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(v[q].x), "+v"(v[q].y), "+v"(v[q].z), "+v"(v[q].w));
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(dst[q]) = v[q];
+                    f32_line_store(v, blk, (size_t)C, lane, yok, a.W - x0);
                 }
             }
         }
@@ -576,20 +573,24 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
                         *reinterpret_cast<float4*>(prow + tt * 32 + 8 * q) = make_float4(acc[r][tt][4 * q], acc[r][tt][4 * q + 1], acc[r][tt][4 * q + 2], acc[r][tt][4 * q + 3]);
             }
         } else {
+            // stores in the full-line layout (conv.h f32_line_store: 16 pixels x 64 contiguous bytes per instruction); bias / saved activations are
+            // read in the MFMA layout (own pixel m); every lane computes and takes part in the exchange, only loads and stores are predicated
             const int x = x0 + m;
             const bool xok = x < a.W;
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
-                const int y = y0 + wave * RPW + r;
-                if (y >= a.H || !xok) continue;
-                const size_t pix = (size_t)(img * a.H + y) * a.W + x;
+                const int y = y0 + wave * RPW + r;                      // wave-uniform
+                const bool yok = y < a.H;
+                const size_t rowpix = (size_t)(img * a.H + (yok ? y : 0)) * a.W;
+                const size_t pix = rowpix + (xok ? x : 0);
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) {
-                    const int nbase = nb * BN + tt * 32 + 4 * hi;
+                    const int nb32 = nb * BN + tt * 32, nbase = nb32 + 4 * hi;
                     float4 v[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = make_float4(acc[r][tt][4 * q], acc[r][tt][4 * q + 1], acc[r][tt][4 * q + 2], acc[r][tt][4 * q + 3]);
-                    float* dst[4];
+                    float* blk;
+                    int C;
                     if (a.epi == EPI_FWD) {
                         float4 bs[4];
 #pragma unroll
@@ -601,34 +602,27 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
                                 v[q].x = fmaxf(0.2f * v[q].x, v[q].x); v[q].y = fmaxf(0.2f * v[q].y, v[q].y);
                                 v[q].z = fmaxf(0.2f * v[q].z, v[q].z); v[q].w = fmaxf(0.2f * v[q].w, v[q].w);
                             }
-                            dst[q] = static_cast<float*>(a.out0) + pix * a.Nout + nbase + 8 * q;
                         }
-                    } else {
-                        float4 s[4];
-                        bool has[4];
+                        C = a.Nout;
+                        blk = static_cast<float*>(a.out0) + (rowpix + x0) * C + nb32;
+                    } else {                                            // a 32-channel block never straddles the concat split
+                        const bool lo = nb32 < a.split;
+                        C = lo ? a.split : a.Nout - a.split;
+                        const int cb = lo ? nb32 : nb32 - a.split;
+                        blk = static_cast<float*>(lo ? a.out0 : a.out1) + (rowpix + x0) * C + cb;
+                        const float* act = static_cast<const float*>(lo ? a.act0 : a.act1);
+                        if (act != nullptr) {
+                            float4 s[4];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int n = nbase + 8 * q;
-                            const bool lo = n < a.split;
-                            const int C = lo ? a.split : a.Nout - a.split;
-                            const size_t idx = pix * C + (lo ? n : n - a.split);
-                            dst[q] = static_cast<float*>(lo ? a.out0 : a.out1) + idx;
-                            const float* act = static_cast<const float*>(lo ? a.act0 : a.act1);
-                            has[q] = act != nullptr;
-                            s[q] = make_float4(1.f, 1.f, 1.f, 1.f);
-                            if (has[q]) s[q] = *reinterpret_cast<const float4*>(act + idx);
-                        }
+                            for (int q = 0; q < 4; ++q) s[q] = *reinterpret_cast<const float4*>(act + pix * C + cb + 4 * hi + 8 * q);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if (has[q]) {
+                            for (int q = 0; q < 4; ++q) {
                                 v[q].x *= lrelu_slope(s[q].x); v[q].y *= lrelu_slope(s[q].y);
                                 v[q].z *= lrelu_slope(s[q].z); v[q].w *= lrelu_slope(s[q].w);
                             }
+                        }
                     }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(v[q].x), "+v"(v[q].y), "+v"(v[q].z), "+v"(v[q].w));
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(dst[q]) = v[q];
+                    f32_line_store(v, blk, (size_t)C, lane, yok, a.W - x0);
                 }
             }
         }
@@ -777,42 +771,40 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv_x3_gemm_k
                 }
             }
         }
-        {   // epilogue: lane (m, hi) owns pixel x0+m and channels 8q+4hi..+3 of each 32-block (see conv_igemm.hip)
+        {   // epilogue: the MFMA leaves lane (m, hi) with channels 8q+4hi..+3 of pixel x0+m in each 32-block; stores in the full-line layout (conv.h f32_line_store)
             const int x = x0 + m;
+            const bool xok = x < a.W;
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
                 const int y = y0 + wave * RPW + r;
-                if (y >= a.H || x >= a.W) continue;
-                const size_t pix = (size_t)(img * a.H + y) * a.W + x;
+                const bool yok = y < a.H;
+                const int yc = yok ? y : 0;
+                const size_t pix = (size_t)(img * a.H + yc) * a.W + (xok ? x : 0);
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) {
-                    const int nbase = nb * BN + tt * 32 + 4 * hi;
+                    const int nb32 = nb * BN + tt * 32, nbase = nb32 + 4 * hi;
                     float4 v[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = make_float4(acc[r][tt][4 * q], acc[r][tt][4 * q + 1], acc[r][tt][4 * q + 2], acc[r][tt][4 * q + 3]);
-                    float* dst[4];
-                    if (MODE == CONV_1X1) {
-                        float4 bs[4];
+                    float* blk;
+                    size_t pstride;
+                    if (MODE == CONV_1X1) {                              // n = tap * Cout + co: a 32-block never straddles a tap (Cout % 32 == 0)
+                        const int tap = nb32 / a.Cout_t, co0 = nb32 - tap * a.Cout_t;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const int n = nbase + 8 * q;
-                            const int tap = n / a.Cout_t, co = n - tap * a.Cout_t;
-                            bs[q] = *reinterpret_cast<const float4*>(a.bias + co);
-                            dst[q] = static_cast<float*>(a.out0) + ((size_t)(img * 2 * a.H + 2 * y + (tap >> 1)) * (2 * a.W) + 2 * x + (tap & 1)) * a.Cout_t + co;
+                            const float4 bq = *reinterpret_cast<const float4*>(a.bias + co0 + 4 * hi + 8 * q);
+                            v[q].x += bq.x; v[q].y += bq.y; v[q].z += bq.z; v[q].w += bq.w;
                         }
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) { v[q].x += bs[q].x; v[q].y += bs[q].y; v[q].z += bs[q].z; v[q].w += bs[q].w; }
+                        blk = static_cast<float*>(a.out0) + ((size_t)(img * 2 * a.H + 2 * yc + (tap >> 1)) * (2 * a.W) + 2 * x0 + (tap & 1)) * a.Cout_t + co0;
+                        pstride = (size_t)2 * a.Cout_t;
                     } else {
-                        float4 sl[4];
+                        blk = static_cast<float*>(a.out0) + ((size_t)(img * a.H + yc) * a.W + x0) * a.Nout + nb32;
+                        pstride = (size_t)a.Nout;
                         const float* act = static_cast<const float*>(a.act0);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const size_t idx = pix * a.Nout + nbase + 8 * q;
-                            dst[q] = static_cast<float*>(a.out0) + idx;
-                            sl[q] = make_float4(1.f, 1.f, 1.f, 1.f);
-                            if (act) sl[q] = *reinterpret_cast<const float4*>(act + idx);
-                        }
                         if (act) {
+                            float4 sl[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) sl[q] = *reinterpret_cast<const float4*>(act + pix * a.Nout + nbase + 8 * q);
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 v[q].x *= lrelu_slope(sl[q].x); v[q].y *= lrelu_slope(sl[q].y);
@@ -820,10 +812,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv_x3_gemm_k
                             }
                         }
                     }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(v[q].x), "+v"(v[q].y), "+v"(v[q].z), "+v"(v[q].w));
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(dst[q]) = v[q];
+                    f32_line_store(v, blk, pstride, lane, yok, a.W - x0);
                 }
             }
         }
