@@ -241,6 +241,156 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(const TG* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// bf16-gradient variant (BASELINE configs[2]) on the bf16 MFMA: the fp32 MFMA above needs 64 cycles per 2 pixels and was the whole kernel
+// (1.3 ms: 223 GFLOP at the 157 TF/s fp32 rate); v_mfma_f32_32x32x16_bf16 covers 16 pixels in 32 cycles.
+//   A[i = co][k = pixel]  = g[pixel][co]          bf16 as stored; the tile's [256 pixels][32 co] image comes HBM -> LDS by LDS-DMA (double buffered)
+//                                                   and is read transposed by ds_read_b64_tr_b16 (as wgrad_kernel<bf16_t> does)
+//   B[k = pixel][j]       = patch value of tap-channel j at that pixel, as TWO bf16 pieces of the fp32 input (x = hi + lo to 2^-17: the raw input keeps
+//                           16 significant bits; the gradient operand is bf16 anyway): acc += g * x_hi, acc += g * x_lo
+// A lane's B operand is 8 horizontally consecutive pixels of one (channel, dy, dx): to make that ONE aligned 16-byte LDS read the halo is stored three
+// times, shifted by dx = 0, 1, 2 ([piece][dx][c][row][40] bf16, 19 KB) -- 6 two-byte stores per halo element, once per tile, instead of 16 two-byte reads
+// per MFMA.  Partials and their reduction are the fp32 kernel's ([2][co][j % 32] + 32 bias sums per workgroup, fixed order).
+// ------------------------------------------------------------------------------------------------------------------
+typedef __bf16 fw_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short fw_s16x4 __attribute__((ext_vector_type(4)));
+typedef int fw_i32x4 __attribute__((ext_vector_type(4)));
+#define FXW 40                                   // padded row of a shifted halo copy (bf16 elements; 80 B keeps 16-byte alignment)
+
+__device__ __forceinline__ void fw_dma16(fw_i32x4 rsrc, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_first_wgrad_bf16_kernel(const bf16_t* __restrict__ g, const float* __restrict__ x, float* __restrict__ part,
+                                                                    int N, int H, int W) {
+    constexpr int K = 9 * CIN;
+    constexpr int XS = 2 * 3 * CIN * (FTH + 2) * FXW;                     // bf16 elements of the shifted halo copies
+    __shared__ __attribute__((aligned(16))) bf16_t gl[2][FTH * FTW * 32];                            // 2 x 16 KB
+    __shared__ __attribute__((aligned(16))) bf16_t xs[XS];
+    const int tid = threadIdx.x, lane = tid & 63, m = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = (W + FTW - 1) / FTW, tiles_y = (H + FTH - 1) / FTH;
+    const int total = tiles_x * tiles_y * N;
+    // this lane's two B columns: tap-channel j = jt*32 + m -> (c, dy, dx); offset of its operand for tile row 0, pixel 0, piece 0 (bf16 elements)
+    int boff[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+        const int j = jt * 32 + m;
+        const int c = j / 9, r9 = j - c * 9, dy = r9 / 3, dx = r9 - dy * 3;
+        boff[jt] = j < K ? ((dx * CIN + c) * (FTH + 2) + dy) * FXW : -1;
+    }
+    const int gi = lane & 15, gg = lane >> 4;
+    const int gq_off = (8 * hi + (gi >> 2)) * 32 + (gg & 1) * 16 + (gi & 3) * 4;          // ds_read_b64_tr_b16 addressing (conv_wgrad.hip)
+    const unsigned lds_gl = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(__attribute__((address_space(3))) bf16_t*)&gl[0][0]);
+    const unsigned long long gbase = (unsigned long long)g;
+    const size_t gbytes = (size_t)N * H * W * 64;
+    const fw_i32x4 rsrc_g = {(int)(unsigned)gbase, (int)((unsigned)(gbase >> 32) & 0xFFFFu), (int)(gbytes < 0xFFFFFFF0ull ? gbytes : 0xFFFFFFF0ull), 0x00020000};
+    f32x16 acc[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[jt][i] = 0.f;
+    float bsum = 0.f;
+    FirstHalo<CIN> hr;
+    auto prefetch = [&](int t, int buf) {
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, img = t / (tiles_x * tiles_y);
+        const int y0 = ty * FTH, x0 = tx * FTW;
+        hr.load(x, img, y0, x0, H, W);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {                                  // 16 pieces of 1 KiB = 16 pixels x 64 B each: piece p = (row p >> 1, pixels 16 (p & 1) ..)
+            const int p = wave + it * 4;
+            const int gy = y0 + (p >> 1), gx = x0 + 16 * (p & 1) + (lane >> 2);
+            const bool ok = gy < H && gx < W;
+            const unsigned voff = ok ? (unsigned)(((size_t)(img * H + gy) * W + gx) * 64 + (lane & 3) * 16) : 0xFFFFFFF0u;
+            fw_dma16(rsrc_g, voff, lds_gl + (unsigned)(buf * (FTH * FTW * 64) + p * 1024));
+        }
+    };
+    int buf = 0;
+    if ((int)blockIdx.x < total) prefetch(blockIdx.x, 0);
+    for (int t = blockIdx.x; t < total; t += gridDim.x, buf ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of the gradient tile (and its halo loads) have landed
+        __syncthreads();                                        // everybody's; the previous tile's fragment reads are done
+#pragma unroll
+        for (int it = 0; it < FirstHalo<CIN>::IT; ++it) {      // halo -> two bf16 pieces -> the three shifted copies
+            const int u = tid + it * 256;
+            if (u >= CIN * FHP) continue;
+            const int c = u / FHP, hp = u - c * FHP;
+            const int hy = hp / (FTW + 2), hx = hp - hy * (FTW + 2);
+            const float v = hr.v[it];
+            const unsigned vb = __float_as_uint(v);
+            const bf16_t ph = (bf16_t)(vb >> 16), pl = f2bf(v - __uint_as_float(vb & 0xFFFF0000u));
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int xx = hx - dx;
+                if (xx < 0 || xx >= FTW) continue;
+                const int o = ((dx * CIN + c) * (FTH + 2) + hy) * FXW + xx;
+                xs[o] = ph;
+                xs[o + 3 * CIN * (FTH + 2) * FXW] = pl;
+            }
+        }
+        __syncthreads();
+        if (t + (int)gridDim.x < total) prefetch(t + gridDim.x, buf ^ 1);
+        const bf16_t* gt = &gl[buf][0];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {                        // 16 consecutive pixels of one row per k-step; the wave owns rows 2 wave, 2 wave + 1
+            const int row = 2 * wave + (ks >> 1), col0 = 16 * (ks & 1);
+            const bf16_t* p0 = gt + (row * FTW + col0) * 32 + gq_off;
+            const fw_s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) fw_s16x4*)p0);
+            const fw_s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) fw_s16x4*)(p0 + 4 * 32));
+            const fw_bf16x8 ga = __builtin_bit_cast(fw_bf16x8, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+            {
+                const uint4 q = __builtin_bit_cast(uint4, ga);
+                bsum += __uint_as_float(q.x << 16) + __uint_as_float(q.x & 0xFFFF0000u) + __uint_as_float(q.y << 16) + __uint_as_float(q.y & 0xFFFF0000u)
+                      + __uint_as_float(q.z << 16) + __uint_as_float(q.z & 0xFFFF0000u) + __uint_as_float(q.w << 16) + __uint_as_float(q.w & 0xFFFF0000u);
+            }
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                uint4 bh = make_uint4(0, 0, 0, 0), bl = make_uint4(0, 0, 0, 0);
+                if (boff[jt] >= 0) {
+                    const bf16_t* pb = xs + boff[jt] + row * FXW + col0 + 8 * hi;
+                    bh = *reinterpret_cast<const uint4*>(pb);
+                    bl = *reinterpret_cast<const uint4*>(pb + 3 * CIN * (FTH + 2) * FXW);
+                }
+                acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, __builtin_bit_cast(fw_bf16x8, bh), acc[jt], 0, 0, 0);
+                acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, __builtin_bit_cast(fw_bf16x8, bl), acc[jt], 0, 0, 0);
+            }
+        }
+    }
+    // reduce the 4 waves through LDS (fixed order), wave 0 writes the partial -- as conv_first_wgrad_kernel
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(&gl[0][0]);            // [3 waves][2][16][64] floats = 24 KB of the 32 KB
+    if (wave > 0) {
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) red[(((wave - 1) * 2 + jt) * 16 + i) * 64 + lane] = acc[jt][i];
+    }
+    float* bred = red + 3 * 2 * 16 * 64;
+    bred[wave * 64 + lane] = bsum;
+    __syncthreads();
+    if (wave == 0) {
+        float* p = part + (size_t)blockIdx.x * (2 * 32 * 32 + 32);
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float v = acc[jt][i];
+                for (int wv = 0; wv < 3; ++wv) v += red[((wv * 2 + jt) * 16 + i) * 64 + lane];
+                const int row = (i & 3) + 8 * (i >> 2) + 4 * hi;             // co
+                p[(jt * 32 + row) * 32 + m] = v;                              // [jt][co][j%32]
+            }
+        if (lane < 32) {
+            float b = 0.f;
+            for (int wv = 0; wv < 4; ++wv) b += bred[wv * 64 + lane] + bred[wv * 64 + 32 + lane];
+            p[2 * 32 * 32 + lane] = b;
+        }
+    }
+}
+
 // dW[co][k] (OIHW, k < K) and db[co] from the per-workgroup partials, fixed order: 16 outputs x 16 partial slices per
 // workgroup, 4 loads in flight per lane, slices combined through LDS
 __global__ __launch_bounds__(256) void conv_first_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nblocks, int K) {
@@ -291,5 +441,15 @@ int launch_conv_first_wgrad(const float* g, const float* x, float* dw, float* db
     return launch_first_wgrad_t<float>(g, x, dw, db, part, N, Cin, H, W, st);
 }
 int launch_conv_first_wgrad_bf16(const bf16_t* g, const float* x, float* dw, float* db, float* part, int N, int Cin, int H, int W, hipStream_t st) {
-    return launch_first_wgrad_t<bf16_t>(g, x, dw, db, part, N, Cin, H, W, st);
+    const int tiles = ((W + FTW - 1) / FTW) * ((H + FTH - 1) / FTH) * N;
+    if (tiles <= 0) return 0;
+    if (Cin != 4 || (size_t)N * H * W * 64 >= 0xFFFFFFF0ull) return launch_first_wgrad_t<bf16_t>(g, x, dw, db, part, N, Cin, H, W, st);      // generic fp32-MFMA kernel
+    const int resident = 3 * eld_num_cus();                  // 51 KB of LDS per workgroup: three per CU; the persistent grid must not exceed what is co-resident
+    const int cap = resident < FW_BLOCKS ? resident : FW_BLOCKS;
+    const int grid = tiles < cap ? tiles : cap;
+    ELD_LAUNCH((conv_first_wgrad_bf16_kernel<4>), dim3(grid), dim3(256), 0, st, g, x, part, N, H, W);
+    ELD_LAUNCH_CHECK();
+    ELD_LAUNCH(conv_first_wgrad_reduce_kernel, dim3((2 * 32 * 32 + 32 + 15) / 16), dim3(256), 0, st, part, dw, db, grid, 9 * Cin);
+    ELD_LAUNCH_CHECK();
+    return 0;
 }
