@@ -326,6 +326,7 @@ def main():
         # the sampler's duration INSIDE the step (right behind the previous step's Adam: clocks and caches as the step leaves them), beside
         # the standalone launch timed below
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(4)]
+        model.exchange = False                      # rank 0 is alone in this block: no collective may be issued here (N > 1: the replicas are done training)
         for i, (e0, e1) in enumerate(evs):          # no host sync inside: the host runs ahead, so e0 -> e1 spans only the queued synthesis work
             ids = [((total_steps + 8 + i) * world * B) + rank + world * k for k in range(B)]
             e0.record()
@@ -335,6 +336,7 @@ def main():
         torch.cuda.synchronize()
         t_in = [e0.elapsed_time(e1) for e0, e1 in evs[1:]]
         sampler_in_step_ms = min(t_in)
+        model.exchange = True
         # BASELINE.json configs[2] (bf16 U-Net with MFMA convs, batch 8) beside the headline: the same step with the bf16 engine, its own
         # roofline against the 2.5 PF/s bf16 peak.  `value` above stays on configs[1] (fp32).
         if args.precision == 'fp32' and world == 1 and not args.no_alt:

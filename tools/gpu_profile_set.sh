@@ -22,3 +22,6 @@ timeout 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM --output-format csv -d $O/pmc -o noise_sq2 -- python tools/noise_microbench.py 8 > $O/pmc_noise2.log 2>&1
 ls $O $O/prof $O/pmc | head -60
 cut -c1-300 $O/bench_fp32.json
+# the N > 1 bench path end to end on ONE GPU: two ranks share the device over gloo (RCCL itself needs two devices: tests/test_dist_gpu.py)
+ELD_DIST_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 3 --warmup 1 --batch 1 --height 512 --width 512 > $O/bench_2rank_gloo.json 2> $O/bench_2rank_gloo.err
+cut -c1-400 $O/bench_2rank_gloo.json
