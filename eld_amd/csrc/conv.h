@@ -9,6 +9,8 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
 
 enum ConvMode { CONV_3X3 = 0, CONV_1X1 = 1, CONV_GATHER2X2 = 2 };
 enum ConvEpi { EPI_FWD = 0, EPI_CONVT_FWD = 1, EPI_GRAD = 2 };
@@ -70,18 +72,45 @@ __device__ __forceinline__ void amax_accumulate(float* slot, float v) {
     if ((threadIdx.x & 63) == 0 && b > *reinterpret_cast<volatile unsigned*>(slot)) atomicMax(reinterpret_cast<unsigned*>(slot), b);
 }
 
+// v_max_f32 without the canonicalising v_max_f32 x, x, x that fmaxf() gets in front of it for every operand the compiler cannot prove quiet
+// (results of packed adds, DPP moves, bit casts): operands here are finite
+__device__ __forceinline__ float fmax_raw(float a, float b) {
+    asm("v_max_f32 %0, %0, %1" : "+v"(a) : "v"(b));
+    return a;
+}
+// max with lane ^ 1 (the horizontal neighbour pixel of the fused 2x2 max-pool): quad_perm [1,0,3,2] folded into the v_max (the builtin pair
+// compiles to v_mov_dpp + canonicalise + v_max).  s_nop 1: a VALU write needs two wait states before a DPP read of the same register.
+__device__ __forceinline__ float fmax_lane_xor1(float f) {
+    float r;
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(f));
+    return r;
+}
+// in place on elements i .. i+3 of an MFMA accumulator: v <- max(sl * t, t), t = v + b: bias and LeakyReLU (sl = 0.2; sl = 1 leaves t) with
+// the packed fp32 add / multiply
+__device__ __forceinline__ void bias_lrelu4(f32x16& acc, int i, float4 b, float sl) {
+    f32x2 t01 = {acc[i], acc[i + 1]}, t23 = {acc[i + 2], acc[i + 3]};
+    const f32x2 b01 = {b.x, b.y}, b23 = {b.z, b.w};
+    t01 += b01; t23 += b23;
+    const f32x2 s01 = t01 * sl, s23 = t23 * sl;
+    acc[i] = fmax_raw(t01.x, s01.x); acc[i + 1] = fmax_raw(t01.y, s01.y); acc[i + 2] = fmax_raw(t23.x, s23.x); acc[i + 3] = fmax_raw(t23.y, s23.y);
+}
+// in place on elements i .. i+3 of an MFMA accumulator: v <- max(sl * v, v) (the bias already sits in the accumulator: it was its initial value)
+__device__ __forceinline__ void lrelu4(f32x16& acc, int i, float sl) {
+    const f32x2 t01 = {acc[i], acc[i + 1]}, t23 = {acc[i + 2], acc[i + 3]};
+    const f32x2 s01 = t01 * sl, s23 = t23 * sl;
+    acc[i] = fmax_raw(t01.x, s01.x); acc[i + 1] = fmax_raw(t01.y, s01.y); acc[i + 2] = fmax_raw(t23.x, s23.x); acc[i + 3] = fmax_raw(t23.y, s23.y);
+}
 __device__ __forceinline__ float lrelu_slope(float y) { return y > 0.f ? 1.0f : (y < 0.f ? 0.2f : 0.6f); }
 
-// bfloat16 <-> float (round to nearest even; NaN not special-cased: activations are finite)
+// bfloat16 <-> float.  Rounding to nearest even is the hardware's (v_cvt_pk_bf16_f32, one instruction per PAIR of values): a software
+// round costs five VALU instructions per value, which made the bf16 conv epilogues VALU-bound (DESIGN.md, bf16 path).
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float((unsigned)v << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_hw));
 }
-__device__ __forceinline__ uint2 pack_bf4(float4 v) {
-    return make_uint2((unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16), (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16));
-}
+__device__ __forceinline__ uint2 pack_bf4(float4 v) { return make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)); }
 __device__ __forceinline__ float4 unpack_bf4(uint2 p) {
     return make_float4(__uint_as_float(p.x << 16), __uint_as_float(p.x & 0xFFFF0000u), __uint_as_float(p.y << 16), __uint_as_float(p.y & 0xFFFF0000u));
 }
@@ -193,6 +222,10 @@ int launch_conv_bfd(const ConvArgs& a, hipStream_t st);      // transposed-conv 
 int debug_kernel_mask(int set);      // eld_debug_kernel_mask: set < 0 only queries
 bool bfs_takes(int Nout, int K, int N, int H, int W);
 int launch_conv_bfs(const ConvArgs& a, hipStream_t st);
+// bf16 3x3 layers with exactly 64 output channels and K = 32 / 64 (conv_bfw.hip: weights resident in LDS, four-deep ring of 16-channel halo tiles);
+// same BN = 64 slab layout as conv_bfd_kernel<64>, chosen per launch inside launch_conv_bfd
+bool bfw_takes(const ConvArgs& a);
+int launch_conv_bfw(const ConvArgs& a, hipStream_t st);
 // bf16 transposed convolutions (conv_bfg.hip: both operands by LDS-DMA): column-block width of the packed slabs (bfg_store), 0 = stays on conv_igemm_kernel
 int bfg_slab_bn(bool gather, int Nout, int Cs, int Cout_t, int N, int H, int W);
 __host__ __device__ inline size_t bfg_slab_bytes(int BN) { return (size_t)BN * 64; }

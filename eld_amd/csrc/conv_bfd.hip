@@ -43,10 +43,6 @@ __device__ __forceinline__ void bfd_dma16(i32x4 rsrc, unsigned voff, unsigned so
 template <int N>
 __device__ __forceinline__ void bfd_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-__device__ __forceinline__ float hmax1b(float f) {       // max with lane ^ 1 (horizontal neighbour pixel): quad_perm [1,0,3,2]
-    return fmaxf(f, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(f), 0xB1, 0xF, 0xF, true)));
-}
-
 template <int BN, int RPW, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) {
     constexpr int THREADS = 64 * WAVES;
@@ -231,9 +227,26 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
         //      -------------------------------------------------------------------------------------------------------------------------
         if (!(ELD_DBG(a) & 1)) {
             const int lp = lane & 15, lg = bf16_line_group(lane);
-            const int halves = (x0 + 16 < a.W) ? 2 : 1;                   // x0 < W for every tile
             const int x = x0 + m;
             const bool xok = x < a.W;
+            // Forward: bias and max(0.2 v, v) once, in place, two values per instruction where the ISA has a packed form (the pooled copy
+            // below reuses the activated values).  The whole epilogue runs with the matrix pipe idle (every wave of the workgroup reaches it
+            // at the same stage), so its VALU instruction count is launch time: 2.5 instructions per value here, against 8 with a
+            // software bf16 round and 14 per pooled value when the pool recomputed bias + activation.
+            if (a.epi == EPI_FWD) {
+                const float* lb4 = lds_bias + nb * BN + 4 * hi;
+                const float sl = a.lrelu ? 0.2f : 1.0f;                  // max(1 v, v) = v: no branch inside the unrolled loops
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 bq = *reinterpret_cast<const float4*>(lb4 + tt * 32 + 8 * q);
+#pragma unroll
+                        for (int r = 0; r < RPW; ++r) bias_lrelu4(acc[r][tt], 4 * q, bq, sl);
+                    }
+            }
+            // (Pairing adjacent blocks into whole 128-byte lines per store instruction -- 8 pixels x 128 B instead of 16 pixels x 64 B -- was
+            // measured and dropped: 2 % slower here, neutral on conv_bfw; profiles/r03_ab_notes.md.)
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
                 const int y = y0 + wave * RPW + r;                      // wave-uniform
@@ -249,15 +262,6 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
                     bf16_t* drow;                                        // block base of pixel x0 of this row in the destination tensor, + this lane's group
                     int C;
                     if (a.epi == EPI_FWD) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float4 bq = *reinterpret_cast<const float4*>(lds_bias + nb32 + 4 * hi + 8 * q);
-                            v[q].x += bq.x; v[q].y += bq.y; v[q].z += bq.z; v[q].w += bq.w;
-                            if (a.lrelu) {
-                                v[q].x = fmaxf(0.2f * v[q].x, v[q].x); v[q].y = fmaxf(0.2f * v[q].y, v[q].y);
-                                v[q].z = fmaxf(0.2f * v[q].z, v[q].z); v[q].w = fmaxf(0.2f * v[q].w, v[q].w);
-                            }
-                        }
                         C = a.Nout;
                         drow = static_cast<bf16_t*>(a.out0) + (rowpix + x0) * C + nb32 + 8 * lg;
                     } else {
@@ -286,20 +290,16 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
                     bf16_line_swap(pk, s0, s1);                          // every lane takes part; only the stores are predicated
                     if (yok) {
                         if (x0 + lp < a.W) *reinterpret_cast<uint4*>(drow + (size_t)lp * C) = s0;
-                        if (halves == 2 && x0 + lp + 16 < a.W) *reinterpret_cast<uint4*>(drow + (size_t)(lp + 16) * C) = s1;
+                        if (x0 + lp + 16 < a.W) *reinterpret_cast<uint4*>(drow + (size_t)(lp + 16) * C) = s1;
                     }
                 }
             }
-            // fused nn.MaxPool2d(2) (Unet.py:51-63): vertical pair in the lane's own rows, horizontal pair in lane ^ 1; pooled from the
-            // bf16-ROUNDED values (max commutes with the monotone rounding, so this equals pooling the stored tensor)
-            if (a.epi == EPI_FWD && a.pool_out != nullptr && xok) {
+            // fused nn.MaxPool2d(2) (Unet.py:51-63): vertical pair in the lane's own rows, horizontal pair in lane ^ 1, on the activated
+            // fp32 values (max commutes with the monotone bf16 rounding, so this equals pooling the stored tensor)
+            if (a.epi == EPI_FWD && a.pool_out != nullptr) {
                 const int Hp = a.H >> 1, Wp = a.W >> 1;
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) {
-                    const int nbase = nb * BN + tt * 32 + 4 * hi;
-                    float4 bs[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) bs[q] = *reinterpret_cast<const float4*>(lds_bias + nbase + 8 * q);
 #pragma unroll
                     for (int rp = 0; rp < RPW / 2; ++rp) {
                         const int y = y0 + wave * RPW + 2 * rp;
@@ -307,19 +307,14 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
                         uint2 pk[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const float bq[4] = {bs[q].x, bs[q].y, bs[q].z, bs[q].w};
                             float u[4];
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                float p0 = acc[2 * rp][tt][4 * q + j] + bq[j], p1 = acc[2 * rp + 1][tt][4 * q + j] + bq[j];
-                                if (a.lrelu) { p0 = fmaxf(0.2f * p0, p0); p1 = fmaxf(0.2f * p1, p1); }
-                                u[j] = hmax1b(fmaxf(p0, p1));
-                            }
+                            for (int j = 0; j < 4; ++j) u[j] = fmax_lane_xor1(fmax_raw(acc[2 * rp][tt][4 * q + j], acc[2 * rp + 1][tt][4 * q + j]));
                             pk[q] = pack_bf4(make_float4(u[0], u[1], u[2], u[3]));
                         }
-                        // (every lane takes part in the exchange; even pixels store)
+                        // (every lane takes part in the exchanges; even pixels inside the image store)
                         const uint4 w0 = bf16_pair_swap(pk[0], pk[1]), w1 = bf16_pair_swap(pk[2], pk[3]);
-                        if (!(x & 1)) {
+                        if (xok && !(x & 1)) {
                             bf16_t* dp = static_cast<bf16_t*>(a.pool_out) + ((size_t)(img * Hp + (y >> 1)) * Wp + (x >> 1)) * a.Nout + nb * BN + tt * 32 + 8 * hi;
                             *reinterpret_cast<uint4*>(dp) = w0;
                             *reinterpret_cast<uint4*>(dp + 16) = w1;
@@ -382,6 +377,6 @@ int launch_conv_bfd(const ConvArgs& a, hipStream_t st) {
     const int bn = bfd_slab_bn(a.Nout, a.C0 + a.C1, a.N, a.H, a.W);
     if (bn == 32) return launch_conv_bfs(a, st);
     if (bn == 128) return launch_bfd<128, 2, 8>(a, st);
-    if (bn == 64) return launch_bfd<64, 2, 8>(a, st);
+    if (bn == 64) return bfw_takes(a) ? launch_conv_bfw(a, st) : launch_bfd<64, 2, 8>(a, st);
     return ELD_ENOTSUP;
 }

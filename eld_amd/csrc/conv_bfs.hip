@@ -35,10 +35,6 @@ __device__ __forceinline__ void bfs_dma16(i32x4 rsrc, unsigned voff, unsigned so
 template <int N>
 __device__ __forceinline__ void bfs_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-__device__ __forceinline__ float hmax1s(float f) {       // max with lane ^ 1 (horizontal neighbour pixel): quad_perm [1,0,3,2]
-    return fmaxf(f, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(f), 0xB1, 0xF, 0xF, true)));
-}
-
 constexpr int BFS_NAB = 3;                               // activation ring depth
 constexpr int BFS_WCHUNK = 9 * 32 * 64;                  // packed weights of one 32-channel chunk: 18 DMA pieces
 
@@ -155,6 +151,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfs_kernel(const ConvArgs a) 
 
 #pragma unroll
     for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(bs[q].x), "+v"(bs[q].y), "+v"(bs[q].z), "+v"(bs[q].w));      // the loads complete HERE, not at a vmcnt(0) inside the loop
+    const float sl = a.lrelu ? 0.2f : 1.0f;                // max(1 v, v) = v
     static_assert(RPW == 2, "the activation-load wait names ac[2][2]");
     u32x4 ac[RPW][2];                                      // native vector type: one 128-bit register tuple per asm operand
 
@@ -212,7 +209,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfs_kernel(const ConvArgs a) 
                         acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw), __builtin_bit_cast(bf16x8, fx[r]), acc[r], 0, 0, 0);      // D[channel][pixel]
                 }
         }
-        if (chunk + 1 < NCH) continue;
+        if constexpr (!ACT) { if (chunk + 1 < NCH) continue; }      // (ACT launches have one chunk per tile: no path from the activation loads past their wait)
         if constexpr (ACT) {                     // the hand-issued activation loads have landed (item j+2's A_IT DMA pieces, issued after them, may still fly)
             // (whole 128-bit tuples as operands: with sixteen 32-bit operands the compiler shuffled the registers -- v_mov copies of data that had
             // not landed yet -- to build the statement's operand list)
@@ -225,22 +222,19 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfs_kernel(const ConvArgs a) 
         int img, y0, x0;
         decode(t, img, y0, x0);
         const int lp = lane & 15, lg = bf16_line_group(lane);
+        if (a.epi == EPI_FWD) {                 // bias + max(0.2 v, v) once, in place (the pooled copy below reuses the activated values)
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bias_lrelu4(acc[r], 4 * q, bs[q], sl);
+        }
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             const int y = y0 + wave * RPW + r;
             float4 v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = make_float4(acc[r][4 * q], acc[r][4 * q + 1], acc[r][4 * q + 2], acc[r][4 * q + 3]);
-            if (a.epi == EPI_FWD) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    v[q].x += bs[q].x; v[q].y += bs[q].y; v[q].z += bs[q].z; v[q].w += bs[q].w;
-                    if (a.lrelu) {
-                        v[q].x = fmaxf(0.2f * v[q].x, v[q].x); v[q].y = fmaxf(0.2f * v[q].y, v[q].y);
-                        v[q].z = fmaxf(0.2f * v[q].z, v[q].z); v[q].w = fmaxf(0.2f * v[q].w, v[q].w);
-                    }
-                }
-            } else if constexpr (ACT) {                                     // EPI_GRAD: times the LeakyReLU slope of the saved activation
+            if constexpr (ACT) {                                            // EPI_GRAD: times the LeakyReLU slope of the saved activation
                 uint2 sp[4];
                 bf16_line_unswap(make_uint4(ac[r][0][0], ac[r][0][1], ac[r][0][2], ac[r][0][3]), make_uint4(ac[r][1][0], ac[r][1][1], ac[r][1][2], ac[r][1][3]), sp);
 #pragma unroll
@@ -260,8 +254,8 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfs_kernel(const ConvArgs a) 
         }
         const int x = x0 + m;
         const bool xok = x < a.W;
-        // fused nn.MaxPool2d(2) (Unet.py:51): vertical pair in the lane's own rows, horizontal pair in lane ^ 1, pooled from the bf16-ROUNDED
-        // values (max commutes with the monotone rounding)
+        // fused nn.MaxPool2d(2) (Unet.py:51): vertical pair in the lane's own rows, horizontal pair in lane ^ 1, on the activated fp32 values
+        // (max commutes with the monotone bf16 rounding, so this equals pooling the stored tensor)
         if (a.epi == EPI_FWD && a.pool_out != nullptr && xok) {
             const int Hp = a.H >> 1, Wp = a.W >> 1;
 #pragma unroll
@@ -271,14 +265,9 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfs_kernel(const ConvArgs a) 
                 uint2 pk[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float bq[4] = {bs[q].x, bs[q].y, bs[q].z, bs[q].w};
                     float u[4];
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) {
-                        float p0 = acc[2 * rp][4 * q + jj] + bq[jj], p1 = acc[2 * rp + 1][4 * q + jj] + bq[jj];
-                        if (a.lrelu) { p0 = fmaxf(0.2f * p0, p0); p1 = fmaxf(0.2f * p1, p1); }
-                        u[jj] = hmax1s(fmaxf(p0, p1));
-                    }
+                    for (int jj = 0; jj < 4; ++jj) u[jj] = fmax_lane_xor1(fmax_raw(acc[2 * rp][4 * q + jj], acc[2 * rp + 1][4 * q + jj]));
                     pk[q] = pack_bf4(make_float4(u[0], u[1], u[2], u[3]));
                 }
                 const uint4 w0 = bf16_pair_swap(pk[0], pk[1]), w1 = bf16_pair_swap(pk[2], pk[3]);
@@ -318,7 +307,7 @@ int launch_bfs(ConvArgs a, hipStream_t st) {
 // Layers this kernel takes: bf16 3x3 with exactly 32 output channels (GEMM N), K = 32 or 64 input channels (one tensor, or the virtual concat of two
 // 32-channel tensors), a single output tensor, on a tile domain that gives every CU a tile; weights in conv_bfd's slab layout at BN = 32.
 int debug_kernel_mask(int set) {
-    static int mask = 0;
+    static int mask = [] { const char* e = getenv("ELD_DEBUG_KERNEL_MASK"); return e ? atoi(e) : 0; }();      // (env: same-box A/B runs of bench.py)
     const int prev = mask;
     if (set >= 0) mask = set;
     return prev;

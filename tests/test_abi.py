@@ -92,10 +92,12 @@ def test_plugin_constructor_and_sample_params(golden_dir, capsys):
     assert tuple(base) == tuple(full) and full.tl_scale > 0 and full.row_scale > 0 and -0.25 < full.tl_lambda < 0.25
 
 
-def test_hand_issued_loads_are_not_touched_before_their_wait():
-    """conv_bfs_kernel<.., ACT = true> loads the saved activations with inline-asm global loads that hipcc does not count
-    (cdna_hip_programming.md 5.7 item 1): between such a load and the hand-written `s_waitcnt vmcnt(5)` that retires it the compiler
-    must neither read nor copy nor overwrite the destination registers.  Audit of the generated gfx950 assembly (cross-compiles
+@pytest.mark.parametrize('src_name,kernel,wait', [('conv_bfs.hip', 'conv_bfs_kernelILi2ELi8ELb1EEEv8ConvArgs:', 's_waitcnt vmcnt(5)'),
+                                                  ('conv_bfw.hip', 'conv_bfw_kernelILb1EEEv8ConvArgs:', 's_waitcnt vmcnt(3)')])
+def test_hand_issued_loads_are_not_touched_before_their_wait(src_name, kernel, wait):
+    """conv_bfs_kernel<.., ACT = true> and conv_bfw_kernel<ACT = true> load the saved activations with inline-asm global loads that hipcc
+    does not count (cdna_hip_programming.md 5.7 item 1): between such a load and the hand-written `s_waitcnt vmcnt(n)` that retires it the
+    compiler must neither read nor copy nor overwrite the destination registers.  Audit of the generated gfx950 assembly (cross-compiles
     without a GPU); silent corruption otherwise -- a passing numerical test is not evidence for this hazard."""
     import re
     import shutil
@@ -104,18 +106,18 @@ def test_hand_issued_loads_are_not_touched_before_their_wait():
     hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     if not os.path.exists(hipcc):
         pytest.skip('no hipcc')
-    src = os.path.join(ROOT, 'eld_amd', 'csrc', 'conv_bfs.hip')
+    src = os.path.join(ROOT, 'eld_amd', 'csrc', src_name)
     with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, 'bfs.s')
+        out = os.path.join(d, 'k.s')
         subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fhip-fp32-correctly-rounded-divide-sqrt',
                                '-S', '--cuda-device-only', '-o', out, src], stderr=subprocess.DEVNULL)
         text = open(out).read()
-    body = text[text.index('conv_bfs_kernelILi2ELi8ELb1EEEv8ConvArgs:'):]
+    body = text[text.index(kernel):]
     body = body[:body.index('.Lfunc_end')]
-    lines = body.split('\n')
-    # asm statements are bracketed by ;;#ASMSTART / ;;#ASMEND
-    in_asm, pending, checked = False, set(), 0
-    for ln in lines:
+    # basic blocks (labels, branches) and a forward dataflow of the "loaded, not yet waited for" register set: mutually exclusive branches
+    # may reuse each other's destination registers as temporaries, so a linear scan of the text would report false hazards
+    blocks, cur, in_asm = [], {'label': None, 'ins': []}, False
+    for ln in body.split('\n')[1:]:
         t = ln.strip()
         if t.startswith(';;#ASMSTART'):
             in_asm = True
@@ -123,21 +125,62 @@ def test_hand_issued_loads_are_not_touched_before_their_wait():
         if t.startswith(';;#ASMEND'):
             in_asm = False
             continue
+        m = re.match(r'^(\.LBB\d+_\d+):', t)
+        if m:
+            blocks.append(cur)
+            cur = {'label': m.group(1), 'ins': []}
+            continue
         if not t or t.startswith(';') or t.startswith('.'):
             continue
-        if in_asm:
-            m = re.match(r'global_load_dwordx4 v\[(\d+):(\d+)\]', t)
-            if m:
-                pending |= set(range(int(m.group(1)), int(m.group(2)) + 1))
-            elif t.startswith('s_waitcnt vmcnt(5)') and pending:
-                pending.clear()
-                checked += 1
-            continue
-        if pending:
-            code = t.split(';')[0]
-            regs = set(int(r) for r in re.findall(r'\bv(\d+)\b', code))
-            for a_, b_ in re.findall(r'v\[(\d+):(\d+)\]', code):
-                regs |= set(range(int(a_), int(b_) + 1))
-            # the address registers of a later hand-issued load may be REUSED destinations only after that load: any touch is a violation
-            assert not (regs & pending), 'compiler instruction touches an un-waited asm load destination: %s' % t
+        code = t.split(';')[0].strip()
+        cur['ins'].append((in_asm, code))
+        if not in_asm and (code.startswith('s_branch') or code.startswith('s_cbranch') or code.startswith('s_endpgm')):
+            blocks.append(cur)
+            cur = {'label': None, 'ins': []}
+    blocks.append(cur)
+    blocks = [b for b in blocks if b['ins'] or b['label']]
+    index = {b['label']: i for i, b in enumerate(blocks) if b['label']}
+    succ = []
+    for i, b in enumerate(blocks):
+        last = b['ins'][-1][1] if b['ins'] else ''
+        if last.startswith('s_endpgm'):
+            succ.append([])
+        elif last.startswith('s_branch'):
+            succ.append([index[last.split()[1]]])
+        elif last.startswith('s_cbranch'):
+            succ.append([index[last.split()[1]]] + ([i + 1] if i + 1 < len(blocks) else []))
+        else:
+            succ.append([i + 1] if i + 1 < len(blocks) else [])
+
+    def regs_of(code):
+        regs = set(int(r) for r in re.findall(r'\bv(\d+)\b', code))
+        for a_, b_ in re.findall(r'v\[(\d+):(\d+)\]', code):
+            regs |= set(range(int(a_), int(b_) + 1))
+        return regs
+
+    pend_in = [set() for _ in blocks]
+    checked, violations = 0, []
+    changed = True
+    while changed:
+        changed = False
+        checked, violations = 0, []
+        for i, b in enumerate(blocks):
+            pending = set(pend_in[i])
+            for is_asm, code in b['ins']:
+                if is_asm:
+                    m = re.match(r'global_load_dwordx4 v\[(\d+):(\d+)\]', code)
+                    if m:
+                        pending |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+                    elif code.startswith(wait):
+                        if pending:
+                            checked += 1
+                        pending = set()
+                    continue
+                if pending and (regs_of(code) & pending):
+                    violations.append(code)
+            for j in succ[i]:
+                if not pending <= pend_in[j]:
+                    pend_in[j] |= pending
+                    changed = True
+    assert not violations, 'compiler instructions touch un-waited asm load destinations: %s' % violations[:5]
     assert checked >= 1

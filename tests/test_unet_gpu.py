@@ -13,6 +13,8 @@ import torch.nn.functional as F      # noqa: E402
 
 from oracle import unet_ref as U     # noqa: E402  (checker only)
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 @pytest.fixture(scope='module')
 def lib(eld_lib):
@@ -438,14 +440,18 @@ def test_unet_bf16_dma_kernels_full_frame(lib):
         assert cos >= 0.995, (n, cos)
 
 
-@pytest.mark.parametrize('shape', [(2, 4, 272, 560), (1, 4, 512, 512), (1, 4, 1424, 2128)])
+@pytest.mark.parametrize('shape', [(2, 4, 272, 560), (1, 4, 512, 512), (2, 4, 1040, 1072), (1, 4, 1424, 2128)])
 def test_bf16_specialised_kernels_equal_the_generic_kernel_bit_for_bit(lib, shape):
     """The LDS-DMA kernels -- conv_bfs_kernel (32-output-channel layers: resident weights, 3-deep activation ring, hand-issued activation
-    loads) and conv_bfd_kernel (the wider layers: slab ring, counted waits across the epilogue's stores) with their fused pools and full-line
-    bf16 stores -- accumulate in the same order on the same MFMA as conv_igemm_kernel<bf16> (chunk -> ky -> kx -> 16-k block), so routing
-    those launches back to the generic kernel (eld_debug_kernel_mask) must reproduce output AND every parameter gradient bit for bit:
-    ragged right / bottom tiles, two images, virtual concats, the slope epilogues of the backward-data launches.  A stale LDS tile (a wait
-    that lets a needed DMA piece fly) shows up here as a wrong tile."""
+    loads), conv_bfd_kernel (the wider layers: slab ring, counted waits across the epilogue's stores) and conv_bfg_kernel (transposed convs)
+    with their fused pools and full-line bf16 stores -- accumulate in the same order on the same MFMA as conv_igemm_kernel<bf16>
+    (chunk -> ky -> kx -> 16-k block), so routing those launches back to the generic kernel (eld_debug_kernel_mask) must reproduce output
+    AND every parameter gradient bit for bit: ragged right / bottom tiles, two images, virtual concats, the slope epilogues of the
+    backward-data launches.  A stale LDS tile (a wait that lets a needed DMA piece fly) shows up here as a wrong tile.
+    conv_bfw_kernel (64-output-channel layers with K <= 64 at the two larger shapes: resident weights, ring of 16-channel half chunks) sums K
+    in the order (chunk, half, ky, kx): it must agree with conv_bfd_kernel<64> on the same launches up to that fp32 summation order -- a
+    handful of bf16 roundings that flip -- which a stale tile or a wrong channel block would exceed by orders of magnitude."""
+    import json
     from eld_amd.unet import UNetSeeInDark
     torch.manual_seed(5)
     net = UNetSeeInDark(4, 4).cuda()
@@ -454,7 +460,7 @@ def test_bf16_specialised_kernels_equal_the_generic_kernel_bit_for_bit(lib, shap
     x = torch.rand(*shape, device='cuda', generator=g)
     t = torch.rand(*shape, device='cuda', generator=g)
     res = {}
-    for mask in (0, 7):
+    for mask in (0, 8, 15):
         prev = lib.eld_debug_kernel_mask(mask)
         try:
             net.zero_grad()
@@ -463,9 +469,21 @@ def test_bf16_specialised_kernels_equal_the_generic_kernel_bit_for_bit(lib, shap
             res[mask] = (out.detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters()})
         finally:
             lib.eld_debug_kernel_mask(prev)
-    assert torch.equal(res[0][0], res[7][0])
+    assert torch.equal(res[8][0], res[15][0])
+    for n in res[8][1]:
+        assert torch.equal(res[8][1][n], res[15][1][n]), n
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300))
+    worst = {'out': rel(res[0][0], res[8][0])}
     for n in res[0][1]:
-        assert torch.equal(res[0][1][n], res[7][1][n]), n
+        worst[n] = rel(res[0][1][n], res[8][1][n])
+    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+    with open(os.path.join(ROOT, 'gpurun_out', 'r03_bfw_vs_bfd_%dx%dx%d.json' % (shape[0], shape[2], shape[3])), 'w') as f:
+        json.dump(worst, f, indent=1)
+    assert worst['out'] <= 3e-3, worst['out']
+    for n in res[0][1]:
+        assert worst[n] <= 1e-2, (n, worst[n])
 
 
 def test_unet_full_frame_properties(lib):

@@ -1,0 +1,8 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/${1:-r03v}; mkdir -p $O
+K="conv_bfw"
+for d in 0 128 0 128; do
+ELD_CONV_DBG=$d bash tools/gpu_kstats.sh $O dev_dbg$d $K bf16 tools/probe/libeld_dev.so
+done
