@@ -61,45 +61,31 @@ __device__ __forceinline__ int stage_row(int r, int limit) {
     return b + 8 > limit ? r : b + ((j & 3) << 1) + (j >> 2);
 }
 
-// max over the horizontal neighbour pixel (lane ^ 1 holds pixel x ^ 1 of the same row and the same channels): quad_perm [1,0,3,2]
-__device__ __forceinline__ float hmax1(float f) {
-    return fmaxf(f, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(f), 0xB1, 0xF, 0xF, true)));
-}
-
 // Fused nn.MaxPool2d(2) of a forward tile (models/arch/Unet.py:51-63): a lane owns pixel column x0+m of RPW consecutive rows starting at an even
-// row, so the vertical pair is in its own registers and the horizontal one in lane ^ 1.  The finished values (bias, LeakyReLU) are formed again
-// from the accumulators -- the same operations as the full-resolution store, hence the same bits as pooling the stored tensor -- and the even
-// lanes write [N, H/2, W/2, Nout].  H and W are even (checked by the launcher), so a window is never split by the image border.
+// row, so the vertical pair is in its own registers and the horizontal one in lane ^ 1 (conv.h fmax_lane_xor1).  acc holds the FINISHED values
+// (the epilogue adds bias and applies LeakyReLU in place before it stores), so this pools exactly what was stored; the even lanes write
+// [N, H/2, W/2, Nout].  H and W are even (checked by the launcher), so a window is never split by the image border.  Every lane of the wave runs
+// the exchange; only the stores are predicated.
 template <int RPW, int NT, int BN>
 __device__ __forceinline__ void pool_epilogue(const ConvArgs& a, const f32x16 (&acc)[RPW][NT], int img, int nb, int yb /* first row of the lane */, int x, int hi) {
     static_assert(RPW % 2 == 0, "row pairs per lane");
-    if (x >= a.W) return;
     const int Hp = a.H >> 1, Wp = a.W >> 1;
 #pragma unroll
     for (int tt = 0; tt < NT; ++tt) {
         const int nbase = nb * BN + tt * 32 + 4 * hi;
-        float4 bs[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) bs[q] = *reinterpret_cast<const float4*>(a.bias + nbase + 8 * q);
 #pragma unroll
         for (int rp = 0; rp < RPW / 2; ++rp) {
             const int y = yb + 2 * rp;
-            if (y >= a.H) continue;
+            if (y >= a.H) continue;                                 // wave-uniform
             float4 pv[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                float u[4], d[4];
-                const float bq[4] = {bs[q].x, bs[q].y, bs[q].z, bs[q].w};
+                float u[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    u[j] = acc[2 * rp][tt][4 * q + j] + bq[j];
-                    d[j] = acc[2 * rp + 1][tt][4 * q + j] + bq[j];
-                    if (a.lrelu) { u[j] = fmaxf(0.2f * u[j], u[j]); d[j] = fmaxf(0.2f * d[j], d[j]); }
-                    u[j] = hmax1(fmaxf(u[j], d[j]));
-                }
+                for (int j = 0; j < 4; ++j) u[j] = fmax_lane_xor1(fmax_raw(acc[2 * rp][tt][4 * q + j], acc[2 * rp + 1][tt][4 * q + j]));
                 pv[q] = make_float4(u[0], u[1], u[2], u[3]);
             }
-            if (!(x & 1)) {
+            if (x < a.W && !(x & 1)) {
                 float* dst = static_cast<float*>(a.pool_out) + ((size_t)(img * Hp + (y >> 1)) * Wp + (x >> 1)) * a.Nout + nbase;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(dst + 8 * q) = pv[q];
@@ -293,6 +279,19 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
             // read in the MFMA layout (own pixel m); every lane computes and takes part in the exchange, only loads and stores are predicated
             const int x = x0 + m;
             const bool xok = x < a.W;
+            // forward: bias and max(0.2 v, v) once, in place (packed fp32 add / multiply, v_max without the canonicalising copy fmaxf() gets);
+            // the pooled copy below reuses the finished values
+            if (a.epi == EPI_FWD) {
+                const float sl = a.lrelu ? 0.2f : 1.0f;                  // max(1 v, v) = v
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 bq = *reinterpret_cast<const float4*>(a.bias + nb * BN + tt * 32 + 4 * hi + 8 * q);
+#pragma unroll
+                        for (int r = 0; r < RPW; ++r) bias_lrelu4(acc[r][tt], 4 * q, bq, sl);
+                    }
+            }
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
                 const int y = y0 + wave * RPW + r;                      // wave-uniform
@@ -301,24 +300,13 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
                 const size_t pix = rowpix + (xok ? x : 0);
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) {
-                    const int nb32 = nb * BN + tt * 32, nbase = nb32 + 4 * hi;
+                    const int nb32 = nb * BN + tt * 32;
                     float4 v[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = make_float4(acc[r][tt][4 * q], acc[r][tt][4 * q + 1], acc[r][tt][4 * q + 2], acc[r][tt][4 * q + 3]);
                     float* blk;
                     int C;
                     if (a.epi == EPI_FWD) {
-                        float4 bs[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) bs[q] = *reinterpret_cast<const float4*>(a.bias + nbase + 8 * q);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            v[q].x += bs[q].x; v[q].y += bs[q].y; v[q].z += bs[q].z; v[q].w += bs[q].w;
-                            if (a.lrelu) {
-                                v[q].x = fmaxf(0.2f * v[q].x, v[q].x); v[q].y = fmaxf(0.2f * v[q].y, v[q].y);
-                                v[q].z = fmaxf(0.2f * v[q].z, v[q].z); v[q].w = fmaxf(0.2f * v[q].w, v[q].w);
-                            }
-                        }
                         C = a.Nout;
                         blk = static_cast<float*>(a.out0) + (rowpix + x0) * C + nb32;
                     } else {                                            // a 32-channel block never straddles the concat split
@@ -577,6 +565,19 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
             // read in the MFMA layout (own pixel m); every lane computes and takes part in the exchange, only loads and stores are predicated
             const int x = x0 + m;
             const bool xok = x < a.W;
+            // forward: bias and max(0.2 v, v) once, in place (packed fp32 add / multiply, v_max without the canonicalising copy fmaxf() gets);
+            // the pooled copy below reuses the finished values
+            if (a.epi == EPI_FWD) {
+                const float sl = a.lrelu ? 0.2f : 1.0f;                  // max(1 v, v) = v
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 bq = *reinterpret_cast<const float4*>(a.bias + nb * BN + tt * 32 + 4 * hi + 8 * q);
+#pragma unroll
+                        for (int r = 0; r < RPW; ++r) bias_lrelu4(acc[r][tt], 4 * q, bq, sl);
+                    }
+            }
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
                 const int y = y0 + wave * RPW + r;                      // wave-uniform
@@ -585,24 +586,13 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
                 const size_t pix = rowpix + (xok ? x : 0);
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) {
-                    const int nb32 = nb * BN + tt * 32, nbase = nb32 + 4 * hi;
+                    const int nb32 = nb * BN + tt * 32;
                     float4 v[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = make_float4(acc[r][tt][4 * q], acc[r][tt][4 * q + 1], acc[r][tt][4 * q + 2], acc[r][tt][4 * q + 3]);
                     float* blk;
                     int C;
                     if (a.epi == EPI_FWD) {
-                        float4 bs[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) bs[q] = *reinterpret_cast<const float4*>(a.bias + nbase + 8 * q);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            v[q].x += bs[q].x; v[q].y += bs[q].y; v[q].z += bs[q].z; v[q].w += bs[q].w;
-                            if (a.lrelu) {
-                                v[q].x = fmaxf(0.2f * v[q].x, v[q].x); v[q].y = fmaxf(0.2f * v[q].y, v[q].y);
-                                v[q].z = fmaxf(0.2f * v[q].z, v[q].z); v[q].w = fmaxf(0.2f * v[q].w, v[q].w);
-                            }
-                        }
                         C = a.Nout;
                         blk = static_cast<float*>(a.out0) + (rowpix + x0) * C + nb32;
                     } else {                                            // a 32-channel block never straddles the concat split
