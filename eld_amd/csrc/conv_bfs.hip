@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfs_kernel(const ConvArgs a) 
                 }
             }
         }
-        if (!(ELD_DBG(a) & 4)) issue_A(j + 2);
+        if (!(ELD_DBG(a) & 4)) issue_A(j + 2);      // (every wave at the top: issuing the SIMD partners' pieces behind the first kernel row, as conv_bfd / conv_bfw do, measured neutral to +2 % here)
         if (chunk == 0) {
 #pragma unroll
             for (int r = 0; r < RPW; ++r)

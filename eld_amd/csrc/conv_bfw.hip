@@ -172,8 +172,8 @@ __global__ __launch_bounds__(512) void conv_bfw_kernel(const ConvArgs a) {
 
     f32x16 acc[RPW][NT];
     // all nine taps of one 16-channel half chunk: 36 MFMAs per wave
-    auto multiply = [&](int j, int chunk, int half) {
-        if (ELD_DBG(a) & 2) return;
+    auto multiply = [&](int j, int chunk, int half, bool late) {
+        if (ELD_DBG(a) & 2) { if (late) issue_A(j + 3); return; }
         const char* la0 = lds + (j & (BFW_NAB - 1)) * A_BYTES + (wave * RPW) * ROWB;
         const char* lw0 = ldsW + chunk * (BFW_WCHUNK / 3) + fw_off[half];      // slab(ky, chunk) at (ky * NCH + chunk) * 12288
 #pragma unroll
@@ -193,6 +193,7 @@ __global__ __launch_bounds__(512) void conv_bfw_kernel(const ConvArgs a) {
                     for (int tt = 0; tt < NT; ++tt)
                         acc[r][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[tt]), __builtin_bit_cast(bf16x8, fx[r]), acc[r][tt], 0, 0, 0);      // D[channel][pixel]
             }
+            if (ky == 0 && late) issue_A(j + 3);
         }
     };
     // epilogue of tile t (layouts: conv_bfd.hip); ac = the saved activations of the tile's pixels in the line layout (ACT)
@@ -277,6 +278,7 @@ __global__ __launch_bounds__(512) void conv_bfw_kernel(const ConvArgs a) {
         // same, profiles/r03_ab_notes.md)
         eld_wait_vmcnt<2 * A_IT>();
         __syncthreads();                         // ... and everybody else's; everybody is done reading ring slot (j - 1) % 4 = (j + 3) % 4
+        const bool late = wave >= 4;             // waves 4-7 (the SIMD partners of 0-3) issue item j+3's pieces behind the first kernel row: see conv_bfd.hip
         if constexpr (ACT) {
             if (last_sub) {
                 // The tile's last item, with the saved activations of its output pixels (line layout) loaded by hand so that the compiler does not
@@ -302,8 +304,8 @@ __global__ __launch_bounds__(512) void conv_bfw_kernel(const ConvArgs a) {
                             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ac[r][tt][i]) : "v"(p) : "memory");
                         }
                 }
-                issue_A(j + 3);
-                multiply(j, chunk, half);
+                if (!late) issue_A(j + 3);
+                multiply(j, chunk, half, late);
                 // (whole 128-bit tuples as operands: see conv_bfs.hip)
                 asm volatile("s_waitcnt vmcnt(%8)"
                              : "+v"(ac[0][0][0]), "+v"(ac[0][0][1]), "+v"(ac[0][1][0]), "+v"(ac[0][1][1]), "+v"(ac[1][0][0]), "+v"(ac[1][0][1]), "+v"(ac[1][1][0]), "+v"(ac[1][1][1])
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(512) void conv_bfw_kernel(const ConvArgs a) {
                 continue;
             }
         }
-        issue_A(j + 3);
+        if (!late) issue_A(j + 3);
         if (sub == 0) {                          // a tile's accumulators start from the bias (0 in the backward launches)
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt)
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(512) void conv_bfw_kernel(const ConvArgs a) {
                     for (int r = 0; r < RPW; ++r) { acc[r][tt][4 * q] = b.x; acc[r][tt][4 * q + 1] = b.y; acc[r][tt][4 * q + 2] = b.z; acc[r][tt][4 * q + 3] = b.w; }
                 }
         }
-        multiply(j, chunk, half);
+        multiply(j, chunk, half, late);
         if constexpr (!ACT) {
             if (last_sub) {
                 u32x4 none[RPW][NT][2];

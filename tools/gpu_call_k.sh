@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/${1:-r03v}; mkdir -p $O
-K="conv_bfw"
-for d in 0 128 0 128; do
+K="${2:-conv_bfd}"
+for d in ${3:-0 256 0 256}; do
 ELD_CONV_DBG=$d bash tools/gpu_kstats.sh $O dev_dbg$d $K bf16 tools/probe/libeld_dev.so
 done
