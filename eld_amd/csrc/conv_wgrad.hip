@@ -386,7 +386,10 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradArgs a) {
     constexpr int COB = 32 * WCO, JBK = 32 * WCI, TPIX = TH * TW, PW = TPIX / WPIX, KSB = PW / 16;
     static_assert(PW % 16 == 0 && PW >= 16, "a wave's pixel slice is a whole number of 16-pixel k-steps");
     constexpr int X_PIX = (TH + 2) * (TW + 2);
-    constexpr int GPL = TPIX * COB, XPL = X_PIX * JBK;                 // elements per piece plane
+    // a 32-channel block of G is padded by one 64-byte row: the staging stores of one pixel's blocks (consecutive lanes) land on different banks
+    // (block planes of TPIX x 64 B are multiples of the 256-byte bank row: 2-way conflicts on every G store without the pad)
+    constexpr int GBLK = TPIX * 32 + (ES == 4 ? 32 : 0);      // (fp32 inputs only: -6 % on the 128 x 64 blocks; the bf16 kernels measured +2...+3 % with the pad)
+    constexpr int GPL = GBLK * WCO, XPL = X_PIX * JBK;                 // elements per piece plane
     constexpr int G_Q = COB / EPU, G_UNITS = TPIX * G_Q, G_IT = G_UNITS / THREADS;
     static_assert(G_UNITS % THREADS == 0 && THREADS % G_Q == 0, "a thread stages the same channel quad of G in every iteration");
     constexpr int X_UNITS1 = X_PIX * XQ, X_IT = (X_UNITS1 + THREADS - 1) / THREADS;     // per 32-channel block of X
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradArgs a) {
     const int g_part = tid % G_Q, g_lp0 = tid / G_Q;
     const int g_px0 = g_lp0 % TW, g_py0 = g_lp0 / TW;
     const unsigned g_off0 = (unsigned)((g_py0 * a.W + g_px0) * a.CA + i0 + g_part * EPU) * (unsigned)ES;
-    const int g_lds0 = (((g_part * EPU) >> 5) * TPIX + g_lp0) * 32 + ((g_part * EPU) & 31);
+    const int g_lds0 = ((g_part * EPU) >> 5) * GBLK + g_lp0 * 32 + ((g_part * EPU) & 31);
     auto g_pxy = [&](int it, int& dpx, int& dpy) {                    // pixel offset of pass `it` relative to (g_px0, g_py0): compile-time
         if (G_STEP >= TW) { dpx = 0; dpy = it * (G_STEP / TW); }
         else { dpx = (it * G_STEP) % TW; dpy = (it * G_STEP) / TW; }   // G_STEP == 16: lp0 < 16, so px0 + dpx < 32 stays in the row
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradArgs a) {
     const int gi = lane & 15, gg = lane >> 4;
     const int lq0 = wpix * PW + 8 * hi + (gi >> 2);
     const int pyq = lq0 / TW, pxq = lq0 - pyq * TW;
-    const bf16_t* gq = ldsG + (wco * TPIX + lq0) * 32 + (gg & 1) * 16 + (gi & 3) * 4;
+    const bf16_t* gq = ldsG + wco * GBLK + lq0 * 32 + (gg & 1) * 16 + (gi & 3) * 4;
     const bf16_t* xq = ldsX + (wci * X_PIX + pyq * (TW + 2) + pxq) * 32 + (gg & 1) * 16 + (gi & 3) * 4;
     auto tr8 = [](const bf16_t* p0) {
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
@@ -622,7 +625,7 @@ static int launch_w8(WgradArgs a, hipStream_t st) {
     constexpr int COB = 32 * WCO, JBK = 32 * WCI;
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + TH - 1) / TH;
-    size_t lds_bytes = (size_t)(TH * TW * COB + (TH + 2) * (TW + 2) * JBK) * (sizeof(T) == 4 ? 6 : 2);
+    size_t lds_bytes = (size_t)((TH * TW * 32 + (sizeof(T) == 4 ? 32 : 0)) * (COB / 32) + (TH + 2) * (TW + 2) * JBK) * (sizeof(T) == 4 ? 6 : 2);
     const size_t red_bytes = (size_t)7 * 16 * 64 * sizeof(float) * 1;       // WPIX-1 <= 7 slices of WCO*WCI*WPIX/... tiles: (WPIX-1)*WCO*WCI <= 7
     if (lds_bytes < red_bytes) lds_bytes = red_bytes;
     const long long blocks = (long long)(a.CA / COB) * (a.CBp / JBK) * a.psplit;
