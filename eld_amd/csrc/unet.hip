@@ -188,6 +188,7 @@ struct Plan {
     size_t wp_fwd[NLAYERS], wp_bwd[NLAYERS];
     size_t x16, ea[NLEV], eb[NLEV], pool[NLEV - 1], up[NLEV - 1], da[NLEV - 1], db[NLEV - 1];
     size_t gA, gB, skip[NLEV - 1], part, part_floats, amax;
+    size_t head_part; // partials of the fused training head (eld_unet_forward_loss_ex -> the backward)
     size_t total;     // floats
 };
 
@@ -224,6 +225,7 @@ int make_plan(Plan& P, int N, int H, int W, int in_ch, int out_ch) {
     }
     P.gA = take(act(0, 32));
     P.gB = take(act(0, 32));
+    P.head_part = take(head_train_ws_floats());
     size_t pmax = head_bwd_ws_floats();
     pmax = pmax > conv_first_wgrad_ws_floats() ? pmax : conv_first_wgrad_ws_floats();
     pmax = pmax > colsum_ws_floats(256) ? pmax : colsum_ws_floats(256);
@@ -321,7 +323,10 @@ struct BucketMarks {
     }
 };
 
-int unet_forward(const Plan& P, const float* x, const float* prm, float* out, float* ws, hipStream_t st) {
+// hl != null: the training step's fused head (output + loss + head backward), see launch_head_train
+struct HeadLoss { const float* target; float* loss; int mse; float grad_scale; };
+
+int unet_forward(const Plan& P, const float* x, const float* prm, float* out, float* ws, hipStream_t st, const HeadLoss* hl = nullptr) {
     const int N = P.N;
     KPartScope kp(ws + P.part, P.part_floats);
     const bool h2 = g_algo == 2;                                 // operand bounds ride along in the workspace
@@ -370,6 +375,9 @@ int unet_forward(const Plan& P, const float* x, const float* prm, float* out, fl
         RC(conv_fwd(ws + P.da[l], chan(l), nullptr, 0, ws + P.wp_fwd[iu + 2], prm + P.L[iu + 2].b_off, ws + P.db[l], N, P.Hl[l], P.Wl[l], chan(l), 1, st));
     }
     const LayerDef& Hd = P.L[L_HEAD];
+    if (hl)      // training step: output, loss, the head's backward and the gradient of conv9_2's output (-> gA) in one pass
+        return launch_head_train(ws + P.db[0], 0, prm + Hd.w_off, prm + Hd.b_off, hl->target, out, ws + P.gA, ws + P.head_part, hl->loss, N, P.H, P.W, P.out_ch,
+                                 hl->mse, hl->grad_scale, st);
     RC(launch_head_fwd(ws + P.db[0], prm + Hd.w_off, prm + Hd.b_off, out, N, P.H, P.W, P.out_ch, st));
     return 0;
 }
@@ -385,7 +393,7 @@ int conv_fwd_bf16(const bf16_t* in0, int C0, const bf16_t* in1, int C1, const bf
     return launch_conv(a, CONV_3X3, st);
 }
 
-int unet_forward_bf16(const Plan& P, const float* x, const float* prm, float* out, float* ws, hipStream_t st) {
+int unet_forward_bf16(const Plan& P, const float* x, const float* prm, float* out, float* ws, hipStream_t st, const HeadLoss* hl = nullptr) {
     const int N = P.N;
     if (P.in_ch > 4) return ELD_ENOTSUP;
     RC(pack_weights(P, prm, ws, false, st, true));
@@ -417,6 +425,9 @@ int unet_forward_bf16(const Plan& P, const float* x, const float* prm, float* ou
         RC(conv_fwd_bf16(B(P.da[l]), chan(l), nullptr, 0, B(P.wp_fwd[iu + 2]), prm + P.L[iu + 2].b_off, B(P.db[l]), N, P.Hl[l], P.Wl[l], chan(l), 1, st));
     }
     const LayerDef& Hd = P.L[L_HEAD];
+    if (hl)
+        return launch_head_train(B(P.db[0]), 1, prm + Hd.w_off, prm + Hd.b_off, hl->target, out, B(P.gA), ws + P.head_part, hl->loss, N, P.H, P.W, P.out_ch,
+                                 hl->mse, hl->grad_scale, st);
     RC(launch_head_fwd_bf16(B(P.db[0]), prm + Hd.w_off, prm + Hd.b_off, out, N, P.H, P.W, P.out_ch, st));
     return 0;
 }
@@ -438,7 +449,8 @@ int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd
     auto BD = [&](int g, int w, int o0, int o1) { if (h2) { g_am.in0 = am + g; g_am.w = am + w; g_am.out0 = am + o0; g_am.out1 = o1 >= 0 ? am + o1 : nullptr; } };
     const LayerDef& Hd = P.L[L_HEAD];
     // head: g (pre-activation grad of conv9_2) -> gA
-    RC(launch_head_bwd(dout, ws + P.db[0], prm + Hd.w_off, gA, grd + Hd.w_off, grd + Hd.b_off, part, N, P.H, P.W, P.out_ch, st));
+    if (dout) RC(launch_head_bwd(dout, ws + P.db[0], prm + Hd.w_off, gA, grd + Hd.w_off, grd + Hd.b_off, part, N, P.H, P.W, P.out_ch, st));
+    else RC(launch_head_train_reduce(ws + P.head_part, grd + Hd.w_off, grd + Hd.b_off, N, P.H, P.W, P.out_ch, 0, st));      // gA and the partials: eld_unet_forward_loss_ex
     RC(marks.done(P, L_HEAD, st));
     if (h2) RC(launch_absmax(gA, (size_t)N * P.H * P.W * 32, am + S_GA, st));
     float* cur = gA; float* oth = gB;
@@ -530,7 +542,8 @@ int unet_backward_bf16(const Plan& P, const float* dout, const float* prm, float
     auto B = [&](size_t off) { return reinterpret_cast<bf16_t*>(ws + off); };
     bf16_t* cur = B(P.gA); bf16_t* oth = B(P.gB); float* part = ws + P.part;
     const LayerDef& Hd = P.L[L_HEAD];
-    RC(launch_head_bwd_bf16(dout, B(P.db[0]), prm + Hd.w_off, cur, grd + Hd.w_off, grd + Hd.b_off, part, N, P.H, P.W, P.out_ch, st));
+    if (dout) RC(launch_head_bwd_bf16(dout, B(P.db[0]), prm + Hd.w_off, cur, grd + Hd.w_off, grd + Hd.b_off, part, N, P.H, P.W, P.out_ch, st));
+    else RC(launch_head_train_reduce(ws + P.head_part, grd + Hd.w_off, grd + Hd.b_off, N, P.H, P.W, P.out_ch, 1, st));
     RC(marks.done(P, L_HEAD, st));
     auto swap = [&]() { bf16_t* t = cur; cur = oth; oth = t; };
     for (int l = 0; l <= 3; ++l) {
@@ -623,13 +636,23 @@ extern "C" int eld_unet_forward_ex(const float* x, const float* params, float* o
     return precision == 1 ? unet_forward_bf16(P, x, params, out, (float*)ws, as_stream(stream)) : unet_forward(P, x, params, out, (float*)ws, as_stream(stream));
 }
 
+extern "C" int eld_unet_forward_loss_ex(const float* x, const float* params, const float* target, float* out, float* loss, void* ws, size_t ws_bytes,
+                                        int N, int H, int W, int in_ch, int out_ch, int precision, int fp32_algo, int loss_kind, float grad_scale, void* stream) {
+    if (N == 0) return 0;
+    if ((precision != 0 && precision != 1) || fp32_algo > 2 || (loss_kind != 0 && loss_kind != 1) || !target || !loss) return ELD_EINVAL;
+    Plan P;
+    RC(unet_entry_checks(P, x, params, out, ws, ws_bytes, N, H, W, in_ch, out_ch));
+    AlgoScope scope(fp32_algo);
+    const HeadLoss hl = {target, loss, loss_kind, grad_scale};
+    return precision == 1 ? unet_forward_bf16(P, x, params, out, (float*)ws, as_stream(stream), &hl) : unet_forward(P, x, params, out, (float*)ws, as_stream(stream), &hl);
+}
 extern "C" int eld_unet_backward_ex(const float* dout, const float* params, float* grads, void* ws, size_t ws_bytes, int N, int H, int W,
                                     int in_ch, int out_ch, int precision, int fp32_algo, const int64_t* bucket_start, void* const* bucket_event,
                                     int n_buckets, void* stream) {
     if (N == 0) return 0;
     if ((precision != 0 && precision != 1) || fp32_algo > 2) return ELD_EINVAL;
     Plan P;
-    RC(unet_entry_checks(P, dout, params, grads, ws, ws_bytes, N, H, W, in_ch, out_ch));
+    RC(unet_entry_checks(P, dout ? (const void*)dout : (const void*)params, params, grads, ws, ws_bytes, N, H, W, in_ch, out_ch));      // dout == NULL: the head's share was done by eld_unet_forward_loss_ex
     if (n_buckets < 0 || (n_buckets > 0 && (!bucket_start || !bucket_event))) return ELD_EINVAL;
     for (int k = 0; k < n_buckets; ++k)
         if (!bucket_event[k] || bucket_start[k] < 0 || (k > 0 && bucket_start[k] <= bucket_start[k - 1]) || (size_t)bucket_start[k] >= P.nparams) return ELD_EINVAL;

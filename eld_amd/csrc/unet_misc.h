@@ -11,6 +11,11 @@ int launch_head_fwd(const float* in, const float* w, const float* b, float* out,
 size_t head_bwd_ws_floats();
 int launch_head_bwd(const float* dout, const float* act, const float* w, float* g, float* dw, float* db, float* part,
                     int N, int H, int W, int OC, hipStream_t st);
+// fused training head (forward + loss + backward in one pass over conv9_2's output): see unet_misc.hip
+size_t head_train_ws_floats();
+int launch_head_train(const void* act, int bf16, const float* w, const float* b, const float* tgt, float* out, void* g, float* part, float* loss,
+                      int N, int H, int W, int OC, int mse, float grad_scale, hipStream_t st);
+int launch_head_train_reduce(const float* part, float* dw, float* db, int N, int H, int W, int OC, int bf16, hipStream_t st);
 size_t colsum_ws_floats(int C);
 int launch_colsum(const float* x, float* out, float* part, size_t P, int C, hipStream_t st);
 int launch_colsum_reduce(const float* part, float* out, int nblocks, int C, hipStream_t st);

@@ -115,41 +115,70 @@ int launch_maxpool_bwd(const float* act, const float* dp, const float* skip, flo
 // ------------------------------------------------------------------------------------------------
 // conv10_1: 1x1, 32 -> OC (<= 4), no activation; NHWC in, NCHW out (Unet.py:46,88)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ b,
-                                                       float* __restrict__ out, int N, size_t HW, int OC) {
-    __shared__ float sw[4 * 32 + 4];
-    for (int i = threadIdx.x; i < 4 * 32 + 4; i += 256) {
-        float v = 0.f;
-        if (i < 128) { if (i / 32 < OC) v = w[i]; } else if (i - 128 < OC) v = b[i - 128];
-        sw[i] = v;
+// LPP lanes per pixel (8 x 4 fp32 channels / 4 x 8 bf16 channels: a wave reads whole pixels, 1 KiB contiguous per instruction); the 32-channel sum
+// is formed as per-lane fma chains + a butterfly over the pixel's lanes -- the SAME order as the fused training head (head_train_kernel), so the
+// inference output and the training step's output are the same bits.
+__device__ __forceinline__ float quad_xor_add(float v, int xor2) {
+    const int i = __float_as_int(v);
+    return v + __int_as_float(xor2 ? __builtin_amdgcn_update_dpp(0, i, 0x4E, 0xF, 0xF, true) : __builtin_amdgcn_update_dpp(0, i, 0xB1, 0xF, 0xF, true));
+}
+// out[o] - b[o] for the pixel whose CPL channels av[] this lane holds (wq[o][j] = W[o][CPL cq + j]); every lane of the pixel returns the same bits
+template <int CPL>
+__device__ __forceinline__ void head_dot(const float (&av)[CPL], const float (&wq)[4][CPL], float (&po)[4]) {
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) sacc = fmaf(av[j], wq[o][j], sacc);
+        sacc = quad_xor_add(sacc, 0);
+        sacc = quad_xor_add(sacc, 1);
+        if (CPL == 4) sacc += __shfl_xor(sacc, 4, 64);
+        po[o] = sacc;
     }
-    __syncthreads();
+}
+template <typename T, int CPL>
+__device__ __forceinline__ void head_load(const T* act, size_t pc, int cq, float (&av)[CPL]) {
+    if constexpr (sizeof(T) == 4) {
+        const float4 a4 = reinterpret_cast<const float4*>(act + pc * 32)[cq];
+        av[0] = a4.x; av[1] = a4.y; av[2] = a4.z; av[3] = a4.w;
+    } else {
+        const uint4 a4 = reinterpret_cast<const uint4*>(act + pc * 32)[cq];
+        const float4 lo = unpack_bf4(make_uint2(a4.x, a4.y)), hi4 = unpack_bf4(make_uint2(a4.z, a4.w));
+        av[0] = lo.x; av[1] = lo.y; av[2] = lo.z; av[3] = lo.w; av[4] = hi4.x; av[5] = hi4.y; av[6] = hi4.z; av[7] = hi4.w;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ in, const float* __restrict__ w, const float* __restrict__ b,
+                                                       float* __restrict__ out, int N, size_t HW, int OC) {
+    constexpr int CPL = sizeof(T) == 4 ? 4 : 8, LPP = 32 / CPL, PPB = 256 / LPP;
+    const int tid = threadIdx.x, cq = tid & (LPP - 1), o_ld = tid & 3;
+    float wq[4][CPL];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) wq[o][j] = o < OC ? w[o * 32 + CPL * cq + j] : 0.f;
+    const float bo = o_ld < OC ? b[o_ld] : 0.f;
     const size_t total = (size_t)N * HW;
-    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
-        const float4* src = reinterpret_cast<const float4*>(in + p * 32);
-        float acc[4] = {sw[128], sw[129], sw[130], sw[131]};
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float4 v = src[k];
-#pragma unroll
-            for (int o = 0; o < 4; ++o) {
-                acc[o] = fmaf(v.x, sw[o * 32 + 4 * k], acc[o]);
-                acc[o] = fmaf(v.y, sw[o * 32 + 4 * k + 1], acc[o]);
-                acc[o] = fmaf(v.z, sw[o * 32 + 4 * k + 2], acc[o]);
-                acc[o] = fmaf(v.w, sw[o * 32 + 4 * k + 3], acc[o]);
-            }
-        }
-        const size_t n = p / HW, q = p - n * HW;
-#pragma unroll
-        for (int o = 0; o < 4; ++o)
-            if (o < OC) out[(n * OC + o) * HW + q] = acc[o];
+    const size_t stride = (size_t)gridDim.x * PPB;
+    size_t p = (size_t)blockIdx.x * PPB + (tid / LPP);
+    const size_t iters = (total + stride - 1) / stride;               // every lane of a pixel group runs the same trip count (the exchanges need its mates)
+    for (size_t itn = 0; itn < iters; ++itn, p += stride) {
+        const bool ok = p < total;
+        const size_t pc = ok ? p : total - 1;
+        float av[CPL], po[4];
+        head_load<T, CPL>(in, pc, cq, av);
+        head_dot<CPL>(av, wq, po);
+        const float mine = (o_ld == 0 ? po[0] : (o_ld == 1 ? po[1] : (o_ld == 2 ? po[2] : po[3]))) + bo;
+        const size_t n = pc / HW, q = pc - n * HW;
+        if (ok && cq < 4 && o_ld < OC) out[(n * OC + o_ld) * HW + q] = mine;
     }
 }
 
 int launch_head_fwd(const float* in, const float* w, const float* b, float* out, int N, int H, int W, int OC, hipStream_t st) {
     const size_t total = (size_t)N * H * W;
     if (!total) return 0;
-    ELD_LAUNCH(head_fwd_kernel, dim3((unsigned)min((total + 255) / 256, (size_t)16384)), dim3(256), 0, st, in, w, b, out, N, (size_t)H * W, OC);
+    ELD_LAUNCH(head_fwd_kernel<float>, dim3((unsigned)min((total + 31) / 32, (size_t)16384)), dim3(256), 0, st, in, w, b, out, N, (size_t)H * W, OC);
     ELD_LAUNCH_CHECK();
     return 0;
 }
@@ -623,40 +652,10 @@ int launch_maxpool_fwd_bf16(const bf16_t* in, bf16_t* out, int N, int Ho, int Wo
     return 0;
 }
 
-__global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const bf16_t* __restrict__ in, const float* __restrict__ w, const float* __restrict__ b,
-                                                            float* __restrict__ out, int N, size_t HW, int OC) {
-    __shared__ float sw[4 * 32 + 4];
-    for (int i = threadIdx.x; i < 4 * 32 + 4; i += 256) {
-        float v = 0.f;
-        if (i < 128) { if (i / 32 < OC) v = w[i]; } else if (i - 128 < OC) v = b[i - 128];
-        sw[i] = v;
-    }
-    __syncthreads();
-    const size_t total = (size_t)N * HW;
-    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (size_t)gridDim.x * blockDim.x) {
-        const uint4* src = reinterpret_cast<const uint4*>(in + p * 32);
-        float acc[4] = {sw[128], sw[129], sw[130], sw[131]};
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint4 q = src[k];                                   // 8 channels
-            const float4 lo = unpack_bf4(make_uint2(q.x, q.y)), hi4 = unpack_bf4(make_uint2(q.z, q.w));
-            const float vv[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
-#pragma unroll
-            for (int o = 0; o < 4; ++o)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[o] = fmaf(vv[j], sw[o * 32 + 8 * k + j], acc[o]);
-        }
-        const size_t n = p / HW, qq = p - n * HW;
-#pragma unroll
-        for (int o = 0; o < 4; ++o)
-            if (o < OC) out[(n * OC + o) * HW + qq] = acc[o];
-    }
-}
-
 int launch_head_fwd_bf16(const bf16_t* in, const float* w, const float* b, float* out, int N, int H, int W, int OC, hipStream_t st) {
     const size_t total = (size_t)N * H * W;
     if (!total) return 0;
-    ELD_LAUNCH(head_fwd_bf16_kernel, dim3((unsigned)min((total + 255) / 256, (size_t)16384)), dim3(256), 0, st, in, w, b, out, N, (size_t)H * W, OC);
+    ELD_LAUNCH(head_fwd_kernel<bf16_t>, dim3((unsigned)min((total + 63) / 64, (size_t)16384)), dim3(256), 0, st, in, w, b, out, N, (size_t)H * W, OC);
     ELD_LAUNCH_CHECK();
     return 0;
 }
@@ -816,6 +815,136 @@ int launch_colsum_bf16(const bf16_t* x, float* out, float* part, size_t P, int C
     ELD_LAUNCH(colsum_bf16_kernel, dim3(nb), dim3(256), 0, st, x, part, P, C);
     ELD_LAUNCH_CHECK();
     ELD_LAUNCH(colsum_reduce_kernel, dim3((C + 63) / 64), dim3(1024), 0, st, part, out, nb, C);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Fused training head: conv10_1 forward (Unet.py:46,88) + nn.L1Loss / nn.MSELoss (models/losses.py:30-34) + the head's backward in ONE pass over
+// conv9_2's output.  The three separate kernels read that 32-channel full-resolution tensor twice and move the output gradient through HBM
+// (head_fwd, l1_kernel, head_bwd: 1.34 ms per 8-frame bf16 step); here every pixel is read once:
+//      out[o]  = b[o] + sum_c W[o][c] act[c]                     (written: NCHW fp32, the network's output)
+//      d[o]    = dLoss/dout[o] from (out[o] - target[o])          (sign * gscale for L1, 2 * diff * gscale for MSE; never stored)
+//      g[c]    = (sum_o W[o][c] d[o]) * slope(act[c])             (written: gradient of conv9_2's pre-activation output)
+//      dW, db, loss: per-block partials -> head_bwd_reduce_kernel / l1_reduce_kernel (fixed order)
+// Layouts as head_bwd_kernel: LPP lanes per pixel (8 x 4 fp32 channels / 4 x 8 bf16 channels), lane o of each quad owns output plane o.
+// The forward sum is head_fwd_kernel's (per-lane fma chains + a butterfly over the pixel's lanes): the output equals the unfused path's bit for bit;
+// the loss differs from l1_kernel's in the order of its partial sums only.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int MSE>
+__global__ __launch_bounds__(256) void head_train_kernel(const T* __restrict__ act, const float* __restrict__ w, const float* __restrict__ b,
+                                                         const float* __restrict__ tgt, float* __restrict__ out, T* __restrict__ g, float* __restrict__ part,
+                                                         float* __restrict__ lpart, int N, size_t HW, int OC, float gscale) {
+    constexpr int CPL = sizeof(T) == 4 ? 4 : 8, LPP = 32 / CPL, PPB = 256 / LPP;      // channels per lane, lanes per pixel, pixels per block pass
+    __shared__ float red[4][133];
+    const int tid = threadIdx.x, cq = tid & (LPP - 1), o_ld = tid & 3;
+    float wq[4][CPL];                                 // w[o][CPL cq + j]
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) wq[o][j] = o < OC ? w[o * 32 + CPL * cq + j] : 0.f;
+    const float bo = o_ld < OC ? b[o_ld] : 0.f;
+    float dw[4][CPL];
+    float db = 0.f, ls = 0.f;                         // lanes with cq < 4 sum plane o_ld = cq
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) dw[o][j] = 0.f;
+    const size_t total = (size_t)N * HW;
+    const size_t stride = (size_t)gridDim.x * PPB;
+    size_t p = (size_t)blockIdx.x * PPB + (tid / LPP);
+    const size_t iters = (total + stride - 1) / stride;               // every lane of a pixel group runs the same trip count (the exchanges need its mates)
+    for (size_t itn = 0; itn < iters; ++itn, p += stride) {
+        const bool ok = p < total;
+        const size_t pc = ok ? p : total - 1;
+        const size_t n = pc / HW, q = pc - n * HW;
+        float av[CPL], po[4];
+        head_load<T, CPL>(act, pc, cq, av);
+        head_dot<CPL>(av, wq, po);                   // forward (the order of head_fwd_kernel: same bits)
+        const float mine = (o_ld == 0 ? po[0] : (o_ld == 1 ? po[1] : (o_ld == 2 ? po[2] : po[3]))) + bo;
+        // loss and its gradient on this lane's plane
+        float dl = 0.f;
+        if (ok && o_ld < OC) {
+            const size_t idx = (n * OC + o_ld) * HW + q;
+            const float diff = mine - tgt[idx];
+            if (cq < 4) { out[idx] = mine; ls += MSE ? diff * diff : fabsf(diff); }
+            dl = MSE ? 2.0f * diff * gscale : (diff > 0.f ? gscale : (diff < 0.f ? -gscale : 0.f));
+        }
+        if (cq < 4) db += dl;
+        float d[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) d[o] = quad_bcast(dl, o);
+        if (!ok) continue;
+        // backward
+        float gv[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) { sacc = fmaf(wq[o][j], d[o], sacc); dw[o][j] = fmaf(d[o], av[j], dw[o][j]); }
+            gv[j] = sacc * lrelu_slope(av[j]);
+        }
+        if constexpr (sizeof(T) == 4) reinterpret_cast<float4*>(g + pc * 32)[cq] = make_float4(gv[0], gv[1], gv[2], gv[3]);
+        else {
+            const uint2 g0 = pack_bf4(make_float4(gv[0], gv[1], gv[2], gv[3])), g1 = pack_bf4(make_float4(gv[4], gv[5], gv[6], gv[7]));
+            reinterpret_cast<uint4*>(g + pc * 32)[cq] = make_uint4(g0.x, g0.y, g1.x, g1.y);
+        }
+    }
+    // block reduction in a fixed order: lanes sharing a channel group by xor-shuffles, then the 4 waves through LDS
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            float v = dw[o][j];
+            for (int off = LPP; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+            if (lane < LPP) red[wave][o * 32 + CPL * lane + j] = v;
+        }
+    {
+        float v = db;
+        for (int off = LPP; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+        if (lane < 4) red[wave][128 + lane] = v;
+        float l = ls;
+        for (int off = 1; off < 64; off <<= 1) l += __shfl_xor(l, off, 64);
+        if (lane == 0) red[wave][132] = l;
+    }
+    __syncthreads();
+    if (tid < 132) part[(size_t)blockIdx.x * 132 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    if (tid == 132) lpart[blockIdx.x] = red[0][132] + red[1][132] + red[2][132] + red[3][132];
+}
+
+size_t head_train_ws_floats() { return (size_t)HEAD_BLOCKS * 133; }
+static int head_train_blocks(size_t total, int bf16) { return (int)min((total + (bf16 ? 63 : 31)) / (bf16 ? 64 : 32), (size_t)HEAD_BLOCKS); }
+
+// part: head_train_ws_floats() floats that must survive until launch_head_train_reduce (the backward) has run
+int launch_head_train(const void* act, int bf16, const float* w, const float* b, const float* tgt, float* out, void* g, float* part, float* loss,
+                      int N, int H, int W, int OC, int mse, float grad_scale, hipStream_t st) {
+    const size_t total = (size_t)N * H * W;
+    if (!total) return ELD_EINVAL;
+    const int nb = head_train_blocks(total, bf16);
+    float* lpart = part + (size_t)HEAD_BLOCKS * 132;
+    const float n = (float)(total * (size_t)OC);
+    const float gs = grad_scale / n;
+    const size_t HW = (size_t)H * W;
+    if (bf16) {
+        if (mse) { ELD_LAUNCH((head_train_kernel<bf16_t, 1>), dim3(nb), dim3(256), 0, st, (const bf16_t*)act, w, b, tgt, out, (bf16_t*)g, part, lpart, N, HW, OC, gs); }
+        else { ELD_LAUNCH((head_train_kernel<bf16_t, 0>), dim3(nb), dim3(256), 0, st, (const bf16_t*)act, w, b, tgt, out, (bf16_t*)g, part, lpart, N, HW, OC, gs); }
+    } else {
+        if (mse) { ELD_LAUNCH((head_train_kernel<float, 1>), dim3(nb), dim3(256), 0, st, (const float*)act, w, b, tgt, out, (float*)g, part, lpart, N, HW, OC, gs); }
+        else { ELD_LAUNCH((head_train_kernel<float, 0>), dim3(nb), dim3(256), 0, st, (const float*)act, w, b, tgt, out, (float*)g, part, lpart, N, HW, OC, gs); }
+    }
+    ELD_LAUNCH_CHECK();
+    ELD_LAUNCH(l1_reduce_kernel, dim3(1), dim3(256), 0, st, lpart, loss, nb, 1.0f / n);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
+// the head's dW / db from the partials launch_head_train left in `part`
+int launch_head_train_reduce(const float* part, float* dw, float* db, int N, int H, int W, int OC, int bf16, hipStream_t st) {
+    const size_t total = (size_t)N * H * W;
+    if (!total) return 0;
+    ELD_LAUNCH(head_bwd_reduce_kernel, dim3((132 + 15) / 16), dim3(256), 0, st, part, dw, db, head_train_blocks(total, bf16), OC);
     ELD_LAUNCH_CHECK();
     return 0;
 }

@@ -136,6 +136,8 @@ class ELDModel:
             self.optimizers = [self.optimizer_G]
             self.schedulers = []
         self._l1_ws = torch.empty(L.lib().eld_l1_workspace_bytes(), dtype=torch.uint8, device=self.device)
+        # last layer + loss + the head's backward as one pass over conv9_2's output (eld_unet_forward_loss_ex); ELD_FUSED_HEAD=0: the three separate kernels
+        self.fused_head = os.environ.get('ELD_FUSED_HEAD', '1') != '0'
         self._loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.noise_model = NoiseModel.last_instance      # the plugin instance the entry script built (train_syn.py:38); may be None
         self._sample_counter = 0
@@ -262,15 +264,23 @@ class ELDModel:
     def optimize_parameters(self, **kwargs):
         net, opt = self.netG, self.optimizer_G
         x = self.input.contiguous().float()
-        out, key, _ = net._engine_forward(x, save=True, bf16=net.train_precision == 'bf16')      # forward()
-        self.output = out
-        dout = torch.empty_like(out)
         tgt = self.target.contiguous().float()            # a float64 / half target (custom datasets) must not reach the float4 loads
-        if tgt.shape != out.shape:
-            raise RuntimeError('target shape %s does not match the network output %s' % (tuple(tgt.shape), tuple(out.shape)))
-        loss_fn = L.lib().eld_mse_loss if self.loss_name == 'l2' else L.lib().eld_l1_loss
-        L.check(loss_fn(L.dptr(out), L.dptr(tgt), L.dptr(dout), L.dptr(self._loss_buf), L.dptr(self._l1_ws),
-                        out.numel(), 1.0, L.cur_stream()), 'eld_%s_loss' % self.loss_name)      # backward_G(): loss + its gradient
+        if self.fused_head:
+            # forward() + the loss of backward_G() with the last layer, the loss and the head's backward in one pass (eld_unet_forward_loss_ex)
+            if tuple(tgt.shape) != (x.shape[0], net.out_channels, x.shape[2], x.shape[3]):
+                raise RuntimeError('target shape %s does not match the network output %s' % (tuple(tgt.shape), (x.shape[0], net.out_channels, x.shape[2], x.shape[3])))
+            out, key, _ = net._engine_forward_loss(x, tgt, self._loss_buf, bf16=net.train_precision == 'bf16', mse=self.loss_name == 'l2')
+            self.output = out
+            dout = None
+        else:
+            out, key, _ = net._engine_forward(x, save=True, bf16=net.train_precision == 'bf16')      # forward()
+            self.output = out
+            dout = torch.empty_like(out)
+            if tgt.shape != out.shape:
+                raise RuntimeError('target shape %s does not match the network output %s' % (tuple(tgt.shape), tuple(out.shape)))
+            loss_fn = L.lib().eld_mse_loss if self.loss_name == 'l2' else L.lib().eld_l1_loss
+            L.check(loss_fn(L.dptr(out), L.dptr(tgt), L.dptr(dout), L.dptr(self._loss_buf), L.dptr(self._l1_ws),
+                            out.numel(), 1.0, L.cur_stream()), 'eld_%s_loss' % self.loss_name)      # backward_G(): loss + its gradient
         if not self.exchange:
             net._engine_backward(dout, key, tuple(x.shape), grads=opt.grads)
             w = 1

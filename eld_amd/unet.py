@@ -142,14 +142,41 @@ class UNetSeeInDark(nn.Module):
                                             N, H, W, self.in_channels, self.out_channels, 1 if bf16 else 0, algo, L.cur_stream()), 'eld_unet_forward_ex')
         return out, key, self._ws.gen[key]
 
+    def _engine_forward_loss(self, x, target, loss_buf, bf16=False, mse=False, grad_scale=1.0):
+        """The training forward with the loss fused into the head (include/eld_amd.h eld_unet_forward_loss_ex): returns (out, key, generation);
+        the mean loss lands in loss_buf (a 1-element CUDA float tensor).  The matching backward is _engine_backward(None, key, shape)."""
+        if not x.is_cuda:
+            raise RuntimeError('eld_amd U-Net runs on the GPU only (no CPU fallback); got a CPU tensor')
+        x = x.contiguous().float()
+        target = target.contiguous().float()
+        N, Cc, H, W = x.shape
+        if Cc != self.in_channels:
+            raise RuntimeError('expected %d input channels, got %d' % (self.in_channels, Cc))
+        if H % 16 or W % 16:
+            raise RuntimeError('U-Net input H, W must be multiples of 16 (4 pooling levels), got %dx%d' % (H, W))
+        if tuple(target.shape) != (N, self.out_channels, H, W) or not target.is_cuda:
+            raise RuntimeError('target must be a CUDA tensor of shape %s, got %s' % ((N, self.out_channels, H, W), tuple(target.shape)))
+        nbytes = L.lib().eld_unet_workspace_bytes(N, H, W, self.in_channels, self.out_channels)
+        key = ('train_bf16' if bf16 else 'train', N, H, W)
+        ws = self._ws.get(key, nbytes, x.device)
+        self._ws.gen[key] += 1
+        out = torch.empty((N, self.out_channels, H, W), dtype=torch.float32, device=x.device)
+        algo = self.fp32_products if self.fp32_products is not None else L.lib().eld_conv_fp32_algo(-1)
+        self._ws.algo[key] = algo
+        L.check(L.lib().eld_unet_forward_loss_ex(L.dptr(x), L.dptr(self.flat_params), L.dptr(target), L.dptr(out), L.dptr(loss_buf), L.dptr(ws), ws.numel(),
+                                                 N, H, W, self.in_channels, self.out_channels, 1 if bf16 else 0, algo, 1 if mse else 0, float(grad_scale),
+                                                 L.cur_stream()), 'eld_unet_forward_loss_ex')
+        return out, key, self._ws.gen[key]
+
     def _engine_backward(self, dout, key, shape, grads=None, buckets=None):
-        """buckets: eld_amd.dist.GradBuckets -- record one event per gradient bucket as soon as it is final (data-parallel overlap)."""
+        """buckets: eld_amd.dist.GradBuckets -- record one event per gradient bucket as soon as it is final (data-parallel overlap).
+        dout = None: the forward was _engine_forward_loss (the head's share of the backward is already in the workspace)."""
         N, _, H, W = shape
         ws = self._ws.bufs[key]
         if grads is None:
-            grads = torch.empty(self._offsets[-1], dtype=torch.float32, device=dout.device)
+            grads = torch.empty(self._offsets[-1], dtype=torch.float32, device=ws.device)
         starts, events, nb = (buckets.starts_c, buckets.events_c, buckets.n) if buckets is not None else (None, None, 0)
-        L.check(L.lib().eld_unet_backward_ex(L.dptr(dout), L.dptr(self.flat_params), L.dptr(grads), L.dptr(ws), ws.numel(), N, H, W,
+        L.check(L.lib().eld_unet_backward_ex(L.dptr(dout) if dout is not None else None, L.dptr(self.flat_params), L.dptr(grads), L.dptr(ws), ws.numel(), N, H, W,
                                              self.in_channels, self.out_channels, 1 if key[0] == 'train_bf16' else 0, self._ws.algo[key],
                                              starts, events, nb, L.cur_stream()), 'eld_unet_backward_ex')
         return grads

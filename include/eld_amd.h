@@ -175,6 +175,14 @@ int eld_unet_backward_buckets(const float* dout, const float* params, float* gra
                               int N, int H, int W, int in_ch, int out_ch, int precision,
                               const int64_t* bucket_start, void* const* bucket_event, int n_buckets, void* stream);
 
+/* Training forward with the loss fused into the head (ELD_model.py:469-475: forward() + backward_G()'s loss): as eld_unet_forward_ex with the
+ * activations kept for the backward, but the last layer (conv10_1, Unet.py:46,88), the loss against `target` (loss_kind 0: nn.L1Loss, 1:
+ * nn.MSELoss, models/losses.py:30-34; mean over all elements, written to *loss on the device) and the head's own backward run as ONE pass over
+ * conv9_2's output: `out` is written, the output gradient never touches memory, the gradient of conv9_2's output and the head's weight-gradient
+ * partials stay in the workspace.  Follow with eld_unet_backward_ex(dout = NULL, same workspace, same shape / precision), which finishes the
+ * head's dW / db and runs the rest of the backward.  grad_scale multiplies dLoss/dout (1 for a plain mean loss). */
+int eld_unet_forward_loss_ex(const float* x, const float* params, const float* target, float* out, float* loss, void* ws, size_t ws_bytes,
+                             int N, int H, int W, int in_ch, int out_ch, int precision, int fp32_algo, int loss_kind, float grad_scale, void* stream);
 /* The same two calls with everything per call: precision 0 = fp32 / 1 = bf16 activations; fp32_algo names the fp32 product
  * scheme (see eld_conv_fp32_algo below; < 0 = the process default); n_buckets may be 0.  A backward must name the scheme its
  * forward ran with: scheme 2 leaves operand bounds in the workspace that only a scheme-2 backward reads. */

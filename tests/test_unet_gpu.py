@@ -527,3 +527,36 @@ def test_unet_full_frame_properties(lib):
         assert float((head_bias - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-9
     finally:
         lib.eld_conv_fp32_algo(prev)
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+@pytest.mark.parametrize('mse', [False, True], ids=['l1', 'mse'])
+def test_fused_head_equals_the_three_kernel_path(lib, prec, mse):
+    """eld_unet_forward_loss_ex (last layer + nn.L1Loss / nn.MSELoss + the head's backward as ONE pass over conv9_2's output, ELD_model.py:469-475,
+    models/losses.py:30-34) against eld_unet_forward_ex + eld_l1_loss / eld_mse_loss + eld_unet_backward_ex on the same activations: the fused
+    kernel forms the 32-channel sum, the loss gradient and the weight-gradient partials in the order of the separate kernels, so the output and
+    EVERY gradient must be the same bits; only the loss value (a different order of partial sums) is compared with a tolerance (2e-6 relative)."""
+    from eld_amd.unet import UNetSeeInDark
+    from eld_amd import _lib as L
+    torch.manual_seed(11)
+    net = UNetSeeInDark(4, 4).cuda()
+    bf16 = prec == 'bf16'
+    g = torch.Generator(device='cuda').manual_seed(3)
+    shape = (2, 4, 272, 560)
+    x = torch.rand(*shape, device='cuda', generator=g)
+    t = torch.rand(*shape, device='cuda', generator=g)
+    out0, key, _ = net._engine_forward(x, save=True, bf16=bf16)
+    out0 = out0.clone()
+    dout = torch.empty_like(out0)
+    loss0 = torch.zeros(1, device='cuda')
+    ws = torch.empty(lib.eld_l1_workspace_bytes(), dtype=torch.uint8, device='cuda')
+    fn = lib.eld_mse_loss if mse else lib.eld_l1_loss
+    L.check(fn(L.dptr(out0), L.dptr(t), L.dptr(dout), L.dptr(loss0), L.dptr(ws), out0.numel(), 1.0, L.cur_stream()), 'loss')
+    g0 = net._engine_backward(dout, key, shape).clone()
+    loss1 = torch.zeros(1, device='cuda')
+    out1, key, _ = net._engine_forward_loss(x, t, loss1, bf16=bf16, mse=mse)
+    g1 = net._engine_backward(None, key, shape).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(out1, out0)
+    assert abs(float(loss1) - float(loss0)) <= 2e-6 * abs(float(loss0))
+    assert torch.equal(g1, g0)
