@@ -94,7 +94,7 @@ def unet_roofline(model, B, Hh, Ww, precision, dev, traffic):
     if traffic and full_frame and key in traffic:
         tr = round(traffic[key] * B / traffic.get('frames_per_pass', 1))
     if precision == 'bf16':
-        kern = 'conv_bfd_kernel / conv_igemm_kernel<bf16> fwd + bwd-data, wgrad8_kernel<bf16>: bf16 operands, v_mfma_f32_32x32x16_bf16, fp32 accumulate'
+        kern = 'conv_bfd / conv_bfw / conv_bfs / conv_bfg kernels fwd + bwd-data, wgrad8_kernel<bf16>: bf16 operands, v_mfma_f32_32x32x16_bf16, fp32 accumulate'
         note = 'bf16 dense MFMA peak 2500 TFLOP/s (MI355X_MICROARCH.md)'
     elif x3:
         kern = 'conv_x3d_kernel / conv_x3_kernel fwd + bwd-data, wgrad8_kernel: fp32 operands as 3 bf16 pieces, 6 x v_mfma_f32_32x32x16_bf16 per k-block'

@@ -5,4 +5,4 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out/${1:-full}; mkdir -p $O
 ( time timeout 1500 python -m pytest tests -m gpu -q ) > $O/pytest.log 2>&1
 grep -n "passed\|failed" $O/pytest.log | tail -2
-timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; cut -c1-300 $O/bench.json; tail -2 $O/bench.err
+python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" > $O/smoke.log 2>&1; tail -1 $O/smoke.log; timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; cut -c1-300 $O/bench.json; tail -2 $O/bench.err
