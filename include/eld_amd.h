@@ -185,7 +185,8 @@ int eld_unet_forward_loss_ex(const float* x, const float* params, const float* t
                              int N, int H, int W, int in_ch, int out_ch, int precision, int fp32_algo, int loss_kind, float grad_scale, void* stream);
 /* The same two calls with everything per call: precision 0 = fp32 / 1 = bf16 activations; fp32_algo names the fp32 product
  * scheme (see eld_conv_fp32_algo below; < 0 = the process default); n_buckets may be 0.  A backward must name the scheme its
- * forward ran with: scheme 2 leaves operand bounds in the workspace that only a scheme-2 backward reads. */
+ * forward ran with: scheme 2 leaves operand bounds in the workspace that only a scheme-2 backward reads.
+ * eld_unet_backward_ex accepts dout == NULL when (and only when) the forward on this workspace was eld_unet_forward_loss_ex. */
 int eld_unet_forward_ex(const float* x, const float* params, float* out, void* ws, size_t ws_bytes,
                         int N, int H, int W, int in_ch, int out_ch, int precision, int fp32_algo, void* stream);
 int eld_unet_backward_ex(const float* dout, const float* params, float* grads, void* ws, size_t ws_bytes,

@@ -560,3 +560,28 @@ def test_fused_head_equals_the_three_kernel_path(lib, prec, mse):
     assert torch.equal(out1, out0)
     assert abs(float(loss1) - float(loss0)) <= 2e-6 * abs(float(loss0))
     assert torch.equal(g1, g0)
+
+
+def test_forward_loss_argument_checks(lib):
+    """eld_unet_forward_loss_ex rejects what it cannot run (include/eld_amd.h): a missing target / loss pointer, an unknown loss kind, a workspace
+    that is too small -- error codes, no launch."""
+    from eld_amd.unet import UNetSeeInDark
+    from eld_amd import _lib as L
+    net = UNetSeeInDark(4, 4).cuda()
+    N, H, W = 1, 64, 64
+    x = torch.rand(N, 4, H, W, device='cuda')
+    t = torch.rand(N, 4, H, W, device='cuda')
+    out = torch.empty_like(x)
+    loss = torch.zeros(1, device='cuda')
+    nbytes = lib.eld_unet_workspace_bytes(N, H, W, 4, 4)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+
+    def call(target, lossp, wsbytes, kind):
+        return lib.eld_unet_forward_loss_ex(L.dptr(x), L.dptr(net.flat_params), target, L.dptr(out), lossp, L.dptr(ws), wsbytes, N, H, W, 4, 4, 0, 1, kind, 1.0,
+                                            L.cur_stream())
+    assert call(L.dptr(t), L.dptr(loss), nbytes, 0) == 0
+    assert call(None, L.dptr(loss), nbytes, 0) != 0
+    assert call(L.dptr(t), None, nbytes, 0) != 0
+    assert call(L.dptr(t), L.dptr(loss), nbytes, 2) != 0
+    assert call(L.dptr(t), L.dptr(loss), nbytes // 2, 0) != 0
+    torch.cuda.synchronize()
