@@ -117,11 +117,158 @@ __global__ __launch_bounds__(256) void conv_first_fwd_kernel(const float* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The 4-channel first layer on the bf16 MFMA.  K is laid out as 3 kernel rows x (4 horizontal slots x 4 channels) = 48 = three 16-k blocks,
+// slot 3 carrying zero weights: a lane's B operand of a block (its pixel m, k-half hi) is then the 16 contiguous bytes of halo pixels
+// m + 2hi and m + 2hi + 1 in a [pixel][4 channels] bf16 plane -- one 8-byte-aligned read, no gather.  fp32 values enter as exact bf16
+// pieces (NPC = 3: the three-piece cut of conv_x3.hip, six products, fp32-exact; NPC = 2 for the bf16 network: two pieces, three
+// products, 2^-16), cut ONCE per halo pixel while the tile is staged.  9 (18) MFMAs of 32 cycles per row of 32 pixels instead of 18 of 64
+// on v_mfma_f32_32x32x2_f32, and 6 (9) LDS reads instead of 36.
+// ------------------------------------------------------------------------------------------------------------------
+typedef __bf16 fbf16x8 __attribute__((ext_vector_type(8)));
+template <int NPC>
+__device__ __forceinline__ void first_cut(float v, bf16_t (&p)[NPC]) {      // v = p[0] + p[1] (+ p[2]) with truncated pieces (exact for NPC = 3)
+    float r = v;
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+        const unsigned u = __float_as_uint(r) & 0xFFFF0000u;
+        p[i] = (bf16_t)(u >> 16);
+        r -= __uint_as_float(u);
+    }
+}
+
+template <typename TO, int NPC>
+__global__ __launch_bounds__(256) void conv_first_fwd_mma_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                                 TO* __restrict__ out, int N, int H, int W, int lrelu) {
+    constexpr int CIN = 4, HPX = FHP + 2;                     // + 2 pixels: slot 3 of the last halo row reads one pixel past it (zero weights, finite data)
+    __shared__ __attribute__((aligned(16))) bf16_t halo[NPC][HPX][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, hi = lane >> 5;
+    for (int u = tid; u < NPC * 2 * 4; u += 256) (&halo[0][0][0])[(u / 8) * HPX * 4 + FHP * 4 + (u & 7)] = 0;      // the pad pixels of every plane
+    // A operand: rows = output channel m; k = 8 hi + 4 dxo + c of kernel row dy  <->  w[m][c][dy][2 hi + dxo]  (OIHW)
+    fbf16x8 wq[NPC][3];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        bf16_t pc[8][NPC];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int dx = 2 * hi + (j >> 2), c = j & 3;
+            first_cut<NPC>(dx < 3 ? w[m * 36 + c * 9 + dy * 3 + dx] : 0.f, pc[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) {
+            const uint4 q = make_uint4((unsigned)pc[0][i] | ((unsigned)pc[1][i] << 16), (unsigned)pc[2][i] | ((unsigned)pc[3][i] << 16),
+                                       (unsigned)pc[4][i] | ((unsigned)pc[5][i] << 16), (unsigned)pc[6][i] | ((unsigned)pc[7][i] << 16));
+            wq[i][dy] = __builtin_bit_cast(fbf16x8, q);
+        }
+    }
+    const int tiles_x = (W + FTW - 1) / FTW, tiles_y = (H + FTH - 1) / FTH;
+    const int total = tiles_x * tiles_y * N;
+    const float4 b0 = *reinterpret_cast<const float4*>(bias + 4 * hi), b1 = *reinterpret_cast<const float4*>(bias + 8 + 4 * hi),
+                 b2 = *reinterpret_cast<const float4*>(bias + 16 + 4 * hi), b3 = *reinterpret_cast<const float4*>(bias + 24 + 4 * hi);
+    // halo staging: a thread owns halo pixels tid and tid + 256 (all four channels), fetched one tile ahead
+    float hv[2][CIN];
+    auto prefetch = [&](int t) {
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, img = t / (tiles_x * tiles_y);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int hp = tid + it * 256;
+            const int hy = hp / (FTW + 2), hx = hp - hy * (FTW + 2);
+            const int gy = ty * FTH + hy - 1, gx = tx * FTW + hx - 1;
+            const bool ok = hp < FHP && gy >= 0 && gy < H && gx >= 0 && gx < W;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) hv[it][c] = ok ? x[((size_t)(img * CIN + c) * H + gy) * W + gx] : 0.f;
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int hp = tid + it * 256;
+            if (hp >= FHP) continue;
+            bf16_t pc[CIN][NPC];
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) first_cut<NPC>(hv[it][c], pc[c]);
+#pragma unroll
+            for (int i = 0; i < NPC; ++i)
+                *reinterpret_cast<uint2*>(&halo[i][hp][0]) = make_uint2((unsigned)pc[0][i] | ((unsigned)pc[1][i] << 16), (unsigned)pc[2][i] | ((unsigned)pc[3][i] << 16));
+        }
+    };
+    if ((int)blockIdx.x < total) prefetch(blockIdx.x);
+    for (int t = blockIdx.x; t < total; t += gridDim.x) {
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, img = t / (tiles_x * tiles_y);
+        const int y0 = ty * FTH, x0 = tx * FTW;
+        __syncthreads();
+        stage();
+        __syncthreads();
+        if (t + (int)gridDim.x < total) prefetch(t + gridDim.x);
+        f32x16 acc[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                fbf16x8 xb[NPC];
+                const int hp = (wave * 2 + r + dy) * (FTW + 2) + m + 2 * hi;
+#pragma unroll
+                for (int i = 0; i < NPC; ++i) {
+                    const uint2 lo = *reinterpret_cast<const uint2*>(&halo[i][hp][0]), hi2 = *reinterpret_cast<const uint2*>(&halo[i][hp + 1][0]);
+                    xb[i] = __builtin_bit_cast(fbf16x8, make_uint4(lo.x, lo.y, hi2.x, hi2.y));
+                }
+                if constexpr (NPC == 3) {       // six piece products, smallest first (conv_x3.hip)
+                    constexpr int WI[6] = {0, 1, 2, 0, 1, 0};
+                    constexpr int XI[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[WI[q]][dy], xb[XI[q]], acc[r], 0, 0, 0);
+                } else {
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[0][dy], xb[1], acc[r], 0, 0, 0);
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[1][dy], xb[0], acc[r], 0, 0, 0);
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[0][dy], xb[0], acc[r], 0, 0, 0);
+                }
+            }
+        // epilogue in the full-line layouts of conv.h (every lane takes part in the exchanges; the stores are predicated)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int y = y0 + wave * 2 + r;                 // wave-uniform
+            const bool yok = y < H;
+            const float4 bs[4] = {b0, b1, b2, b3};
+            float4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v[q] = make_float4(acc[r][4 * q] + bs[q].x, acc[r][4 * q + 1] + bs[q].y, acc[r][4 * q + 2] + bs[q].z, acc[r][4 * q + 3] + bs[q].w);
+                if (lrelu) { v[q].x = fmaxf(0.2f * v[q].x, v[q].x); v[q].y = fmaxf(0.2f * v[q].y, v[q].y); v[q].z = fmaxf(0.2f * v[q].z, v[q].z); v[q].w = fmaxf(0.2f * v[q].w, v[q].w); }
+            }
+            TO* blk = out + ((size_t)(img * H + (yok ? y : 0)) * W + x0) * 32;
+            if constexpr (sizeof(TO) == 4) {
+                f32_line_store(v, reinterpret_cast<float*>(blk), 32, lane, yok, W - x0);
+            } else {
+                uint2 pk[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pk[q] = pack_bf4(v[q]);
+                uint4 s0, s1;
+                bf16_line_swap(pk, s0, s1);
+                const int lp = lane & 15;
+                bf16_t* row = reinterpret_cast<bf16_t*>(blk) + 8 * bf16_line_group(lane);
+                if (yok && x0 + lp < W) *reinterpret_cast<uint4*>(row + lp * 32) = s0;
+                if (yok && x0 + lp + 16 < W) *reinterpret_cast<uint4*>(row + (lp + 16) * 32) = s1;
+            }
+        }
+    }
+}
+
 template <typename TO>
 static int launch_first_t(const float* x, const float* w, const float* bias, TO* out, int N, int Cin, int H, int W, int lrelu, hipStream_t st) {
     const int tiles = ((W + FTW - 1) / FTW) * ((H + FTH - 1) / FTH) * N;
     if (tiles <= 0) return 0;
     const int grid = tiles < 2048 ? tiles : 2048;
+    static int mma = -1;                          // ELD_FIRST_MMA=0: the K = 36 kernel on the fp32 MFMA for every Cin
+    if (mma < 0) { const char* e = getenv("ELD_FIRST_MMA"); mma = e ? atoi(e) : 1; }
+    if (Cin == 4 && mma) {                        // packed Bayer raw: the bf16-MFMA kernel (fp32 output: exact three-piece products; bf16 output: two pieces)
+        ELD_LAUNCH((conv_first_fwd_mma_kernel<TO, sizeof(TO) == 4 ? 3 : 2>), dim3(grid), dim3(256), 0, st, x, w, bias, out, N, H, W, lrelu);
+        ELD_LAUNCH_CHECK();
+        return 0;
+    }
     switch (Cin) {
         case 1: ELD_LAUNCH((conv_first_fwd_kernel<1, TO>), dim3(grid), dim3(256), 0, st, x, w, bias, out, N, H, W, lrelu); break;
         case 2: ELD_LAUNCH((conv_first_fwd_kernel<2, TO>), dim3(grid), dim3(256), 0, st, x, w, bias, out, N, H, W, lrelu); break;
