@@ -1,5 +1,9 @@
 """CPU oracle for the evaluation metrics -- TEST INFRASTRUCTURE ONLY.
 
+tensor2im and illuminance_correct are pinned by tests/golden/eval.npz, which oracle/gen_golden_eval.py mints by running the
+reference's models/ELD_model.py (tensor2im :23-38, IlluminanceCorrect :138-169); forward_chop's restatement is
+oracle/unet_ref.py::forward_chop, pinned by the same file.  PSNR / SSIM stay "parity unpinned":
+
 The reference calls scikit-image (util/index.py:2,79-80: peak_signal_noise_ratio, structural_similarity(data_range=255,
 multichannel=True)).  scikit-image is a third-party dependency that is ABSENT here and unpinned by the reference
 (no requirements file), so parity for SSIM is "unpinned": this file restates the published algorithm (Wang et al. 2004) with
@@ -36,13 +40,16 @@ def ssim(x, y, data_range=255.0):
 
 def tensor2im(x):
     """models/ELD_model.py:23-38 for one (C,H,W) image in [0,1] units: x*255 clipped to [0,255], float32, not rounded
-    (the transpose to HWC does not change the metrics)."""
+    (the transpose to HWC does not change the metrics).  PINNED by tests/golden/eval.npz (t2i_*: the reference's own output)."""
     return np.clip(np.asarray(x, np.float32) * np.float32(255.0), 0, 255)
 
 
 def illuminance_correct(predict, source):
     """models/ELD_model.py:138-169 per image: p = clip(predict,0,1); alpha = <p,s>/<p,p> over source != 1 (float32 ratio of the
-    two dot products, accumulated here in float64); out = alpha * p.  predict: (N,C,H,W); source: (N or 1,C,H,W)."""
+    two dot products, accumulated here in float64 and rounded once: the reference's float32 torch.dot differs from that by its
+    summation-order rounding, a few ulp of alpha); out = alpha * p.  predict: (N,C,H,W); source: (N or 1,C,H,W).
+    PINNED by tests/golden/eval.npz (minted by the reference's IlluminanceCorrect, oracle/gen_golden_eval.py): equal to the
+    last bit on its three cases, tests/test_oracle_golden.py::test_eval_oracle_vs_reference_fixture."""
     predict, source = np.asarray(predict, np.float32), np.asarray(source, np.float32)
     out = np.empty_like(predict)
     for i in range(predict.shape[0]):

@@ -37,6 +37,25 @@ def unet_forward(sd, x):
     return conv('conv10_1', t, act=False)         # Unet.py:88
 
 
+def forward_chop(sd, x, base=16):
+    """models/ELD_model.py:434-467: the frame as four overlapping quadrants, each h//2 (w//2) plus a shave that is the
+    round-up of the half to a multiple of `base`, +base more when that is below 10 (:438-442); each output quadrant is cut
+    from its tile (:456-463).  Pinned by tests/golden/eval.npz (minted by the reference method, oracle/gen_golden_eval.py)."""
+    import math
+    b, c, h, w = x.shape
+    hh, wh = h // 2, w // 2
+    sh = math.ceil(hh / base) * base - hh
+    sw = math.ceil(wh / base) * base - wh
+    hs, ws = hh + (sh if sh >= 10 else sh + base), wh + (sw if sw >= 10 else sw + base)
+    o = [unet_forward(sd, t) for t in (x[:, :, :hs, :ws], x[:, :, :hs, w - ws:], x[:, :, h - hs:, :ws], x[:, :, h - hs:, w - ws:])]
+    out = x.new_empty(b, o[0].shape[1], h, w)
+    out[:, :, :hh, :wh] = o[0][:, :, :hh, :wh]
+    out[:, :, :hh, wh:] = o[1][:, :, :hh, ws - w + wh:]
+    out[:, :, hh:, :wh] = o[2][:, :, hs - h + hh:, :wh]
+    out[:, :, hh:, wh:] = o[3][:, :, hs - h + hh:, ws - w + wh:]
+    return out
+
+
 def seeded_state_dict(in_ch=4, out_ch=4, seed=2018, dtype=torch.float32):
     """Default-initialised parameters in the reference's construction order (Unet.py:11-46), so that
     torch.manual_seed(seed) reproduces the reference module's initial weights."""

@@ -368,6 +368,36 @@ def test_illuminance_correct_kernel_vs_oracle(eld_lib, shape, one_source):
     assert np.abs(got - ref).max() <= 2e-7 * max(1.0, float(np.abs(ref).max()))
 
 
+def test_eval_kernels_vs_reference_minted_fixture(eld_lib, tmp_path, golden_dir):
+    """SURVEY 8(f) n2 pinned: csrc/eval.hip and ELDModel.forward_chop against tests/golden/eval.npz, which oracle/gen_golden_eval.py
+    minted by running the reference's IlluminanceCorrect (ELD_model.py:138-169), tensor2im (:23-38) and forward_chop (:434-467)."""
+    from eld_amd.metrics import quality_assess_frames
+    from eld_amd.model import illuminance_correct
+    from oracle import metrics_ref as M
+    d = np.load(os.path.join(golden_dir, 'eval.npz'))
+    for tag in ('ic_n', 'ic_one', 'ic_b1'):          # own sources / one shared source frame / batch 1 with saturated pixels
+        got = illuminance_correct(torch.from_numpy(d[tag + '_pred']).cuda(), torch.from_numpy(d[tag + '_src']).cuda()).cpu().numpy()
+        ref = d[tag + '_out']
+        assert np.abs(got - ref).max() <= 2e-7 * float(np.abs(ref).max()), tag        # the gain: double accumulation vs float32 torch.dot
+    # tensor2im fused in the quality kernel: PSNR / SSIM of ([0,1]-unit frames) == the metrics of the reference's tensor2im images
+    x = torch.from_numpy(d['t2i_in']).cuda()
+    q = quality_assess_frames(x[:1], x[1:2]).cpu().numpy()[0]
+    a, b = np.transpose(d['t2i_out'], (2, 0, 1)), np.transpose(d['t2i_out1'], (2, 0, 1))
+    assert abs(q[0] - M.psnr(b, a)) < 1e-9 and abs(q[1] - M.ssim(b, a)) < 1e-9
+    # forward_chop: the reference's seeded default init (same torch build) -> the reference's own chopped output
+    m = new_model(tmp_path, chop=True)
+    wsum = np.array([float(p.detach().double().cpu().sum()) for p in m.netG.parameters()])
+    if not np.array_equal(wsum, d['wsum']):
+        pytest.skip('seeded default init differs from the minting torch build')
+    for tag in ('chop_a', 'chop_b'):                 # shave < 10 -> +16 (64x96) and shave >= 10 (44x74) branches of :441-442
+        xx = torch.from_numpy(d[tag + '_x'])
+        m.set_input({'input': xx, 'target': xx, 'fn': ['a']}, 'eval')
+        with torch.no_grad():
+            out = m.forward().cpu().numpy()
+        assert out.shape == d[tag + '_out'].shape
+        assert np.abs(out - d[tag + '_out']).max() < 1e-5, tag
+
+
 def test_l2_loss_training_step(eld_lib, tmp_path):
     """--loss l2 (train_options / models/losses.py:34): one fused step == torch-CPU forward, MSELoss, backward, Adam."""
     m = new_model(tmp_path, loss='l2')

@@ -229,3 +229,30 @@ def test_oracle_table_poisson_is_poisson():
         keep = pmf * n > 10
         chi2 = ((obs[keep] - pmf[keep] * n) ** 2 / (pmf[keep] * n)).sum()
         assert chi2 < stats.chi2.ppf(1 - 1e-6, keep.sum()), (lam, chi2)
+
+
+def test_eval_oracle_vs_reference_fixture(golden_dir):
+    """the eval-path checker against outputs of the reference itself (oracle/gen_golden_eval.py ran
+    models/ELD_model.py's tensor2im :23-38, IlluminanceCorrect :138-169 and forward_chop :434-467)."""
+    import torch
+    from oracle import metrics_ref as M
+    from oracle import unet_ref as U
+    d = np.load(os.path.join(golden_dir, 'eval.npz'))
+    for tag in ('ic_n', 'ic_one', 'ic_b1'):                    # batch with own sources / one shared source / batch 1
+        got = M.illuminance_correct(d[tag + '_pred'], d[tag + '_src'])
+        ref = d[tag + '_out']
+        assert got.dtype == np.float32 and got.shape == ref.shape
+        assert np.abs(got - ref).max() <= 2e-7 * float(np.abs(ref).max()), tag       # float32 torch.dot vs float64 dot: <= 2 ulp of alpha
+    assert (d['ic_b1_src'] == 1).any() and (d['ic_b1_pred'] < 0).any() and (d['ic_b1_pred'] > 1).any()
+    t = M.tensor2im(d['t2i_in'][0])
+    assert np.array_equal(np.transpose(t, (1, 2, 0)), d['t2i_out'])                  # image 0 only, HWC, exact
+    assert d['t2i_out'].min() == 0.0 and d['t2i_out'].max() == 255.0                 # both clip sides exercised
+    sd = U.seeded_state_dict(4, 4, seed=2018)
+    wsum = np.array([float(v.double().sum()) for v in sd.values()])
+    if str(d['torch_version']) != torch.__version__ or not np.array_equal(wsum, d['wsum']):
+        pytest.skip('seeded default init differs from the minting torch build')
+    torch.set_num_threads(1)
+    with torch.no_grad():
+        for tag in ('chop_a', 'chop_b'):                       # shave < 10 (+16) and shave >= 10 branches
+            out = U.forward_chop(sd, torch.from_numpy(d[tag + '_x']))
+            assert float(np.abs(out.numpy() - d[tag + '_out']).max()) < 1e-6, tag

@@ -282,6 +282,8 @@ def test_unet_all_gradients_vs_oracle(lib, shape, algo):
         ref = grads[n]
         err = float((p.grad.cpu().double() - ref).abs().max())
         assert err <= 1e-5 * (1 + float(ref.abs().max())), (n, err, float(ref.abs().max()))      # plain north_star bound; measured: profiles/r02_parity.md
+        # ... which the deep layers' tiny gradients meet even when they are zero: a relative bound against the float64 oracle too
+        assert err <= 2e-4 * float(ref.abs().max()), (n, err, float(ref.abs().max()))
     # eval-mode forward (no autograd) gives the same bits; state_dict round-trips through the reference key set
     with torch.no_grad():
         assert torch.equal(net(x.cuda()), out.detach())
