@@ -175,6 +175,62 @@ def cpu_baseline(h, w, seed=2018):
             'os_cpu_count': os.cpu_count()}
 
 
+def eval_sweep_leg(dev, precision, frames=3):
+    """BASELINE.json configs[4] on the driver line: one setting of the reference's evaluation sweep (test_ELD.py:18-52 -> ELDModel.eval,
+    ELD_model.py:203-307) at sensor resolution, on the device: SonyA7S2 packed frame, ISO 1600, ratio 100 -- noise synthesis with the camera's
+    tables -> U-Net inference -> IlluminanceCorrect -> tensor2im + PSNR + SSIM (csrc/eval.hip), HIP events per stage.  tools/eval_sweep.py runs
+    all 4 cameras x 3 ISOs x 2 ratios (profiles/r04_eval_sweep_*.json)."""
+    import importlib.util
+    import eld_amd
+    from eld_amd import _lib as L
+    from eld_amd.metrics import illuminance_correct, quality_assess_frames
+    from eld_amd.noise import load_camera_params, model_flags, sample_noise
+    from eld_amd.unet import UNetSeeInDark
+    spec = importlib.util.spec_from_file_location('eval_sweep', os.path.join(ROOT, 'tools', 'eval_sweep.py'))
+    es = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(es)
+    cam, iso, ratio = 'SonyA7S2', 1600, 100
+    H, W = es.CAMERAS[cam]
+    torch.manual_seed(2018)
+    net = UNetSeeInDark(4, 4).to(dev)
+    net.inference_precision = precision
+    flags = model_flags('PGRU') | L.CLIP
+    rng = np.random.RandomState(5)
+    g = torch.Generator(device=dev).manual_seed(77)
+    tables = load_camera_params(cam)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(frames + 1)]
+    q = None
+    for f in range(frames + 1):                               # frame 0 warms up (workspace allocation)
+        clean = (torch.floor(65535.0 * torch.rand(1, 4, H, W, device=dev, generator=g) ** 2.2) / 65535.0).contiguous()
+        p = es.params_for(tables, iso, ratio, rng)
+        ev[f][0].record()
+        noisy = sample_noise(clean, [p], flags, 2018, [f])
+        ev[f][1].record()
+        with torch.no_grad():
+            out = net(noisy)
+        ev[f][2].record()
+        out = illuminance_correct(out, clean)
+        ev[f][3].record()
+        q = quality_assess_frames(out, clean)
+        ev[f][4].record()
+    torch.cuda.synchronize()
+    st = [min(ev[f][i].elapsed_time(ev[f][i + 1]) for f in range(1, frames + 1)) for i in range(4)]
+    tot = min(ev[f][0].elapsed_time(ev[f][4]) for f in range(1, frames + 1))
+    npx = 4.0 * H * W
+    # the two evaluation kernels are single passes over the frames: IlluminanceCorrect reads predict + source for the two dot products, then
+    # reads predict and writes the output (16 B per element); the quality kernel reads both images once (8 B per element)
+    gb_corr, gb_q = 16.0 * npx / (st[2] * 1e-3) / 1e9, 8.0 * npx / (st[3] * 1e-3) / 1e9
+    psnr, ssim = q[0].tolist()
+    return {'value': round(npx / (tot * 1e-3) / 1e6, 1), 'unit': 'raw MPix/s', 'ms_per_frame': round(tot, 3), 'frames': frames, 'dtype': 'f32' if precision == 'fp32' else 'bf16',
+            'config': {'workload': 'BASELINE.json configs[4], one setting: %s packed %dx%d, ISO %d, ratio x%d, synthetic frame; synth (PGRU) -> U-Net inference -> '
+                                   'IlluminanceCorrect -> tensor2im + PSNR + SSIM, all on the device' % (cam, H, W, iso, ratio)},
+            'stage_ms': {'sampler': round(st[0], 4), 'unet_inference': round(st[1], 3), 'illuminance_correct': round(st[2], 4), 'quality_assess': round(st[3], 4)},
+            'unet_inference_tflops': round(FLOP_FWD_PER_PIX * npx / (st[1] * 1e-3) / 1e12, 1),
+            'eval_kernels_hbm': {'illuminance_correct': {'algorithmic_bytes': 16 * int(npx), 'achieved_GBps': round(gb_corr, 1), 'frac': round(gb_corr / PEAK_HBM_GBS, 4)},
+                                 'quality_assess': {'algorithmic_bytes': 8 * int(npx), 'achieved_GBps': round(gb_q, 1), 'frac': round(gb_q / PEAK_HBM_GBS, 4)}},
+            'psnr_ssim_random_init': [round(psnr, 3), round(ssim, 5)]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -365,6 +421,25 @@ def main():
                                                       'gradients / packed weights on v_mfma_f32_32x32x16_bf16, fp32 accumulation, master weights, '
                                                       'parameter gradients and Adam), %d frames per GPU' % B}}
             del model_b
+            torch.cuda.empty_cache()
+        # the same fp32 step with the reference's OWN noise model 'Pg' (noise.py:158-166: the one model string whose arithmetic is pinned by
+        # reference-minted vectors) beside the full model of the headline
+        if args.precision == 'fp32' and world == 1 and not args.no_alt and args.noise != 'Pg':
+            with contextlib.redirect_stdout(io.StringIO()):
+                nm_pg = NoiseModel(model='Pg', include=4)
+            model.set_noise_model(nm_pg)
+            step(total_steps + 20); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(3):
+                step(total_steps + 21 + i)
+            torch.cuda.synchronize()
+            dtp = (time.perf_counter() - t0) / 3
+            model.set_noise_model(nm)
+            res['alt_Pg_step'] = {'value': round(pix_per_step / dtp / 1e6, 3), 'unit': 'raw MPix/s', 'ms_per_step': round(dtp * 1e3, 3), 'steps': 3,
+                                  'note': "the headline step with NoiseModel(model='Pg') (Poisson shot + Gaussian read, the reference's own model) instead of PGRU"}
+        # BASELINE.json configs[4]: one setting of the evaluation sweep at sensor resolution, both precisions
+        if world == 1 and not args.no_alt:
+            res['alt_eval_sweep'] = {'fp32': eval_sweep_leg(dev, 'fp32'), 'bf16': eval_sweep_leg(dev, 'bf16')}
             torch.cuda.empty_cache()
         # sampler alone (HBM-bound: 8 B per raw pixel), batch of 8 resident images
         nb = 8

@@ -32,6 +32,7 @@ SIGNATURES = {
     'eld_noise_forward': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _u32, _u64, _vp, _vp, _vp]),
     'eld_noise_forward_strided': (_i, [_vp, _i, _sz, _vp, _sz, _vp, _i, _i, _i, _i, _u32, _u64, _vp, _vp, _vp]),
     'eld_augment_u16': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _u32, _vp]),
+    'eld_philox_rounds': (_i, []),
     'eld_philox_words': (_i, [_vp, _u32, _u32, _u64, _u32, _u32, _u64, _vp]),
     'eld_pack_bayer': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'eld_unpack_bayer': (_i, [_vp, _vp, _i, _i, _i, _vp]),
@@ -74,6 +75,9 @@ SIGNATURES = {
 }
 
 
+PHILOX_ROUNDS = 7      # the sampler's generator: Philox4x32-7 (csrc/philox.h); checked against the library at load
+
+
 class LibraryMissing(RuntimeError):
     pass
 
@@ -96,12 +100,20 @@ def load_library(path=None):
     # no device context -- every launch then fails with hipErrorNoDevice).
     import torch  # noqa: F401
     lib_ = C.CDLL(p)
+    any_philox = bool(os.environ.get('ELD_AMD_ANY_PHILOX'))
     for name, (res, args) in SIGNATURES.items():
+        if name == 'eld_philox_rounds' and any_philox and not hasattr(lib_, name):
+            continue                      # dev A/B runs against a library older than the symbol (tools/build_variant.sh <old rev>)
         fn = getattr(lib_, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
     if lib_.eld_abi_version() != 1:
         raise RuntimeError('libeld_amd ABI version mismatch')
+    if not any_philox and lib_.eld_philox_rounds() != PHILOX_ROUNDS:
+        # the noise stream of a (seed, sample id) pair depends on the round count: a library built with another -DELD_PHILOX_ROUNDS replays
+        # different noise for the same checkpoint / seed ("noise streams")
+        raise RuntimeError('libeld_amd runs Philox4x32-%d, this package expects %d rounds (set ELD_AMD_ANY_PHILOX=1 to accept)'
+                           % (lib_.eld_philox_rounds(), PHILOX_ROUNDS))
     _lib = lib_
     return lib_
 

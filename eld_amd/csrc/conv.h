@@ -41,6 +41,8 @@ struct ConvArgs {
     const void* act1;
     int Cout_t;         // EPI_CONVT_FWD: real Cout (Nout = 4*Cout_t, n = tap*Cout_t + co)
     int tiles_x, tiles_y;
+    int vp;             // virtual-row pitch of the strip tiles_y was counted on (vrow_pitch; set by the launchers that tile the strip)
+    int tile_h, tile_w; // conv_x3d / conv_bfd: the launch's tile shape (rows x columns of pixels; tile_h * tile_w <= the kernel's pixel count)
     int dtype;          // DT_F32 / DT_BF16
     int algo;           // fp32 product scheme of THIS call: 0 fp32 MFMA, 1 three bf16 pieces, 2 two fp16 pieces; < 0 = process default (conv_fp32_algo)
     int dbg;            // ablation switches for tools/ (env ELD_CONV_DBG): 1 skip epilogue, 4 skip staging loads, 8/16 skip slab/halo stores (conv_x3), 64 one workgroup per CU
@@ -198,6 +200,46 @@ __device__ __forceinline__ void f32_line_store(float4 (&v)[4], float* blk, size_
     }
 }
 
+// ---- virtual rows (round 4): no MFMA work on rows that do not exist --------------------------------------------------------------------
+// The N images of a launch are stacked into ONE strip: row y of image i is virtual row i * P + y with pitch P = H + S, where the S = 2 - (H & 1)
+// rows between two images hold nothing (they read as the convolution's zero padding and are never stored).  Row tiles are cut from the strip, not
+// from each image, so a level of 89 rows costs 8 x 90 / 16 = 45 sixteen-row tiles per batch of eight instead of 8 x 6 = 48 (7.9 % -> 1.1 % of
+// padding rows; 178 rows: 7.9 % -> 1.1 %).  P is even, so a row pair (2k, 2k + 1) of the strip is a row pair of one image: the fused 2x2 max-pool
+// still finds its vertical neighbour in the lane's own registers.  A tile touches at most two images (TH + 2 <= P): kernels address a window of two
+// images through one buffer descriptor (base = the image of the tile's first row), which is why the launchers want two images within 4 GB.
+// The pitch is a per-launch choice (vrow_pitch): H + S (tiles straddle image seams) when that needs fewer TH-row tiles than the plain
+// per-image tiling, else H rounded up to a multiple of TH (tiles never straddle: exactly the per-image tiling, no separator needed).  Kernels
+// tell the two apart by P % TH: when it is 0 every strip row beyond the pitch of the tile's first image is treated as absent (it could only be
+// the halo of a tile's last row, which must read zeros or feeds a separator row).
+__host__ __device__ inline int vrow_extent(int N, int H, int P) { return (N - 1) * P + H; }      // the last image needs no separator
+__host__ __device__ inline int vrow_pitch(int N, int H, int TH) {
+    const int flat = H + 2 - (H & 1), own = (H + TH - 1) / TH * TH;
+    if (flat < TH + 2) return own;                                       // a tile would span more than two images
+    return (vrow_extent(N, H, flat) + TH - 1) / TH < (vrow_extent(N, H, own) + TH - 1) / TH ? flat : own;
+}
+
+// Tile shape (rows x columns) of conv_x3d_kernel / conv_bfd_kernel for a launch over N images of H x W: the one that covers the strip with
+// the fewest tiles among th * tw <= TH * 32 pixel slots and (th + 2)(tw + 2) <= (TH + 2) * 34 halo pixels (what the kernels' LDS holds);
+// ties go to the standard TH x 32.  `pooled` launches (fused 2x2 max-pool) keep TH x 32.  conv_tile_count = tiles of that shape.
+void conv_tile_shape(int N, int H, int W, int TH, bool pooled, int& th, int& tw);
+long long conv_tile_count(int N, int H, int W, int TH, bool pooled);
+
+// f32_line_store for pixel slots whose pixels are per-lane: p0 / p1 = channel 0 of the 32-channel block in the pixels of slot lane & 15 and slot
+// (lane & 15) + 16 of the MFMA column (nullptr: nothing to store).  EVERY lane must take part in the exchange.
+__device__ __forceinline__ void f32_line_store2(float4 (&v)[4], float* p0, float* p1, int lane) {
+    f32_rows_swap(v[0], v[1]);
+    f32_rows_swap(v[2], v[3]);
+    const int g = 4 * bf16_line_group(lane);      // same row -> piece map {0,2,1,3}
+    if (p0 != nullptr) {
+        *reinterpret_cast<float4*>(p0 + g) = v[0];
+        *reinterpret_cast<float4*>(p0 + g + 16) = v[2];
+    }
+    if (p1 != nullptr) {
+        *reinterpret_cast<float4*>(p1 + g) = v[1];
+        *reinterpret_cast<float4*>(p1 + g + 16) = v[3];
+    }
+}
+
 int launch_conv(const ConvArgs& a, int mode, hipStream_t st);
 // fp32 3x3 convolutions: 0 = exact-fp32 MFMA (conv_igemm.hip), 1 = three-piece bf16 split on the bf16 MFMA (conv_x3.hip).
 // set < 0 only queries.  Initial value from env ELD_FP32_CONV (mfma | x3).  Returns the value in force before the call.
@@ -246,6 +288,7 @@ struct WgradArgs {
     int CBp;             // padded CB (multiple of 32)
     int psplit;
     int tiles_x, tiles_y;
+    int vp;              // wgrad8_kernel: virtual-row pitch of the strip tiles_y was counted on (vrow_pitch)
     int dtype;           // DT_F32 / DT_BF16 inputs (partials and accumulation are always fp32)
     int algo;            // as ConvArgs::algo
     int wgrad8;          // partials were sized for wgrad8_kernel's block shape (wgrad8_shape): use it
@@ -255,7 +298,9 @@ struct WgradArgs {
 int launch_wgrad(const WgradArgs& a, int mode, hipStream_t st);
 // block shape (COB out-channels x JB in-channels, TH-row tiles) wgrad8_kernel uses for a 3x3 layer under the three-piece scheme;
 // false if the layer stays on wgrad_kernel
-bool wgrad8_shape(int CA, int CBp, int& COB, int& JB, int& TH, bool bf16 = false);
+bool wgrad8_shape(int CA, int CBp, int& COB, int& JB, int& TH, int& TWo, bool bf16 = false);
+// spatial tiles wgrad8_kernel walks for a layer (TH x TWo tiles over the virtual-row strip of the batch); 0 if the layer is not on wgrad8_kernel
+int wgrad8_ntiles(int CA, int CBp, int N, int H, int W, bool bf16);
 // out[(i*CBr + j)*T + tap] = sum_s part[s][tap][i][j]   (OIHW / (Cin,Cout,2,2) layouts);  bgrad[i] = sum_s bpart[s][i]
 int launch_wgrad_reduce(const float* part, const float* bpart, float* wgrad, float* bgrad, int psplit, int T, int CA,
                         int CBp, int CBr, hipStream_t st);

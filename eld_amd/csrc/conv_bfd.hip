@@ -22,6 +22,14 @@
 //     3 x 24 KB (BN = 128) + 2 x 39 KB (18 x 34 pixel halo, 64 B per pixel) = 150 KB, one 8-wave workgroup per CU.
 //   * tile = 16 rows x 32 pixels x BN channels; a wave owns 2 rows x BN channels (2 x 4 accumulator tiles): each k-block reads
 //     2 + 4 fragments for 8 MFMAs -> 36 KB of LDS reads per wave and stage against 48 x 32 matrix-pipe cycles (LDS 256 B/clk: 37 %).
+//
+// Round 4 -- no MFMA work on pixels that do not exist.  The workgroup still owns 512 pixel slots (8 waves x 2 MFMA columns-of-32), but which pixel
+// a slot is follows from the LAUNCH's tile shape (a.tile_h rows x a.tile_w columns, tile_h * tile_w <= 512, (tile_h + 2)(tile_w + 2) <= 612 halo
+// pixels): slot p is tile pixel (p / tile_w, p % tile_w), i.e. the M index -> (row, column) map is per-lane LDS addressing (12 fragment offsets
+// instead of 6) and per-lane epilogue addressing.  Rows are rows of the virtual strip of the batch (conv.h vrow_*).  With 16 x 32 tiles cut per
+// image, the 89 x 133 / 178 x 266 / 356 x 532 levels of a 1424 x 2128 frame executed 1.30x / 1.17x / 1.06x their pixels; with the shapes
+// conv_tile_shape() picks (15 x 34, 17 x 30, 18 x 28 on the strip) it is 1.04x / 1.03x / 1.02x.  Launches that fuse the 2x2 max-pool keep 16 x 32
+// (the pool wants a lane's two rows to be a vertical pair); they still take the strip.
 #include <stdlib.h>
 #include "conv.h"
 
@@ -59,8 +67,11 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
     const int m = lane & 31, hi = lane >> 5;
     const int NB = a.Nout / BN;
     const int Cin = a.C0 + a.C1, NCH = Cin >> 5, NCH0 = a.C0 >> 5;
-    const int total_tiles = a.tiles_x * a.tiles_y * a.N * NB;
+    const int total_tiles = a.tiles_x * a.tiles_y * NB;                   // tiles_y: tile rows of the virtual strip (all images)
     const int Cs0 = a.C0;                                                 // channels per source tensor (C1 == C0 or 0)
+    const int THL = a.tile_h, TWL = a.tile_w, HWL = TWL + 2;              // the launch's tile shape; halo row = TWL + 2 pixels
+    const int APX = (THL + 2) * HWL, NPX = THL * TWL, VP = a.vp;          // halo pixels / tile pixels in use (<= A_PIX / TH * TW)
+    const bool seam = VP % THL != 0;                                      // tiles may straddle two images (conv.h vrow_pitch)
 
     const unsigned lds_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(__attribute__((address_space(3))) char*)lds);
     const unsigned ldsB_addr = lds_base, ldsA_addr = lds_base + NBB * B_BYTES;
@@ -70,37 +81,45 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
     constexpr unsigned OOB = 0xFFFFFFF0u;
 
     // ---- activation DMA: which (halo pixel, octet) lands in this lane's slot of piece wave + it*WAVES ----------------------------
-    int a_hy[A_IT], a_hx[A_IT];            // halo coordinates - 1 (image offsets relative to the tile origin); hy < -1: no unit
+    int a_hy[A_IT], a_hx[A_IT];            // halo coordinates - 1 (offsets relative to the tile origin); hy very negative: no unit
     unsigned a_oct[A_IT];
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
         const int piece = (wave + it * WAVES) % A_PIECES;                 // every wave issues A_IT pieces (a duplicate rewrites the same bytes)
         const int u = piece * 64 + lane;
         const int P = u >> 2;
-        const int hr = P / HW2, hc = P - hr * HW2;
-        a_hy[it] = u < A_UNITS ? hr - 1 : -1000;
+        const int hr = P / HWL, hc = P - hr * HWL;
+        a_hy[it] = P < APX ? hr - 1 : -(1 << 20);
         a_hx[it] = hc - 1;
         a_oct[it] = (unsigned)((u & 3) ^ ((hc >> 2) & 3)) * 16u;
     }
     unsigned a_voff[A_IT];
     int l_img = 0;
-    auto decode = [&](int t, int& nb, int& img, int& y0, int& x0) {
+    // tile -> channel block, first strip row, first column, and the image the first row lies in (img0) with the row's offset in its pitch (vrel)
+    auto decode = [&](int t, int& nb, int& img0, int& vrel, int& x0) {
         nb = t % NB;
-        int r = t / NB;
-        const int tx = r % a.tiles_x;
-        r /= a.tiles_x;
-        const int ty = r % a.tiles_y;
-        img = r / a.tiles_y;
-        y0 = ty * TH; x0 = tx * TW;
+        const int r = t / NB;
+        const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+        const int v0 = ty * THL;
+        img0 = v0 / VP; vrel = v0 - img0 * VP;
+        x0 = tx * TWL;
+    };
+    // strip row `row` relative to image img0's pitch -> row index inside the two-image window at img0 (second image: H ..), false: no such pixel row
+    auto win_row = [&](int row, int& wrow) -> bool {
+        const bool over = row >= VP;
+        wrow = over ? row - VP + a.H : row;
+        return over ? seam && row - VP < a.H : (unsigned)row < (unsigned)a.H;
     };
     auto setup_load = [&](int t) {
-        int nb, y0, x0;
-        decode(t, nb, l_img, y0, x0);
+        int nb, vrel, x0;
+        decode(t, nb, l_img, vrel, x0);
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            const int gy = y0 + a_hy[it], gx = x0 + a_hx[it];
-            const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            a_voff[it] = ok ? (unsigned)(gy * a.W + gx) * (unsigned)(Cs0 * 2) + a_oct[it] : OOB;
+            int wrow;
+            const bool rok = win_row(vrel + a_hy[it], wrow);
+            const int gx = x0 + a_hx[it];
+            const bool ok = rok && gx >= 0 && gx < a.W;                  // rows of the window's second image that do not exist lie outside the descriptor
+            a_voff[it] = ok ? (unsigned)(wrow * a.W + gx) * (unsigned)(Cs0 * 2) + a_oct[it] : OOB;
         }
     };
     auto dma_A = [&](int buf, int chunk) {
@@ -109,7 +128,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
         const int cs = chunk < NCH0 ? chunk : chunk - NCH0;
         const size_t img_bytes = (size_t)a.H * a.W * Cs0 * 2;
         const unsigned long long ab = (unsigned long long)(src + (size_t)l_img * img_bytes);
-        const i32x4 rsrc_a = {(int)(unsigned)ab, (int)((unsigned)(ab >> 32) & 0xFFFFu), (int)img_bytes, 0x00020000};
+        const i32x4 rsrc_a = {(int)(unsigned)ab, (int)((unsigned)(ab >> 32) & 0xFFFFu), (int)(unsigned)(img_bytes * (size_t)(a.N - l_img < 2 ? a.N - l_img : 2)), 0x00020000};
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int piece = (wave + it * WAVES) % A_PIECES;            // wave-uniform
@@ -127,13 +146,31 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
     };
 
     // ---- fragment addresses: per lane, per (kx, k-block); rows / taps / buffers are uniform or immediate offsets ---------------
-    unsigned fx_off[3][2], fw_off[2];
+    // slot p = (wave * RPW + r) * 32 + m of the workgroup is tile pixel (p / TWL, p % TWL); slots beyond the tile's pixel count compute on pixel 0
+    unsigned fx_off[RPW][3][2], fw_off[2];
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx)
+    for (int r = 0; r < RPW; ++r) {
+        int p = (wave * RPW + r) * 32 + m;
+        p = p < NPX ? p : 0;
+        const int tr = p / TWL, tc = p - tr * TWL;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            const int hc = m + kx;
-            fx_off[kx][kb] = (unsigned)(hc * 64 + (((kb * 2 + hi) ^ ((hc >> 2) & 3)) * 16));
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const int hc = tc + kx;
+                fx_off[r][kx][kb] = (unsigned)((tr * HWL + hc) * 64 + (((kb * 2 + hi) ^ ((hc >> 2) & 3)) * 16));
+            }
+    }
+    // epilogue: the two pixels of each MFMA column-of-32 this lane stores in the full-line layout (slots lp and lp + 16 of column r), as
+    // (tile row << 8 | tile column); 0xFFFF: the slot is beyond the tile
+    unsigned ep_rc[RPW][2];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int p = (wave * RPW + r) * 32 + (lane & 15) + 16 * h;
+            const int tr = p / TWL, tc = p - tr * TWL;
+            ep_rc[r][h] = p < NPX ? (unsigned)((tr << 8) | tc) : 0xFFFFu;
         }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) fw_off[kb] = (unsigned)(m * 64 + (((kb * 2 + hi) ^ ((m >> 2) & 3)) * 16));
@@ -160,15 +197,15 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
     };
     int young;                                   // DMA instructions this wave issued during the previous stage; < 0: wait for everything
     {
-        int nb0, i0, y00, x00;
-        decode(t, nb0, i0, y00, x00);
+        int nb0, i0, v00, x00;
+        decode(t, nb0, i0, v00, x00);
         dma_A(0, 0);
         dma_B(0, nb0, 0, 0);
         young = dma_B_ahead(1, nb0, 0, 0, 1, t + (int)gridDim.x) ? B_IT : 0;
     }
     for (;;) {
-        int nb, img, y0, x0;
-        decode(t, nb, img, y0, x0);
+        int nb, img0, vrel, x0;
+        decode(t, nb, img0, vrel, x0);
         const int t_next = t + gridDim.x;
         f32x16 acc[RPW][NT];
 #pragma unroll
@@ -204,7 +241,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
                 const bool late = wave >= 4;
                 if (!late) issue_stage();
                 __builtin_amdgcn_s_setprio(0);
-                const char* la = ldsA + bufA * A_BYTES + (wave * RPW + ky) * (HW2 * 64);
+                const char* la = ldsA + bufA * A_BYTES + ky * (HWL * 64);
                 const char* lb = ldsB + bufB * B_BYTES;
                 if (!(ELD_DBG(a) & 2))
 #pragma unroll
@@ -213,7 +250,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
                     for (int kb = 0; kb < 2; ++kb) {
                         uint4 fx[RPW], fw[NT];
 #pragma unroll
-                        for (int r = 0; r < RPW; ++r) fx[r] = *reinterpret_cast<const uint4*>(la + r * (HW2 * 64) + fx_off[kx][kb]);
+                        for (int r = 0; r < RPW; ++r) fx[r] = *reinterpret_cast<const uint4*>(la + fx_off[r][kx][kb]);
 #pragma unroll
                         for (int tt = 0; tt < NT; ++tt) fw[tt] = *reinterpret_cast<const uint4*>(lb + (kx * BN + tt * 32) * 64 + fw_off[kb]);
 #pragma unroll
@@ -230,14 +267,13 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
             bufA ^= 1;
         }
 
-        // ---- epilogue.  The MFMA leaves lane (m, hi) with channels 8q + 4hi .. +3 of pixel x0 + m in every 32-channel block; stores (and the
-        //      loads of the saved activations) use the full-line layout of conv.h bf16_line_swap: per block, instruction i of a wave covers the
-        //      64 bytes of pixels x0 + 16 i .. + 15, lane l holding pixel (l & 15) + 16 i, channel group bf16_line_group(l).
+        // ---- epilogue.  The MFMA leaves lane (m, hi) with channels 8q + 4hi .. +3 of slot m of its column-of-32 in every 32-channel block; stores
+        //      (and the loads of the saved activations) use the full-line layout of conv.h bf16_line_swap: per block, instruction i of a wave covers
+        //      the 64 bytes of slots 16 i .. 16 i + 15, lane l holding slot (l & 15) + 16 i, channel group bf16_line_group(l).  A slot's pixel
+        //      is per-lane (ep_rc): consecutive slots are consecutive pixels of a tile row except where the row wraps.
         //      -------------------------------------------------------------------------------------------------------------------------
         if (!(ELD_DBG(a) & 1)) {
-            const int lp = lane & 15, lg = bf16_line_group(lane);
-            const int x = x0 + m;
-            const bool xok = x < a.W;
+            const int lg = bf16_line_group(lane);
             // Forward: bias and max(0.2 v, v) once, in place, two values per instruction where the ISA has a packed form (the pooled copy
             // below reuses the activated values).  The whole epilogue runs with the matrix pipe idle (every wave of the workgroup reaches it
             // at the same stage), so its VALU instruction count is launch time: 2.5 instructions per value here, against 8 with a
@@ -258,31 +294,38 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
             // measured and dropped: 2 % slower here, neutral on conv_bfw; profiles/r03_ab_notes.md.)
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
-                const int y = y0 + wave * RPW + r;                      // wave-uniform
-                const bool yok = y < a.H;
-                const int yc = yok ? y : a.H - 1;                       // loads of out-of-range rows / columns re-read a valid pixel (result unused)
-                const size_t rowpix = (size_t)(img * a.H + yc) * a.W;
+                // this lane's two pixels of column r: NHW pixel index (0 where there is none: loads re-read a valid pixel, stores are predicated)
+                size_t pix[2];
+                bool pok[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = vrel + (int)(ep_rc[r][h] >> 8), x = x0 + (int)(ep_rc[r][h] & 255u);
+                    const bool over = row >= VP;
+                    const int y = over ? row - VP : row, img = img0 + (over ? 1 : 0);
+                    pok[h] = ep_rc[r][h] != 0xFFFFu && y < a.H && img < a.N && x < a.W;
+                    pix[h] = pok[h] ? (size_t)(img * a.H + y) * a.W + x : 0;
+                }
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) {
                     const int nb32 = nb * BN + tt * 32;
                     float4 v[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = make_float4(acc[r][tt][4 * q], acc[r][tt][4 * q + 1], acc[r][tt][4 * q + 2], acc[r][tt][4 * q + 3]);
-                    bf16_t* drow;                                        // block base of pixel x0 of this row in the destination tensor, + this lane's group
+                    bf16_t* dst;                                         // channel 0 of this lane's group in pixel 0 of the destination tensor
                     int C;
                     if (a.epi == EPI_FWD) {
                         C = a.Nout;
-                        drow = static_cast<bf16_t*>(a.out0) + (rowpix + x0) * C + nb32 + 8 * lg;
+                        dst = static_cast<bf16_t*>(a.out0) + nb32 + 8 * lg;
                     } else {
                         const bool lo = nb32 < a.split;
                         C = lo ? a.split : a.Nout - a.split;
                         const int cb = lo ? nb32 : nb32 - a.split;
-                        drow = static_cast<bf16_t*>(lo ? a.out0 : a.out1) + (rowpix + x0) * C + cb + 8 * lg;
+                        dst = static_cast<bf16_t*>(lo ? a.out0 : a.out1) + cb + 8 * lg;
                         const bf16_t* act = static_cast<const bf16_t*>(lo ? a.act0 : a.act1);
                         if (act != nullptr) {
-                            const bf16_t* arow = act + rowpix * C + cb + 8 * lg;
-                            const uint4 a0 = *reinterpret_cast<const uint4*>(arow + (size_t)min(x0 + lp, a.W - 1) * C);
-                            const uint4 a1 = *reinterpret_cast<const uint4*>(arow + (size_t)min(x0 + lp + 16, a.W - 1) * C);
+                            const bf16_t* arow = act + cb + 8 * lg;
+                            const uint4 a0 = *reinterpret_cast<const uint4*>(arow + pix[0] * C);
+                            const uint4 a1 = *reinterpret_cast<const uint4*>(arow + pix[1] * C);
                             uint2 sp[4];
                             bf16_line_unswap(a0, a1, sp);
 #pragma unroll
@@ -297,22 +340,25 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
                     for (int q = 0; q < 4; ++q) pk[q] = pack_bf4(v[q]);
                     uint4 s0, s1;
                     bf16_line_swap(pk, s0, s1);                          // every lane takes part; only the stores are predicated
-                    if (yok) {
-                        if (x0 + lp < a.W) *reinterpret_cast<uint4*>(drow + (size_t)lp * C) = s0;
-                        if (x0 + lp + 16 < a.W) *reinterpret_cast<uint4*>(drow + (size_t)(lp + 16) * C) = s1;
-                    }
+                    if (pok[0]) *reinterpret_cast<uint4*>(dst + pix[0] * C) = s0;
+                    if (pok[1]) *reinterpret_cast<uint4*>(dst + pix[1] * C) = s1;
                 }
             }
             // fused nn.MaxPool2d(2) (Unet.py:51-63): vertical pair in the lane's own rows, horizontal pair in lane ^ 1, on the activated
-            // fp32 values (max commutes with the monotone bf16 rounding, so this equals pooling the stored tensor)
+            // fp32 values (max commutes with the monotone bf16 rounding, so this equals pooling the stored tensor).  Pooled launches run
+            // 16 x 32 tiles (launcher): slot m of column r is pixel (wave * RPW + r, m) of the tile, and strip rows keep their parity.
             if (a.epi == EPI_FWD && a.pool_out != nullptr) {
                 const int Hp = a.H >> 1, Wp = a.W >> 1;
+                const int x = x0 + m;
+                const bool xok = x < a.W;
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) {
 #pragma unroll
                     for (int rp = 0; rp < RPW / 2; ++rp) {
-                        const int y = y0 + wave * RPW + 2 * rp;
-                        if (y >= a.H) continue;
+                        const int row = vrel + wave * RPW + 2 * rp;     // wave-uniform
+                        const bool over = row >= VP;
+                        const int y = over ? row - VP : row, img = img0 + (over ? 1 : 0);
+                        if (y >= a.H || img >= a.N) continue;
                         uint2 pk[4];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
@@ -345,12 +391,14 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
 template <int BN, int RPW, int WAVES>
 int launch_bfd(ConvArgs a, hipStream_t st) {
     constexpr int TH = WAVES * RPW;
-    a.tiles_x = (a.W + TW - 1) / TW;
-    a.tiles_y = (a.H + TH - 1) / TH;
+    conv_tile_shape(a.N, a.H, a.W, TH, a.pool_out != nullptr, a.tile_h, a.tile_w);
+    a.vp = vrow_pitch(a.N, a.H, a.tile_h);
+    a.tiles_x = (a.W + a.tile_w - 1) / a.tile_w;
+    a.tiles_y = (vrow_extent(a.N, a.H, a.vp) + a.tile_h - 1) / a.tile_h;
     constexpr size_t A_BYTES = (size_t)(((TH + 2) * (TW + 2) * 4 + 63) / 64) * 1024, B_BYTES = (size_t)3 * BN * 64;
     if (a.Nout > 1024) return ELD_ENOTSUP;
     const size_t lds_bytes = 2 * A_BYTES + 3 * B_BYTES + 4096;      // + bias (up to 1024 floats)
-    const long long tiles = (long long)a.tiles_x * a.tiles_y * a.N * (a.Nout / BN);
+    const long long tiles = (long long)a.tiles_x * a.tiles_y * (a.Nout / BN);
     if (tiles <= 0) return 0;
     if (tiles > 0x7fffffffLL) return ELD_ENOTSUP;
     auto kern = conv_bfd_kernel<BN, RPW, WAVES>;
@@ -373,7 +421,7 @@ int bfd_slab_bn(int Nout, int K, int N, int H, int W) {
     if (bfs_takes(Nout, K, N, H, W)) return 32;      // conv_bfs.hip: the same slab layout at BN = 32
     if (debug_kernel_mask(-1) & 4) return 0;         // test hook: everything else back on conv_igemm_kernel<bf16>
     if (K % 32 || Nout % 64) return 0;
-    const long long px_tiles = (long long)((W + TW - 1) / TW) * ((H + 15) / 16) * N;
+    const long long px_tiles = conv_tile_count(N, H, W, 16, false);
     const int cus = eld_num_cus();
     if (Nout % 128 == 0 && px_tiles * (Nout / 128) >= cus) return 128;
     return px_tiles * (Nout / 64) >= cus ? 64 : 0;
@@ -381,7 +429,7 @@ int bfd_slab_bn(int Nout, int K, int N, int H, int W) {
 
 // a: bf16 CONV_3X3 arguments already validated by launch_conv; weights in slab layout
 int launch_conv_bfd(const ConvArgs& a, hipStream_t st) {
-    if ((size_t)a.H * a.W * a.C0 * 2 >= 0xFFFFFFF0ull) return ELD_ENOTSUP;
+    if ((size_t)a.H * a.W * a.C0 * 2 * (a.N > 1 ? 2 : 1) >= 0xFFFFFFF0ull) return ELD_ENOTSUP;      // conv_bfd_kernel addresses a two-image window (virtual rows)
     if (a.pool_out && (a.epi != EPI_FWD || (a.H & 1) || (a.W & 1))) return ELD_EINVAL;
     const int bn = bfd_slab_bn(a.Nout, a.C0 + a.C1, a.N, a.H, a.W);
     if (bn == 32) return launch_conv_bfs(a, st);

@@ -428,6 +428,44 @@ int conv_fp32_algo(int set) {
     return prev;
 }
 
+// ---- tile shape of the 3x3 kernels whose pixel slots are mapped per lane (conv_x3d_kernel, conv_bfd_kernel): see conv.h ----------------------
+static long long tile_count(int N, int H, int W, int th, int tw) {
+    const int vp = vrow_pitch(N, H, th);
+    return (long long)((W + tw - 1) / tw) * ((vrow_extent(N, H, vp) + th - 1) / th);
+}
+void conv_tile_shape(int N, int H, int W, int TH, bool pooled, int& th, int& tw) {
+    th = TH; tw = 32;
+    // ELD_CONV_TILES (A/B runs of the tile choice; virtual rows stay): f = TH x 32 everywhere, p = widths 8/16/32/64 only, m<k> = widths >= k,
+    // q<k> = widths that are multiples of k
+    static int mode = -1, marg = 0;
+    if (mode < 0) {
+        const char* e = getenv("ELD_CONV_TILES");
+        mode = 0;
+        if (e && e[0] == 'f') mode = 1;
+        if (e && e[0] == 'p') mode = 2;
+        if (e && e[0] == 'm') { mode = 3; marg = atoi(e + 1); }
+        if (e && e[0] == 'q') { mode = 4; marg = atoi(e + 1) > 0 ? atoi(e + 1) : 1; }
+    }
+    if (pooled || mode == 1 || N <= 0 || H <= 0 || W <= 0) return;
+    const int slots = TH * 32, halo = (TH + 2) * 34;
+    long long best = tile_count(N, H, W, th, tw);
+    for (int w = 8; w <= 64; ++w) {                          // narrower than 8 pixels: a halo row is no longer a few whole 64-byte DMA units
+        if (mode == 2 && (w & (w - 1))) continue;
+        if (mode == 3 && w < marg) continue;
+        if (mode == 4 && w % marg) continue;
+        int h = slots / w;
+        while (h > 1 && (h + 2) * (w + 2) > halo) --h;
+        if (h > 128) h = 128;
+        const long long c = tile_count(N, H, W, h, w);
+        if (c < best) { best = c; th = h; tw = w; }
+    }
+}
+long long conv_tile_count(int N, int H, int W, int TH, bool pooled) {
+    int th, tw;
+    conv_tile_shape(N, H, W, TH, pooled, th, tw);
+    return tile_count(N, H, W, th, tw);
+}
+
 int launch_conv(const ConvArgs& a_in, int mode, hipStream_t st) {
     ConvArgs a = a_in;
     a.dbg = 0;

@@ -378,14 +378,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 //   * small blocks take taller tiles (TH = 4 / 8 rows): the 3x3 halo overhead of X falls from 2.1x to 1.6x / 1.3x.
 // LDS planes are [32-channel block][pixel][32] bf16 (64-byte rows: what ds_read_b64_tr_b16 reads conflict-free), three planes
 // (pieces) per operand.  Partials / reduction kernel / numerics are those of wgrad_kernel.
-template <typename T, int WCO, int WCI, int WPIX, int TH>      // T = float (three bf16 pieces per operand, six products) or bf16_t (the tiles as they are, one product)
+// Round 4: the spatial tile is TH x TWT pixels with TWT in {8, 16, 32} (a 16-pixel k-step = two rows of 8, one row of 16 or half a row of 32: the
+// fragment offsets below stay compile-time for all three) over the VIRTUAL-ROW strip of the batch (conv.h vrow_*).  Pixels are the K dimension
+// of this GEMM, so every padding pixel of a ragged level is a wasted MFMA column: 8-wide tiles bring 89 x 133 from 1.30x (2 x 32 tiles) to 1.03x,
+// and their 3x3 halo is smaller too (10 x 10 against 4 x 34 pixels of X per 64 pixels of G).
+template <typename T, int WCO, int WCI, int WPIX, int TH, int TWT>      // T = float (three bf16 pieces per operand, six products) or bf16_t (the tiles as they are, one product)
 __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradArgs a) {
     constexpr int ES = sizeof(T), EPU = 16 / ES, NPC = ES == 4 ? 3 : 1, XQ = 32 / EPU;      // element size, elements per 16-byte unit, pieces, units per 32-channel pixel
     static_assert(WCO * WCI * WPIX == 8, "8 waves");
     constexpr int THREADS = 512, TAPS = 9;
-    constexpr int COB = 32 * WCO, JBK = 32 * WCI, TPIX = TH * TW, PW = TPIX / WPIX, KSB = PW / 16;
+    constexpr int COB = 32 * WCO, JBK = 32 * WCI, TPIX = TH * TWT, PW = TPIX / WPIX, KSB = PW / 16;
+    static_assert(TWT == 8 || TWT == 16 || TWT == 32, "tile width");
     static_assert(PW % 16 == 0 && PW >= 16, "a wave's pixel slice is a whole number of 16-pixel k-steps");
-    constexpr int X_PIX = (TH + 2) * (TW + 2);
+    constexpr int X_PIX = (TH + 2) * (TWT + 2);
     // a 32-channel block of G is padded by one 64-byte row: the staging stores of one pixel's blocks (consecutive lanes) land on different banks
     // (block planes of TPIX x 64 B are multiples of the 256-byte bank row: 2-way conflicts on every G store without the pad)
     constexpr int GBLK = TPIX * 32 + (ES == 4 ? 32 : 0);      // (fp32 inputs only: -6 % on the 128 x 64 blocks; the bf16 kernels measured +2...+3 % with the pad)
@@ -415,20 +420,21 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradArgs a) {
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     float4 bsum4 = make_float4(0.f, 0.f, 0.f, 0.f), bsum4b = make_float4(0.f, 0.f, 0.f, 0.f);      // bias sums of this thread's channel group (second quad: bf16 units of 8)
 
-    const int tiles_per_img = a.tiles_x * a.tiles_y;
-    const int ntiles = tiles_per_img * a.N;
+    const int ntiles = a.tiles_x * a.tiles_y;                         // tiles_y counts TH-row tiles of the virtual-row strip (all images)
+    const int VP = a.vp;
+    const bool seam = VP % TH != 0;                                   // tiles may straddle two images (conv.h vrow_pitch)
     constexpr unsigned OOB = 0xFFFFFFF0u;
     // ---- per-thread staging constants -----------------------------------------------------------------------------------------
     // G unit u = tid + it*512: pixel lp = u / G_Q, channel quad part = u % G_Q (the same for every `it`)
     //   -> pixel lp0 + it*G_STEP with lp0 = tid / G_Q < G_STEP: row / column of every iteration follow from (lp0, it) by constants
     constexpr int G_STEP = THREADS / G_Q;                             // 16, 32 or 64 pixels per pass
     const int g_part = tid % G_Q, g_lp0 = tid / G_Q;
-    const int g_px0 = g_lp0 % TW, g_py0 = g_lp0 / TW;
-    const unsigned g_off0 = (unsigned)((g_py0 * a.W + g_px0) * a.CA + i0 + g_part * EPU) * (unsigned)ES;
+    const int g_px0 = g_lp0 % TWT, g_py0 = g_lp0 / TWT;
+    const unsigned g_off0 = (unsigned)(g_px0 * a.CA + i0 + g_part * EPU) * (unsigned)ES;      // column / channel part; the row part follows the strip per tile
     const int g_lds0 = ((g_part * EPU) >> 5) * GBLK + g_lp0 * 32 + ((g_part * EPU) & 31);
     auto g_pxy = [&](int it, int& dpx, int& dpy) {                    // pixel offset of pass `it` relative to (g_px0, g_py0): compile-time
-        if (G_STEP >= TW) { dpx = 0; dpy = it * (G_STEP / TW); }
-        else { dpx = (it * G_STEP) % TW; dpy = (it * G_STEP) / TW; }   // G_STEP == 16: lp0 < 16, so px0 + dpx < 32 stays in the row
+        if (G_STEP >= TWT) { dpx = 0; dpy = it * (G_STEP / TWT); }
+        else { dpx = (it * G_STEP) % TWT; dpy = (it * G_STEP) / TWT; }   // G_STEP == 16, TWT == 32: lp0 < 16, so px0 + dpx < 32 stays in the row
     };
     // X unit (per 32-channel block) u = tid + it*512: halo pixel hp = u / 8, quad part = u % 8; (hy, hx) packed in one register
     const int x_part = (int)((unsigned)tid % (unsigned)XQ);
@@ -436,8 +442,8 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradArgs a) {
 #pragma unroll
     for (int it = 0; it < X_IT; ++it) {
         const int hp = (int)((unsigned)(tid + it * THREADS) / (unsigned)XQ);
-        const int hy = hp / (TW + 2);
-        x_hyx[it] = (hy << 8) | (hp - hy * (TW + 2));
+        const int hy = hp / (TWT + 2);
+        x_hyx[it] = (hy << 8) | (hp - hy * (TWT + 2));
     }
     auto x_alive = [&](int it) { return (it + 1) * THREADS <= X_UNITS1 || (int)((unsigned)(tid + it * THREADS) / (unsigned)XQ) < X_PIX; };
     // sources of the WCI 32-channel blocks of X (virtual concat [x0, x1]); blocks beyond C0 + C1 are zero padding
@@ -451,30 +457,69 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradArgs a) {
     }
     float4 rg[G_IT], rx[WCI][X_IT];
     const size_t g_img = (size_t)a.H * a.W * a.CA * ES;
+    // A tile's rows are rows of the strip: strip row v0 + r lies in image img0 = v0 / VP (r below the end of that image's pitch) or in the next one.
+    // seam == false (the pitch is a multiple of TH: every level whose height is): a tile lies inside ONE image -- a scalar tile base plus per-thread
+    // constants, rows past the image end fall outside the one-image descriptor (zero fill): the round-3 addressing, 3 VALU instructions per load.
+    // seam == true: both operands are addressed through a two-image window at image img0; a row is in the window's first image (r < lim0), in its
+    // second (r >= nxt: the same per-thread constant on a second scalar base) or in the separator (no load).  Separator rows, rows past the last
+    // image and columns outside the image read as zeros -- the convolution's padding for X and "no pixel" for G.
+    const unsigned g_rowc = (unsigned)(g_py0 * a.W * a.CA) * (unsigned)ES;      // this thread's row part of the G offset
     auto load_tile = [&](int tile) {
-        const int img = tile / tiles_per_img;
-        const int trem = tile - img * tiles_per_img;
-        const int ty = trem / a.tiles_x, tx = trem - ty * a.tiles_x;
-        const int y0 = ty * TH, x0 = tx * TW;
-        const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)(static_cast<const char*>(a.g) + (size_t)img * g_img), 0, (int)g_img, 0x00020000);
-        const int gbase = (y0 * a.W + x0) * a.CA * ES;                // rows past the image end fall outside the descriptor: zero fill
+        const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+        const int v0 = ty * TH, x0 = tx * TWT;
+        const int img0 = v0 / VP, vrel = v0 - img0 * VP;
         const int wrem = a.W - x0;
+        if (!seam) {
+            const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)(static_cast<const char*>(a.g) + (size_t)img0 * g_img), 0, (int)g_img, 0x00020000);
+            const int gbase = (vrel * a.W + x0) * a.CA * ES;          // rows past the image end fall outside the descriptor: zero fill
+#pragma unroll
+            for (int it = 0; it < G_IT; ++it) {
+                int dpx, dpy;
+                g_pxy(it, dpx, dpy);
+                const unsigned off = g_off0 + g_rowc + (unsigned)((dpy * a.W + dpx) * a.CA) * (unsigned)ES;
+                rg[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, g_px0 + dpx < wrem ? (int)off : (int)OOB, gbase, 0));
+            }
+#pragma unroll
+            for (int cb = 0; cb < WCI; ++cb) {
+                const size_t x_img = (size_t)a.H * a.W * xC[cb] * ES;
+                const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(xs[cb] ? xs[cb] + (size_t)img0 * x_img : nullptr), 0, xs[cb] ? (int)x_img : 0, 0x00020000);
+#pragma unroll
+                for (int it = 0; it < X_IT; ++it) {
+                    const int gy = vrel - 1 + (x_hyx[it] >> 8), gx = x0 - 1 + (x_hyx[it] & 255);
+                    const bool ok = x_alive(it) && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
+                    const unsigned off = ok ? (unsigned)((gy * a.W + gx) * xC[cb] + xc0[cb] + x_part * EPU) * (unsigned)ES : OOB;
+                    rx[cb][it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)off, 0, 0));
+                }
+            }
+            return;
+        }
+        const int nimg = a.N - img0 < 2 ? a.N - img0 : 2;
+        const int lim0 = a.H - vrel, nxt = VP - vrel;                 // tile rows [0, lim0): first image; [nxt, nxt + H): second image
+        const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)(static_cast<const char*>(a.g) + (size_t)img0 * g_img), 0, (int)(g_img * nimg), 0x00020000);
+        const unsigned gb0 = (unsigned)((vrel * a.W + x0) * a.CA) * (unsigned)ES;
+        const unsigned gb1 = (unsigned)(((a.H - nxt) * a.W + x0) * a.CA) * (unsigned)ES;      // (may wrap: only ever added to offsets of rows >= nxt)
 #pragma unroll
         for (int it = 0; it < G_IT; ++it) {
             int dpx, dpy;
             g_pxy(it, dpx, dpy);
-            const unsigned off = g_off0 + (unsigned)((dpy * a.W + dpx) * a.CA) * (unsigned)ES;
-            rg[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, g_px0 + dpx < wrem ? (int)off : (int)OOB, gbase, 0));
+            const int r = g_py0 + dpy;
+            const bool second = r >= nxt;
+            const bool ok = (r < lim0 || (second && r - nxt < a.H)) && g_px0 + dpx < wrem;
+            const unsigned off = (second ? gb1 : gb0) + g_off0 + g_rowc + (unsigned)((dpy * a.W + dpx) * a.CA) * (unsigned)ES;
+            rg[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, ok ? (int)off : (int)OOB, 0, 0));
         }
 #pragma unroll
         for (int cb = 0; cb < WCI; ++cb) {
             const size_t x_img = (size_t)a.H * a.W * xC[cb] * ES;
-            const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(xs[cb] ? xs[cb] + (size_t)img * x_img : nullptr), 0, xs[cb] ? (int)x_img : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(xs[cb] ? xs[cb] + (size_t)img0 * x_img : nullptr), 0, xs[cb] ? (int)(x_img * nimg) : 0, 0x00020000);
 #pragma unroll
             for (int it = 0; it < X_IT; ++it) {
-                const int gy = y0 - 1 + (x_hyx[it] >> 8), gx = x0 - 1 + (x_hyx[it] & 255);
-                const bool ok = x_alive(it) && (unsigned)gy < (unsigned)a.H && (unsigned)gx < (unsigned)a.W;
-                const unsigned off = ok ? (unsigned)((gy * a.W + gx) * xC[cb] + xc0[cb] + x_part * EPU) * (unsigned)ES : OOB;
+                const int r = (x_hyx[it] >> 8) - 1, gx = x0 - 1 + (x_hyx[it] & 255);      // halo row relative to the tile's first row
+                const bool second = r >= nxt;
+                const int wrow = second ? a.H + r - nxt : vrel + r;                           // row inside the window
+                const bool rok = second ? r - nxt < a.H : (unsigned)(vrel + r) < (unsigned)a.H;      // vrel + r == -1: the separator above / the strip's top edge
+                const bool ok = x_alive(it) && rok && (unsigned)gx < (unsigned)a.W;
+                const unsigned off = ok ? (unsigned)((wrow * a.W + gx) * xC[cb] + xc0[cb] + x_part * EPU) * (unsigned)ES : OOB;
                 rx[cb][it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)off, 0, 0));
             }
         }
@@ -516,9 +561,9 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradArgs a) {
     // fragment addresses (see wgrad_kernel): a 16-lane group reads a [4 pixels][16 channels] block per ds_read_b64_tr_b16
     const int gi = lane & 15, gg = lane >> 4;
     const int lq0 = wpix * PW + 8 * hi + (gi >> 2);
-    const int pyq = lq0 / TW, pxq = lq0 - pyq * TW;
+    const int pyq = lq0 / TWT, pxq = lq0 - pyq * TWT;                 // (the +4 pixels of tr8's second read and the k-step offsets below never leave the row)
     const bf16_t* gq = ldsG + wco * GBLK + lq0 * 32 + (gg & 1) * 16 + (gi & 3) * 4;
-    const bf16_t* xq = ldsX + (wci * X_PIX + pyq * (TW + 2) + pxq) * 32 + (gg & 1) * 16 + (gi & 3) * 4;
+    const bf16_t* xq = ldsX + (wci * X_PIX + pyq * (TWT + 2) + pxq) * 32 + (gg & 1) * 16 + (gi & 3) * 4;
     auto tr8 = [](const bf16_t* p0) {
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
         const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 4 * 32));
@@ -534,7 +579,7 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradArgs a) {
 #pragma unroll
         for (int ks = 0; ks < KSB; ++ks) {
             const int lrel = ks * 16;
-            const int dy0 = lrel / TW, dxp = lrel - dy0 * TW;
+            const int dy0 = lrel / TWT, dxp = lrel - dy0 * TWT;
             bf16x8 ga[NPC];
 #pragma unroll
             for (int pc = 0; pc < NPC; ++pc) ga[pc] = tr8(gq + pc * GPL + lrel * 32);
@@ -543,7 +588,7 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradArgs a) {
                 bf16x8 xb[3][NPC];
 #pragma unroll
                 for (int tt = 0; tt < 3; ++tt) {
-                    const int xoff = (dy0 + t0 / 3) * (TW + 2) + dxp + tt;
+                    const int xoff = (dy0 + t0 / 3) * (TWT + 2) + dxp + tt;
 #pragma unroll
                     for (int pc = 0; pc < NPC; ++pc) xb[tt][pc] = tr8(xq + pc * XPL + xoff * 32);
                 }
@@ -607,30 +652,45 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradArgs a) {
 }
 
 // block shape of wgrad8_kernel for a layer (CA out-channels of G, CBp padded in-channels of X); false: the layer stays on wgrad_kernel.
-// bf16 inputs keep one plane per operand (a third of the LDS of the three-piece tiles), so every block shape takes 8-row tiles:
-// halo overhead of X 1.33x instead of 2.1x / 1.6x and a quarter of the barriers per pixel.
-bool wgrad8_shape(int CA, int CBp, int& COB, int& JBK, int& TH, bool bf16) {
+// bf16 inputs keep one plane per operand (a third of the LDS of the three-piece tiles), so every block shape takes 256-pixel tiles:
+// halo overhead of X 1.33x instead of 1.6x and a quarter of the barriers per pixel.  The 128 x 64 blocks take tiles 8 pixels wide (round 4):
+// the levels they run on are 532, 266, 133 pixels wide -- 536 / 272 / 136 columns of 8-wide tiles against 544 / 288 / 160 of 32-wide ones --
+// and the halo of a 64-pixel tile shrinks from 4 x 34 to 10 x 10 pixels.
+bool wgrad8_shape(int CA, int CBp, int& COB, int& JBK, int& TH, int& TWo, bool bf16) {
     if (CA % 32 || CBp % 32) return false;
+    TWo = 32;
     if (CA % 128 == 0 && CBp % 64 == 0) { COB = 128; JBK = 64; TH = 2; }
     else if (CA % 64 == 0 && CBp % 64 == 0) { COB = 64; JBK = 64; TH = 2; }      // fp32: TH = 4 spills 9 registers: 3.06 vs 2.79 ms (measured)
     else if (CA % 64 == 0) { COB = 64; JBK = 32; TH = 4; }
     else if (CBp % 64 == 0) { COB = 32; JBK = 64; TH = 4; }
     else { COB = 32; JBK = 32; TH = 4; }
     if (bf16) TH = 8;
+    // the 128 x 64 blocks are the >= 128-channel layers = the ragged levels (356 x 532 and below): 8-wide tiles of the same pixel count.  The
+    // 32 / 64-channel layers sit on 2128- and 1064-pixel rows (nothing to win) and are bound by their staging traffic: 8-wide tiles measured
+    // 3 ... 19 % slower there (profiles/r04_ab_notes.md)
+    if (COB == 128) { TH = TH * 4; TWo = 8; }
     return true;
 }
 
-template <typename T, int WCO, int WCI, int WPIX, int TH>
+int wgrad8_ntiles(int CA, int CBp, int N, int H, int W, bool bf16) {
+    int COB, JBK, TH, TWo;
+    if (!wgrad8_shape(CA, CBp, COB, JBK, TH, TWo, bf16)) return 0;
+    const int VP = vrow_pitch(N, H, TH);
+    return ((W + TWo - 1) / TWo) * ((vrow_extent(N, H, VP) + TH - 1) / TH);
+}
+
+template <typename T, int WCO, int WCI, int WPIX, int TH, int TWT>
 static int launch_w8(WgradArgs a, hipStream_t st) {
     constexpr int COB = 32 * WCO, JBK = 32 * WCI;
-    a.tiles_x = (a.W + TW - 1) / TW;
-    a.tiles_y = (a.H + TH - 1) / TH;
-    size_t lds_bytes = (size_t)((TH * TW * 32 + (sizeof(T) == 4 ? 32 : 0)) * (COB / 32) + (TH + 2) * (TW + 2) * JBK) * (sizeof(T) == 4 ? 6 : 2);
+    a.vp = vrow_pitch(a.N, a.H, TH);
+    a.tiles_x = (a.W + TWT - 1) / TWT;
+    a.tiles_y = (vrow_extent(a.N, a.H, a.vp) + TH - 1) / TH;
+    size_t lds_bytes = (size_t)((TH * TWT * 32 + (sizeof(T) == 4 ? 32 : 0)) * (COB / 32) + (TH + 2) * (TWT + 2) * JBK) * (sizeof(T) == 4 ? 6 : 2);
     const size_t red_bytes = (size_t)7 * 16 * 64 * sizeof(float) * 1;       // WPIX-1 <= 7 slices of WCO*WCI*WPIX/... tiles: (WPIX-1)*WCO*WCI <= 7
     if (lds_bytes < red_bytes) lds_bytes = red_bytes;
     const long long blocks = (long long)(a.CA / COB) * (a.CBp / JBK) * a.psplit;
     if (blocks <= 0) return 0;
-    auto kern = wgrad8_kernel<T, WCO, WCI, WPIX, TH>;
+    auto kern = wgrad8_kernel<T, WCO, WCI, WPIX, TH, TWT>;
     static EldAttrOnce once;
     { const int rc = once.ensure(kern, lds_bytes); if (rc) return rc; }
     ELD_LAUNCH(kern, dim3((unsigned)blocks), dim3(512), lds_bytes, st, a);
@@ -641,22 +701,24 @@ static int launch_w8(WgradArgs a, hipStream_t st) {
 static int launch_wgrad8(const WgradArgs& a, hipStream_t st) {
     const bool bf16 = a.dtype == DT_BF16;
     const size_t es = bf16 ? 2 : 4;
-    int COB, JBK, TH;
-    if (!wgrad8_shape(a.CA, a.CBp, COB, JBK, TH, bf16)) return ELD_ENOTSUP;
+    int COB, JBK, TH, TWo;
+    if (!wgrad8_shape(a.CA, a.CBp, COB, JBK, TH, TWo, bf16)) return ELD_ENOTSUP;
     if ((a.C0 % 32) || (a.C1 % 32)) return ELD_ENOTSUP;
-    if ((size_t)a.H * a.W * a.CA * es >= 0x7FFFFFF0ull || (size_t)a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) * es >= 0x7FFFFFF0ull) return ELD_ENOTSUP;
+    // both operands are addressed through a window of two images (virtual rows): it must fit a buffer descriptor with 32-bit offsets
+    const size_t win = a.N > 1 ? 2 : 1;
+    if ((size_t)a.H * a.W * a.CA * es * win >= 0xFFFFFFF0ull || (size_t)a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) * es * win >= 0xFFFFFFF0ull) return ELD_ENOTSUP;
     if (bf16) {
-        if (COB == 128) return launch_w8<bf16_t, 4, 2, 1, 8>(a, st);
-        if (COB == 64 && JBK == 64) return launch_w8<bf16_t, 2, 2, 2, 8>(a, st);
-        if (COB == 64) return launch_w8<bf16_t, 2, 1, 4, 8>(a, st);
-        if (JBK == 64) return launch_w8<bf16_t, 1, 2, 4, 8>(a, st);
-        return launch_w8<bf16_t, 1, 1, 8, 8>(a, st);
+        if (COB == 128) return launch_w8<bf16_t, 4, 2, 1, 32, 8>(a, st);
+        if (COB == 64 && JBK == 64) return launch_w8<bf16_t, 2, 2, 2, 8, 32>(a, st);
+        if (COB == 64) return launch_w8<bf16_t, 2, 1, 4, 8, 32>(a, st);
+        if (JBK == 64) return launch_w8<bf16_t, 1, 2, 4, 8, 32>(a, st);
+        return launch_w8<bf16_t, 1, 1, 8, 8, 32>(a, st);
     }
-    if (COB == 128) return launch_w8<float, 4, 2, 1, 2>(a, st);
-    if (COB == 64 && JBK == 64) return launch_w8<float, 2, 2, 2, 2>(a, st);
-    if (COB == 64) return launch_w8<float, 2, 1, 4, 4>(a, st);
-    if (JBK == 64) return launch_w8<float, 1, 2, 4, 4>(a, st);
-    return launch_w8<float, 1, 1, 8, 4>(a, st);
+    if (COB == 128) return launch_w8<float, 4, 2, 1, 8, 8>(a, st);
+    if (COB == 64 && JBK == 64) return launch_w8<float, 2, 2, 2, 2, 32>(a, st);
+    if (COB == 64) return launch_w8<float, 2, 1, 4, 4, 32>(a, st);
+    if (JBK == 64) return launch_w8<float, 1, 2, 4, 4, 32>(a, st);
+    return launch_w8<float, 1, 1, 8, 4, 32>(a, st);
 }
 
 template <typename T, int MODE, int WCO, int TH, int ALG = ALG_F32>

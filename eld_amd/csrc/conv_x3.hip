@@ -384,8 +384,15 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
     // partial sums; x3_splitk_finish_kernel adds them in a fixed order and runs the epilogue
     constexpr bool SPLITK = WAVES == 4;                                     // only the small-tile variant carries the split (the 8-wave kernels have no register to spare)
     const int KS = SPLITK && a.ksplit > 1 ? a.ksplit : 1;
-    const int total_tiles = a.tiles_x * a.tiles_y * a.N * NB * KS;          // work items
+    const int total_tiles = a.tiles_x * a.tiles_y * NB * KS;                // work items; tiles_y: tile rows of the virtual strip (all images)
     const int Cs0 = a.C0;
+    // Round 4 (see conv_bfd.hip): the workgroup's TH * 32 pixel slots are the pixels of a tile_h x tile_w tile of the launch's choosing
+    // (slot p = tile pixel (p / tile_w, p % tile_w)), rows are rows of the virtual strip of the batch (conv.h vrow_*).
+    const int THL = a.tile_h, TWL = a.tile_w, HWL = TWL + 2;
+    const int APX = (THL + 2) * HWL, NPX = THL * TWL, VP = a.vp;
+    const bool seam = VP % THL != 0;
+    const unsigned mag_hw = (unsigned)((0x100000000ull + (unsigned)HWL - 1) / (unsigned)HWL);      // x / HWL == umulhi(x, mag_hw) for x < 2^16
+    const unsigned mag_tw = (unsigned)((0x100000000ull + (unsigned)TWL - 1) / (unsigned)TWL);
 
     constexpr int A_UNITS = A_PIX * 4;
     constexpr int A_IT = (A_UNITS + THREADS - 1) / THREADS;
@@ -398,33 +405,43 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
     const i32x4 rsrc_w = {(int)(unsigned)wbase, (int)((unsigned)(wbase >> 32) & 0xFFFFu), (int)((size_t)3 * NCH * NB * B_WORDS * 4), 0x00020000};
     const unsigned dma_voff = (unsigned)lane * 16u;
 
-    auto decode = [&](int t, int& nb, int& img, int& y0, int& x0) {
+    // tile -> channel block, image of the tile's first strip row (img0), that row's offset in the image's pitch (vrel), first column
+    auto decode = [&](int t, int& nb, int& img0, int& vrel, int& x0) {
         nb = t % NB;
-        int r = t / NB;
-        const int tx = r % a.tiles_x;
-        r /= a.tiles_x;
-        const int ty = r % a.tiles_y;
-        img = r / a.tiles_y;
-        y0 = ty * TH; x0 = tx * TW;
+        const int r = t / NB;
+        const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+        const int v0 = ty * THL;
+        img0 = v0 / VP; vrel = v0 - img0 * VP;
+        x0 = tx * TWL;
+    };
+    // strip row relative to image img0's pitch -> (image offset 0 / 1, row); false: a separator row, or beyond the strip
+    auto strip_row = [&](int row, int& dimg, int& y) -> bool {
+        const bool over = row >= VP;
+        dimg = over ? 1 : 0;
+        y = over ? row - VP : row;
+        return over ? seam && y < a.H : (unsigned)row < (unsigned)a.H;
     };
     auto setup_load = [&](int t) {
-        int nb, y0, x0;
-        decode(t, nb, l_img, y0, x0);
+        int nb, vrel, x0;
+        decode(t, nb, l_img, vrel, x0);
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int u = tid + it * THREADS;
             const int hp = stage_row(u >> 2, A_PIX), part = u & 3;
-            const int hy = hp / (TW + 2), hx = hp - hy * (TW + 2);
-            const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-            const bool ok = u < A_UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            a_voff[it] = ok ? (unsigned)(gy * a.W + gx) * (unsigned)(Cs0 * 4) + (unsigned)part * 16u : OOB;
+            const int hy = (int)__umulhi((unsigned)hp, mag_hw), hx = hp - hy * HWL;
+            int dimg, y;
+            const bool rok = strip_row(vrel + hy - 1, dimg, y);
+            const int gx = x0 + hx - 1;
+            const bool ok = u < A_UNITS && hp < APX && rok && gx >= 0 && gx < a.W;      // rows of a second image that does not exist: outside the descriptor
+            a_voff[it] = ok ? (unsigned)((dimg * a.H + y) * a.W + gx) * (unsigned)(Cs0 * 4) + (unsigned)part * 16u : OOB;
         }
     };
     auto load_A = [&](int c0) {
         const char* src = static_cast<const char*>(c0 < a.C0 ? a.in0 : a.in1);
         const int cs = c0 < a.C0 ? c0 : c0 - a.C0;
         const size_t img_bytes = (size_t)a.H * a.W * Cs0 * 4;
-        const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)l_img * img_bytes), 0, (int)img_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)l_img * img_bytes), 0,
+                                                                                (int)(unsigned)(img_bytes * (size_t)(a.N - l_img < 2 ? a.N - l_img : 2)), 0x00020000);
 #pragma unroll
         for (int it = 0; it < A_IT; ++it)
             ra[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)a_voff[it], cs * 4, 0));
@@ -446,6 +463,15 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
         }
     };
 
+    // LDS word offset of this lane's pixel slot in MFMA column r (+ its k half): slot p = (wave * RPW + r) * 32 + m -> halo pixel (p / TWL, p % TWL)
+    int pb[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        int p = (wave * RPW + r) * 32 + m;
+        p = p < NPX ? p : 0;
+        const int tr = (int)__umulhi((unsigned)p, mag_tw);
+        pb[r] = (tr * HWL + (p - tr * TWL)) * PX + hi * 4;
+    }
     auto chunk_begin = [&](int t) { return ((t % KS) * NCH) / KS; };
     auto chunk_end = [&](int t) { return ((t % KS + 1) * NCH) / KS; };
     int t = blockIdx.x;
@@ -454,13 +480,13 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
     load_A(chunk_begin(t) * CK);
     int buf = 0;
     {
-        int nb0, i0, y00, x00;
-        decode(t / KS, nb0, i0, y00, x00);
+        int nb0, i0, v00, x00;
+        decode(t / KS, nb0, i0, v00, x00);
         dma_B(0, nb0, chunk_begin(t), 0);
     }
     for (;;) {
-        int nb, img, y0, x0;
-        decode(t / KS, nb, img, y0, x0);
+        int nb, img0, vrel, x0;
+        decode(t / KS, nb, img0, vrel, x0);
         const int t_next = t + gridDim.x;
         const int c_begin = chunk_begin(t), c_end = chunk_end(t);
         f32x16 acc[RPW][NT];
@@ -495,7 +521,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
                 auto read_tap = [&](int kx, uint4 (&X)[3][RPW], uint4 (&Wt)[3][NT]) {
 #pragma unroll
                     for (int r = 0; r < RPW; ++r) {
-                        const float* p = ldsA + ((wave * RPW + r + ky) * (TW + 2) + m + kx) * PX + hi * 4;
+                        const float* p = ldsA + pb[r] + (ky * HWL + kx) * PX;
 #pragma unroll
                         for (int pc = 0; pc < 3; ++pc) X[pc][r] = *reinterpret_cast<const uint4*>(p + pc * 8);
                     }
@@ -545,15 +571,23 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
             }
         }
 
-        // ---- epilogue: lane (m, hi) owns pixel x0+m and channels 8q+4hi..+3 of each 32-block (as conv_x3_kernel) ----
+        // ---- epilogue: lane (m, hi) owns pixel slot m of MFMA column r and channels 8q+4hi..+3 of each 32-block (as conv_x3_kernel) ----
+        // slot of column r -> NHW pixel index; false: no such pixel (slot beyond the tile, separator row, outside the image)
+        auto slot_pixel = [&](int r, int sl, size_t& pix) -> bool {
+            const int p = (wave * RPW + r) * 32 + sl;
+            const int tr = (int)__umulhi((unsigned)p, mag_tw), x = x0 + p - tr * TWL;
+            int dimg, y;
+            const bool ok = strip_row(vrel + tr, dimg, y) && p < NPX && img0 + dimg < a.N && x < a.W;
+            pix = ok ? (size_t)((img0 + dimg) * a.H + y) * a.W + x : 0;
+            return ok;
+        };
         if (KS > 1) {                            // split K: raw partial sums of this K part, [part][image][y][x][Nout]
-            const int x = x0 + m;
             float* pbase = a.kpart + (size_t)(t % KS) * ((size_t)a.N * a.H * a.W * a.Nout);
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
-                const int y = y0 + wave * RPW + r;
-                if (y >= a.H || x >= a.W) continue;
-                float* prow = pbase + ((size_t)(img * a.H + y) * a.W + x) * a.Nout + nb * BN + 4 * hi;
+                size_t pix;
+                if (!slot_pixel(r, m, pix)) continue;
+                float* prow = pbase + pix * a.Nout + nb * BN + 4 * hi;
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
@@ -561,10 +595,8 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
                         *reinterpret_cast<float4*>(prow + tt * 32 + 8 * q) = make_float4(acc[r][tt][4 * q], acc[r][tt][4 * q + 1], acc[r][tt][4 * q + 2], acc[r][tt][4 * q + 3]);
             }
         } else {
-            // stores in the full-line layout (conv.h f32_line_store: 16 pixels x 64 contiguous bytes per instruction); bias / saved activations are
-            // read in the MFMA layout (own pixel m); every lane computes and takes part in the exchange, only loads and stores are predicated
-            const int x = x0 + m;
-            const bool xok = x < a.W;
+            // stores in the full-line layout (conv.h f32_line_store2: 16 slots x 64 contiguous bytes per instruction); bias / saved activations are
+            // read in the MFMA layout (own slot m); every lane computes and takes part in the exchange, only loads and stores are predicated
             // forward: bias and max(0.2 v, v) once, in place (packed fp32 add / multiply, v_max without the canonicalising copy fmaxf() gets);
             // the pooled copy below reuses the finished values
             if (a.epi == EPI_FWD) {
@@ -580,26 +612,25 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
             }
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
-                const int y = y0 + wave * RPW + r;                      // wave-uniform
-                const bool yok = y < a.H;
-                const size_t rowpix = (size_t)(img * a.H + (yok ? y : 0)) * a.W;
-                const size_t pix = rowpix + (xok ? x : 0);
+                size_t pix, pix0, pix1;
+                slot_pixel(r, m, pix);                                  // own slot (0 where there is none: the load re-reads a valid pixel)
+                const bool ok0 = slot_pixel(r, lane & 15, pix0), ok1 = slot_pixel(r, (lane & 15) + 16, pix1);
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) {
                     const int nb32 = nb * BN + tt * 32;
                     float4 v[4];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = make_float4(acc[r][tt][4 * q], acc[r][tt][4 * q + 1], acc[r][tt][4 * q + 2], acc[r][tt][4 * q + 3]);
-                    float* blk;
+                    float* blk;                                         // channel 0 of the block in pixel 0 of the destination tensor
                     int C;
                     if (a.epi == EPI_FWD) {
                         C = a.Nout;
-                        blk = static_cast<float*>(a.out0) + (rowpix + x0) * C + nb32;
+                        blk = static_cast<float*>(a.out0) + nb32;
                     } else {                                            // a 32-channel block never straddles the concat split
                         const bool lo = nb32 < a.split;
                         C = lo ? a.split : a.Nout - a.split;
                         const int cb = lo ? nb32 : nb32 - a.split;
-                        blk = static_cast<float*>(lo ? a.out0 : a.out1) + (rowpix + x0) * C + cb;
+                        blk = static_cast<float*>(lo ? a.out0 : a.out1) + cb;
                         const float* act = static_cast<const float*>(lo ? a.act0 : a.act1);
                         if (act != nullptr) {
                             float4 s[4];
@@ -612,11 +643,15 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
                             }
                         }
                     }
-                    f32_line_store(v, blk, (size_t)C, lane, yok, a.W - x0);
+                    f32_line_store2(v, ok0 ? blk + pix0 * C : nullptr, ok1 ? blk + pix1 * C : nullptr, lane);
                 }
             }
         }
-        if (KS == 1 && a.epi == EPI_FWD && a.pool_out != nullptr) pool_epilogue<RPW, NT, BN>(a, acc, img, nb, y0 + wave * RPW, x0 + m, hi);
+        if (KS == 1 && a.epi == EPI_FWD && a.pool_out != nullptr) {     // pooled launches run TH x 32 tiles (launcher): slot m of column r = tile pixel (wave * RPW + r, m)
+            int dimg, y;
+            const bool rok = strip_row(vrel + wave * RPW, dimg, y) && img0 + dimg < a.N;
+            pool_epilogue<RPW, NT, BN>(a, acc, img0 + dimg, nb, rok ? y : a.H, x0 + m, hi);
+        }
         if (t_next >= total_tiles) break;
         t = t_next;
     }
@@ -896,10 +931,12 @@ int launch_x3(ConvArgs a, hipStream_t st) {
 template <int BN, int RPW, int WAVES, bool DB>
 int launch_x3d(ConvArgs a, hipStream_t st) {
     constexpr int TH = WAVES * RPW;
-    a.tiles_x = (a.W + TW - 1) / TW;
-    a.tiles_y = (a.H + TH - 1) / TH;
+    conv_tile_shape(a.N, a.H, a.W, TH, a.pool_out != nullptr, a.tile_h, a.tile_w);
+    a.vp = vrow_pitch(a.N, a.H, a.tile_h);
+    a.tiles_x = (a.W + a.tile_w - 1) / a.tile_w;
+    a.tiles_y = (vrow_extent(a.N, a.H, a.vp) + a.tile_h - 1) / a.tile_h;
     const size_t lds_bytes = (size_t)(TH + 2) * (TW + 2) * PX * sizeof(float) + 2 * (size_t)((3 * BN * PX * 4 + 1023) / 1024 * 1024);
-    long long tiles = (long long)a.tiles_x * a.tiles_y * a.N * (a.Nout / BN);
+    long long tiles = (long long)a.tiles_x * a.tiles_y * (a.Nout / BN);
     if (tiles <= 0) return 0;
     // split K where the smallest tiles still leave most of the chip idle (single patches: conv5_x of a 512 x 512 input is 32 workgroups) and the
     // caller provided room for the partial sums
@@ -963,7 +1000,7 @@ void conv_x3_set_prof(unsigned long long*) {}       // the s_memtime stage profi
 int x3_slab_bn(int Nout, int N, int H, int W, int* waves) {
     if (waves) *waves = 8;
     if (Nout % 64) return 0;
-    const long long px_tiles = (long long)((W + TW - 1) / TW) * ((H + 15) / 16) * N;
+    const long long px_tiles = conv_tile_count(N, H, W, 16, false);
     const int cus = eld_num_cus();
     if (Nout % 128 == 0 && px_tiles * (Nout / 128) >= cus) return 128;
     if (waves && px_tiles * (Nout / 64) < cus) *waves = 4;
@@ -977,6 +1014,9 @@ int launch_conv_x3(const ConvArgs& a_in, hipStream_t st) {
     if ((size_t)a.H * a.W * a.C0 * 4 >= 0xFFFFFFF0ull) return ELD_ENOTSUP;
     if (a.pool_out && (a.epi != EPI_FWD || (a.H & 1) || (a.W & 1))) return ELD_EINVAL;
     int waves = 8;
+    const int bn0 = x3_slab_bn(a.Nout, a.N, a.H, a.W, nullptr);
+    // conv_x3d_kernel addresses a two-image window (virtual rows)
+    if (bn0 && a.N > 1 && (size_t)a.H * a.W * a.C0 * 8 >= 0xFFFFFFF0ull) return ELD_ENOTSUP;
     const int bn = x3_slab_bn(a.Nout, a.N, a.H, a.W, &waves);
     if (bn == 128) return launch_x3d<128, 2, 8, false>(a, st);      // weights pre-split in slab layout: LDS-DMA kernel
     if (bn == 64) return waves == 8 ? launch_x3d<64, 2, 8, false>(a, st) : launch_x3d<64, 2, 4, false>(a, st);

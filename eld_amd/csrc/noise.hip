@@ -30,6 +30,8 @@
 #define RES_STEPS 5            // branch-free inversion steps of the fractional-rate draw (P(more) < 6e-4 at a rate below 1)
 #define PTRS_DENSE_MIN 13      // lanes of a wave with lam >= 32 in one pixel slot: above -> PTRS inline, else -> queue
 #define QP_CAP 768             // open PTRS draws per 4096 pixels (16 B entries: 12 of 64 lanes at most take the queue route); overflow is resolved in place
+#define NOISE_WAVES (NOISE_THREADS / 64)
+#define QP_WAVE (QP_CAP / NOISE_WAVES)      // round 4: every wave owns a slice of the queue and drains it itself -- no workgroup barrier around the Poisson phases
 #define PASS_GROUPS 1           // 4-pixel groups a lane carries through one pass of phase 1 (1: 4 pixels -> <= 128 VGPRs, 4 workgroups per CU)
 
 struct NoiseArgs {
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a)
     __shared__ uint32_t s_cnt[MAYBE_P ? ELEMS_PER_BLOCK : 1];     // (count << 9) | low 9 bits of the pixel's POIS_V word (free: u01 takes w >> 9)
     __shared__ uint4 s_qp[MAYBE_P ? QP_CAP : 1];
     __shared__ uint32_t s_tab[MAYBE_P ? POIS_TAB_N * POIS_TAB_ENT : 1];
-    __shared__ uint32_t s_qn[2];
+    __shared__ uint32_t s_qn[NOISE_WAVES];
     const uint32_t flags = (TFLAGS == RUNTIME_FLAGS) ? a.flags : TFLAGS;
     const uint32_t n = blockIdx.y;
     const EldNoiseParams P = a.params[n];             // wave-uniform -> scalar loads
@@ -242,8 +244,9 @@ __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a)
     const bool do_pois = MAYBE_P && (flags & ELD_SHOT_POISSON) && !inject;
     const float S = P.saturation, ratio = P.ratio, K = P.K;
 
+    const uint32_t wave = tid >> 6;
     if (do_pois) {
-        if (tid < 2) s_qn[tid] = 0;
+        if (tid < NOISE_WAVES) s_qn[tid] = 0;
 #pragma unroll
         for (int i = 0; i < POIS_TAB_N * POIS_TAB_ENT / NOISE_THREADS; ++i) s_tab[tid + i * NOISE_THREADS] = POIS_ALIAS[tid + i * NOISE_THREADS];
     }
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a)
             // ---- one LDS atomic per lane reserves the queue slots of its open draws ----------------------------------------
             const uint32_t pend = pendF | pendR;
             uint32_t base = 0;
-            if (pend) base = atomicAdd(&s_qn[0], (uint32_t)__popc(pend));
+            if (pend) base = atomicAdd(&s_qn[wave], (uint32_t)__popc(pend));
 #pragma unroll
             for (int e = 0; e < PE; ++e) {
                 if (!ok[e]) continue;
@@ -369,22 +372,27 @@ __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a)
                 if (pend & (1u << e)) {
                     const bool fresh = (pendF >> e) & 1u;
                     const uint32_t pos = base + (uint32_t)__popc(pend & ((1u << e) - 1u));
-                    if (pos < QP_CAP) s_qp[pos] = make_uint4(le | (fresh ? 0x80000000u : 0u), __float_as_uint(lam[e]), w[e], wv[e]);
+                    if (pos < QP_WAVE) s_qp[wave * QP_WAVE + pos] = make_uint4(le | (fresh ? 0x80000000u : 0u), __float_as_uint(lam[e]), w[e], wv[e]);
                     else s_cnt[le] = pack_cnt(ptrs_resolve(lam[e], g_begin * 4u + le, rng, fresh, w[e], wv[e]), wv[e]);
                 } else {
                     s_cnt[le] = pack_cnt((float)kk[e], wv[e]);
                 }
             }
         }
-        __syncthreads();
-        // ---- phase 2: drain the queue with dense lanes -----------------------------------------------------------------
-        const uint32_t nP = (ELD_DBG(a) & 1) ? 0u : min(s_qn[0], (uint32_t)QP_CAP);
-        for (uint32_t q = tid; q < nP; q += NOISE_THREADS) {
-            const uint4 en = s_qp[q];
+        // ---- phase 2: the wave drains ITS OWN queue slice with dense lanes ----------------------------------------------------
+        // Everything a wave reads from here on (its queue slice, the counts of its own pixels) was written by the wave itself: LDS operations of a
+        // wave execute in order, so no workgroup barrier is needed -- only the compiler must keep the order (round 3 had two barriers here, and
+        // a third of the wave time of the full model was spent parked at them waiting for the slowest wave's rejection loops).
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t nP = (ELD_DBG(a) & 1) ? 0u : min(s_qn[wave], (uint32_t)QP_WAVE);
+        for (uint32_t q = tid & 63u; q < nP; q += 64u) {
+            const uint4 en = s_qp[wave * QP_WAVE + q];
             const uint32_t le = en.x & 0x7FFFFFFFu;
             s_cnt[le] = pack_cnt(ptrs_resolve(__uint_as_float(en.y), g_begin * 4u + le, rng, (en.x >> 31) != 0u, en.z, en.w), en.w);
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 
     // ================================ phase 3: the rest of the model + reference arithmetic ===================
@@ -627,6 +635,8 @@ __global__ void philox_words_kernel(uint32_t* out, uint32_t n, uint32_t index0, 
     const uint4 w = rng.words(index0 + i, stream, iter);
     reinterpret_cast<uint4*>(out)[i] = w;
 }
+
+extern "C" int eld_philox_rounds(void) { return ELD_PHILOX_ROUNDS; }
 
 extern "C" int eld_philox_words(uint32_t* out, uint32_t n, uint32_t index0, uint64_t sample_id,
                                 uint32_t stream, uint32_t iter, uint64_t seed, void* stream_h) {

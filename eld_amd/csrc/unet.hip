@@ -6,6 +6,8 @@
 // Network (models/arch/Unet.py:6-91): 5 scales, channels 32/64/128/256/512, 18 conv3x3+LeakyReLU,
 // 4 maxpool2, 4 transposed conv 2x2/s2, 4 channel concats [up, skip] (never materialised: the conv
 // kernels read two sources), 1x1 head.
+#include <mutex>
+#include <unordered_map>
 #include <math.h>
 #include "unet_misc.h"
 
@@ -66,12 +68,12 @@ WgradGeom wgrad_geom(int mode, int CA, int CB, int N, int H, int W, int algo) {
     g.CA = CA;
     g.CBp = (CB + 31) / 32 * 32;
     g.w8 = 0;
-    int cob8, jb8, th8;
-    // algo 3 = bf16 tensors on the same re-blocked kernel (one plane per operand, 8-row tiles)
-    if ((algo == 1 || algo == 3) && mode == CONV_3X3 && CB % 32 == 0 && wgrad8_shape(CA, g.CBp, cob8, jb8, th8, algo == 3)) {
+    int cob8, jb8, th8, tw8;
+    // algo 3 = bf16 tensors on the same re-blocked kernel (one plane per operand, 256-pixel tiles)
+    if ((algo == 1 || algo == 3) && mode == CONV_3X3 && CB % 32 == 0 && wgrad8_shape(CA, g.CBp, cob8, jb8, th8, tw8, algo == 3)) {
         g.w8 = 1;
         g.groups = (CA / cob8) * (g.CBp / jb8);
-        g.ntiles = ((W + 31) / 32) * ((H + th8 - 1) / th8) * N;
+        g.ntiles = wgrad8_ntiles(CA, g.CBp, N, H, W, algo == 3);
         int ps = 256 / g.groups;
         if (ps > g.ntiles) ps = g.ntiles;
         g.psplit = ps < 1 ? 1 : ps;
@@ -619,6 +621,29 @@ extern "C" size_t eld_unet_workspace_bytes(int N, int H, int W, int in_ch, int o
     return P.total * sizeof(float);
 }
 
+// Which forward last filled a workspace (host call order = stream order for calls on one stream): eld_unet_backward_ex with dout == NULL consumes
+// the gradient buffer and the head partials that ONLY eld_unet_forward_loss_ex leaves there, for exactly its N / H / W / precision.  Keyed by the
+// workspace pointer; a plain forward on the same workspace clears the entry.  Host bookkeeping only: no device read, no synchronisation.
+namespace {
+struct HeadState { int N, H, W, in_ch, out_ch, precision; };
+std::mutex g_head_mu;
+std::unordered_map<const void*, HeadState> g_head;
+void head_state_set(const void* ws, const HeadState* st) {
+    std::lock_guard<std::mutex> lk(g_head_mu);
+    if (st) {
+        if (g_head.size() > 256) g_head.clear();      // workspaces come and go with their owners: stay small
+        g_head[ws] = *st;
+    } else g_head.erase(ws);
+}
+bool head_state_is(const void* ws, const HeadState& want) {
+    std::lock_guard<std::mutex> lk(g_head_mu);
+    const auto it = g_head.find(ws);
+    if (it == g_head.end()) return false;
+    const HeadState& h = it->second;
+    return h.N == want.N && h.H == want.H && h.W == want.W && h.in_ch == want.in_ch && h.out_ch == want.out_ch && h.precision == want.precision;
+}
+}  // namespace
+
 static int unet_entry_checks(Plan& P, const void* a, const void* b, const void* c, const void* ws, size_t ws_bytes, int N, int H, int W, int in_ch, int out_ch) {
     RC(make_plan(P, N, H, W, in_ch, out_ch));
     if (!a || !b || !c || !ws) return ELD_EINVAL;
@@ -633,6 +658,7 @@ extern "C" int eld_unet_forward_ex(const float* x, const float* params, float* o
     Plan P;
     RC(unet_entry_checks(P, x, params, out, ws, ws_bytes, N, H, W, in_ch, out_ch));
     AlgoScope scope(fp32_algo);
+    head_state_set(ws, nullptr);      // whatever fused head state the workspace held is overwritten
     return precision == 1 ? unet_forward_bf16(P, x, params, out, (float*)ws, as_stream(stream)) : unet_forward(P, x, params, out, (float*)ws, as_stream(stream));
 }
 
@@ -644,7 +670,10 @@ extern "C" int eld_unet_forward_loss_ex(const float* x, const float* params, con
     RC(unet_entry_checks(P, x, params, out, ws, ws_bytes, N, H, W, in_ch, out_ch));
     AlgoScope scope(fp32_algo);
     const HeadLoss hl = {target, loss, loss_kind, grad_scale};
-    return precision == 1 ? unet_forward_bf16(P, x, params, out, (float*)ws, as_stream(stream), &hl) : unet_forward(P, x, params, out, (float*)ws, as_stream(stream), &hl);
+    head_state_set(ws, nullptr);
+    const int rc = precision == 1 ? unet_forward_bf16(P, x, params, out, (float*)ws, as_stream(stream), &hl) : unet_forward(P, x, params, out, (float*)ws, as_stream(stream), &hl);
+    if (rc == 0) { const HeadState hs = {N, H, W, in_ch, out_ch, precision}; head_state_set(ws, &hs); }
+    return rc;
 }
 extern "C" int eld_unet_backward_ex(const float* dout, const float* params, float* grads, void* ws, size_t ws_bytes, int N, int H, int W,
                                     int in_ch, int out_ch, int precision, int fp32_algo, const int64_t* bucket_start, void* const* bucket_event,
@@ -654,6 +683,9 @@ extern "C" int eld_unet_backward_ex(const float* dout, const float* params, floa
     Plan P;
     RC(unet_entry_checks(P, dout ? (const void*)dout : (const void*)params, params, grads, ws, ws_bytes, N, H, W, in_ch, out_ch));      // dout == NULL: the head's share was done by eld_unet_forward_loss_ex
     if (n_buckets < 0 || (n_buckets > 0 && (!bucket_start || !bucket_event))) return ELD_EINVAL;
+    // dout == NULL is only meaningful right after eld_unet_forward_loss_ex on this workspace with the same problem: anything else would hand back
+    // stale head gradients without a sign of trouble
+    if (!dout) { const HeadState hs = {N, H, W, in_ch, out_ch, precision}; if (!head_state_is(ws, hs)) return ELD_EINVAL; }
     for (int k = 0; k < n_buckets; ++k)
         if (!bucket_event[k] || bucket_start[k] < 0 || (k > 0 && bucket_start[k] <= bucket_start[k - 1]) || (size_t)bucket_start[k] >= P.nparams) return ELD_EINVAL;
     BucketMarks marks;

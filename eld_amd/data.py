@@ -153,17 +153,28 @@ class ELDTrainDataset(tdata.Dataset):
         self.flag = flag
         self.augment = augment
         self.cfa = cfa
+        # SynDataset applies the noise to ITS OWN dataset[i] (sid_dataset.py:265-275), independently of target_dataset.  When both
+        # are the same database read at the same index for EVERY i (train_syn.py:61-64: SynDataset(LMDBDataset(SID_Sony_Raw.db)) beside
+        # the same target database, no `size` wrap-around) the clean patch IS the target: it is read once and travels once.  Decided once per
+        # input dataset, so that every sample of a run carries the same keys (default_collate takes them from the first sample of a batch).
+        self._shared = [self._shares_target(d) for d in input_datasets]
+
+    def _shares_target(self, d):
+        if not isinstance(d, SynDataset):
+            return False
+        src, tgt = d.dataset, self.target_dataset
+        if src is not tgt and not (getattr(src, 'db_path', None) is not None and getattr(src, 'db_path', None) == getattr(tgt, 'db_path', object())
+                                   and getattr(src, 'length', None) == getattr(tgt, 'length', object())):
+            return False
+        try:                                                 # SynDataset reads dataset[i % (size or len(dataset))]: the index must never wrap below len(target)
+            return (d.size is None or d.size >= len(tgt)) and len(src) >= len(tgt)
+        except TypeError:
+            return False
 
     def __getitem__(self, i):
         N = len(self.input_datasets)
         inp = self.input_datasets[i % N][i // N]
-        # SynDataset applies the noise to ITS OWN dataset[i] (sid_dataset.py:265-275), independently of target_dataset.  When both
-        # are the same database read at the same index (train_syn.py:61-64: SynDataset(LMDBDataset(SID_Sony_Raw.db)) beside the
-        # same target database) the clean patch IS the target: it is read once and travels once.  Otherwise it travels as 'clean'.
-        same = (isinstance(inp, Deferred) and inp.isp is None and inp.source is not None and inp.index == i // N and
-                (inp.source is self.target_dataset or
-                 (getattr(inp.source, 'db_path', None) is not None and getattr(inp.source, 'db_path', None) == getattr(self.target_dataset, 'db_path', object())
-                  and getattr(inp.source, 'length', None) == getattr(self.target_dataset, 'length', object()))))
+        same = self._shared[i % N] and isinstance(inp, Deferred) and inp.isp is None and inp.index == i // N
         target = inp.clean if same else self.target_dataset[i // N]
         bits = 0
         if self.augment:                                     # sid_dataset.py:344-352: flip H, flip W, transpose
@@ -178,7 +189,7 @@ class ELDTrainDataset(tdata.Dataset):
             else:
                 dic = {'target': _as_wire(target), 'params': inp.params.record(0).reshape(1).view(np.uint8).copy(),
                        'aug': bits, 'burst': inp.burst}
-                if not same:
+                if not self._shared[i % N]:                  # (per dataset, not per sample: a batch never mixes samples with and without the key)
                     dic['clean'] = _as_wire(inp.clean)
         else:                                                # pre-synthesised input (offline-noise LMDB): the reference's host path
             if getattr(inp, 'dtype', None) == np.uint16:

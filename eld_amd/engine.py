@@ -46,7 +46,9 @@ class Engine(object):
         avg_meters = AverageMeters()
         model = self.model
         t0 = time.time()
-        log_every = max(1, int(getattr(self.opt, 'print_freq', 1)))
+        # ELD_AMD_LOG_EVERY=k: read the loss back (one device sync) every k-th iteration only.  Default 1 = the reference's behaviour: it reads
+        # loss.item() every iteration (engine.py:48-53, ELD_model.py:480).  An environment switch, not an option: the reference's CLI has no such flag.
+        log_every = max(1, int(os.environ.get('ELD_AMD_LOG_EVERY', '1') or 1))
         for i, data in enumerate(train_loader):
             model.set_input(data, mode='train')
             model.optimize_parameters(**kwargs)

@@ -104,8 +104,16 @@ class ELDModel:
             if st not in ('raw', 'srgb'):
                 raise NotImplementedError('Invalid Stage: {}'.format(st))
         ch = getattr(opt, 'channels', 4)
-        burst = _plugin_num_burst()                          # SynDataset(num_burst=k) built by the entry script / launcher: k * channels planes in
-        cin = 3 if self.stage_in == 'srgb' else (getattr(opt, 'in_channels', None) or ch * burst)      # sid_dataset.py:267-273
+        # Input planes.  The reference always builds arch(opt.channels, ...) (ELD_model.py:391); a burst SynDataset (sid_dataset.py:267-273) hands it
+        # num_burst * channels planes.  opt.in_channels (set by eld_amd.launch --num-burst) names the count explicitly; without it, a TRAINING model
+        # infers it from the SynDataset the entry script built -- eval / test / resume of a non-burst checkpoint never silently change shape.
+        cin = getattr(opt, 'in_channels', None)
+        if cin is None:
+            burst = _plugin_num_burst() if self.isTrain else 1
+            if burst > 1:
+                print('[i] eld_amd: input planes inferred from SynDataset(num_burst=%d): %d x %d = %d (set opt.in_channels to pin it)' % (burst, burst, ch, burst * ch))
+            cin = ch * burst
+        cin = 3 if self.stage_in == 'srgb' else int(cin)
         cout = 3 if self.stage_out == 'srgb' else ch
         # CRF tables (E, fs) of process.load_CRF for the sRGB input stage: opt.crf_tables, else what the entry script handed to
         # ISPDataset(CRF=...) (train_syn.py:42-58); None = gamma 2.2.  --crf without tables anywhere is an error, not a silent gamma.
@@ -113,11 +121,21 @@ class ELDModel:
         self.CRF = getattr(opt, 'crf_tables', None)
         if self.CRF is None and ISPDataset.last() is not None:
             self.CRF = ISPDataset.last().CRF
-        if self.CRF is None and getattr(opt, 'crf', False) and self.stage_in == 'srgb':
-            raise RuntimeError('--crf: no CRF tables reached the model (opt.crf_tables / ISPDataset(CRF=...)); refusing to render the input with gamma 2.2 '
-                               'against a CRF-rendered target')
-        self.netG = ARCH[getattr(opt, 'netG', 'unet')](cin, cout).to(self.device)
+        if self.CRF is None and getattr(opt, 'crf', False):
+            try:                                             # what the reference model does itself (ELD_model.py:374-375)
+                from util import process as _ref_process
+                self.CRF = _ref_process.load_CRF()
+            except Exception:
+                self.CRF = None
+        if self.CRF is None and getattr(opt, 'crf', False) and self.stage_in == 'srgb' and self.isTrain:
+            # only the training step renders the input on the device (set_input of a deferred ISPDataset sample); eval / test entry points
+            # (test_ELD.py) get inputs rendered by their own datasets
+            raise RuntimeError('--crf: no CRF tables reached the model (opt.crf_tables / ISPDataset(CRF=...) / util.process.load_CRF()); refusing to render '
+                               'the input with gamma 2.2 against a CRF-rendered target')
         prec = getattr(opt, 'precision', os.environ.get('ELD_AMD_PRECISION', 'fp32'))      # 'bf16' = BASELINE config 3
+        if prec == 'bf16' and cin > 4:
+            raise NotImplementedError('precision=bf16 supports up to 4 input planes (got %d: burst inputs run in fp32)' % cin)
+        self.netG = ARCH[getattr(opt, 'netG', 'unet')](cin, cout).to(self.device)
         self.netG.train_precision = self.netG.inference_precision = prec
         self.world, self.rank = D.world_size(), D.rank()
         self.exchange = True                                 # False: skip the gradient all-reduce (bench.py measures its exposed cost)

@@ -32,12 +32,13 @@ class _Workspace:
         self.bufs = {}
         self.gen = {}
         self.algo = {}       # fp32 product scheme the forward that filled the buffer ran with
+        self.fused_head = {} # True: the buffer was filled by eld_unet_forward_loss_ex (the only forward a dout = None backward may follow)
 
     def get(self, key, nbytes, device):
         b = self.bufs.get(key)
         if b is None or b.numel() < nbytes or b.device != device:
             if len(self.bufs) > 4:          # shapes changed (e.g. chop tiles): drop old scratch
-                self.bufs.clear(); self.gen.clear(); self.algo.clear()
+                self.bufs.clear(); self.gen.clear(); self.algo.clear(); self.fused_head.clear()
             b = torch.empty(nbytes, dtype=torch.uint8, device=device)
             self.bufs[key] = b
             self.gen[key] = 0
@@ -138,6 +139,7 @@ class UNetSeeInDark(nn.Module):
         # runs the same scheme even if the process default (eld_conv_fp32_algo) is changed in between
         algo = self.fp32_products if self.fp32_products is not None else L.lib().eld_conv_fp32_algo(-1)
         self._ws.algo[key] = algo
+        self._ws.fused_head[key] = False
         L.check(L.lib().eld_unet_forward_ex(L.dptr(x), L.dptr(self.flat_params), L.dptr(out), L.dptr(ws), ws.numel(),
                                             N, H, W, self.in_channels, self.out_channels, 1 if bf16 else 0, algo, L.cur_stream()), 'eld_unet_forward_ex')
         return out, key, self._ws.gen[key]
@@ -163,6 +165,7 @@ class UNetSeeInDark(nn.Module):
         out = torch.empty((N, self.out_channels, H, W), dtype=torch.float32, device=x.device)
         algo = self.fp32_products if self.fp32_products is not None else L.lib().eld_conv_fp32_algo(-1)
         self._ws.algo[key] = algo
+        self._ws.fused_head[key] = True
         L.check(L.lib().eld_unet_forward_loss_ex(L.dptr(x), L.dptr(self.flat_params), L.dptr(target), L.dptr(out), L.dptr(loss_buf), L.dptr(ws), ws.numel(),
                                                  N, H, W, self.in_channels, self.out_channels, 1 if bf16 else 0, algo, 1 if mse else 0, float(grad_scale),
                                                  L.cur_stream()), 'eld_unet_forward_loss_ex')
@@ -173,6 +176,9 @@ class UNetSeeInDark(nn.Module):
         dout = None: the forward was _engine_forward_loss (the head's share of the backward is already in the workspace)."""
         N, _, H, W = shape
         ws = self._ws.bufs[key]
+        if dout is None and not self._ws.fused_head.get(key):
+            raise RuntimeError('eld_amd U-Net: backward without an output gradient needs the fused-loss forward (_engine_forward_loss) '
+                               'to be the last forward of this shape; a plain forward overwrote its head state')
         if grads is None:
             grads = torch.empty(self._offsets[-1], dtype=torch.float32, device=ws.device)
         starts, events, nb = (buckets.starts_c, buckets.events_c, buckets.n) if buckets is not None else (None, None, 0)

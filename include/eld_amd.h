@@ -100,6 +100,11 @@ int eld_noise_forward_strided(const void* in, int in_dtype, size_t in_image_stri
                               const EldNoiseParams* params, int N, int C, int H, int W, uint32_t flags, uint64_t seed,
                               const float* inject, float* dump, void* stream);
 
+/* Rounds of the Philox4x32 generator this build's sampler runs (7 since round 3 of this library; -DELD_PHILOX_ROUNDS=10 restores
+ * cuRAND's count).  The noise stream of a (seed, sample id) pair is a function of this number: a binding that pins or replays streams
+ * (checkpoints, golden vectors, the test oracle) must compare it with the count it was made for -- eld_amd/_lib.py does at load time. */
+int eld_philox_rounds(void);
+
 /* Raw Philox4x32-7 words (ELD_PHILOX_ROUNDS, csrc/philox.h) of the sampler's counter layout, for bit-exact RNG tests:
  * out[i*4..i*4+3] = philox(ctr=(index0+i, sample_id, stream|iter<<8), key=seed). */
 int eld_philox_words(uint32_t* out, uint32_t n, uint32_t index0, uint64_t sample_id,
@@ -186,7 +191,9 @@ int eld_unet_forward_loss_ex(const float* x, const float* params, const float* t
 /* The same two calls with everything per call: precision 0 = fp32 / 1 = bf16 activations; fp32_algo names the fp32 product
  * scheme (see eld_conv_fp32_algo below; < 0 = the process default); n_buckets may be 0.  A backward must name the scheme its
  * forward ran with: scheme 2 leaves operand bounds in the workspace that only a scheme-2 backward reads.
- * eld_unet_backward_ex accepts dout == NULL when (and only when) the forward on this workspace was eld_unet_forward_loss_ex. */
+ * eld_unet_backward_ex accepts dout == NULL when (and only when) the LAST forward on this workspace (host call order) was
+ * eld_unet_forward_loss_ex with the same N / H / W / channels / precision; otherwise it returns ELD_EINVAL (the library remembers, per
+ * workspace pointer, which forward filled it -- host bookkeeping, no device read). */
 int eld_unet_forward_ex(const float* x, const float* params, float* out, void* ws, size_t ws_bytes,
                         int N, int H, int W, int in_ch, int out_ch, int precision, int fp32_algo, void* stream);
 int eld_unet_backward_ex(const float* dout, const float* params, float* grads, void* ws, size_t ws_bytes,

@@ -28,6 +28,14 @@ def test_library_exports_every_declared_symbol(eld_lib):
     assert b'EINVAL' in eld_lib.eld_error_string(-1)
 
 
+def test_philox_round_count_agrees_everywhere(eld_lib):
+    """The sampler's noise stream depends on the Philox round count: the library (csrc/philox.h ELD_PHILOX_ROUNDS), the package
+    (eld_amd/_lib.py PHILOX_ROUNDS, checked at load) and the test oracle (oracle/philox_ref.py ROUNDS) must name the same number."""
+    from eld_amd import _lib as L
+    from oracle import philox_ref as px
+    assert eld_lib.eld_philox_rounds() == L.PHILOX_ROUNDS == px.ROUNDS
+
+
 def test_missing_library_fails_loudly(tmp_path):
     import eld_amd
     with pytest.raises(eld_amd.LibraryMissing):

@@ -74,14 +74,18 @@ def oracle_f64(sd, x, t):
 
 
 REL = 2e-4
+# the two opt-in fp32 product schemes: the fp32 MFMA (algo 0) accumulates its K = 9 * Cin products with the matrix core's own rounding of every
+# add -- measured 3.3e-4 of max|ref| on conv5_x's weight gradients at 512 x 512 (12 x the torch-CPU float32 oracle's own distance from float64;
+# the default three-piece scheme on the bf16 MFMA: 2.6e-5); the two-piece fp16 scheme (algo 2) carries 22 significant bits per product
+REL_BY_ALGO = {0: 1e-3, 1: REL, 2: 1e-3}
 
 
-def rel_ok(got, ref32, ref64):
+def rel_ok(got, ref32, ref64, rel=REL):
     """The relative criterion (module docstring): against the float64 oracle when there is one."""
     ref = ref64 if ref64 is not None else ref32.double()
     err = float((got.double() - ref).abs().max())
     rmax = float(ref.abs().max())
-    ok = err <= REL * rmax
+    ok = err <= rel * rmax
     if not ok and ref64 is not None:
         ok = err <= 8.0 * float((ref32.double() - ref64).abs().max())
     return ok, (err / rmax if rmax > 0 else (0.0 if err == 0 else float('inf')))
@@ -129,7 +133,7 @@ def compare(tag, lib, shape, algo, want_f64=True, zero=None):
             c64 = float((ref32.double() - ref64).abs().max())
             row.update(err_vs_f64=e64, cpu32_vs_f64=c64)
             ok = ok or e64 <= bound
-        rok, rerr = rel_ok(got, ref32, ref64)
+        rok, rerr = rel_ok(got, ref32, ref64, REL_BY_ALGO.get(algo, REL))
         row.update(rel_err=rerr, rel_ok=bool(rok))
         ok = ok and rok
         row['ok'] = bool(ok)

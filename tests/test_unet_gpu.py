@@ -587,3 +587,38 @@ def test_forward_loss_argument_checks(lib):
     assert call(L.dptr(t), L.dptr(loss), nbytes, 2) != 0
     assert call(L.dptr(t), L.dptr(loss), nbytes // 2, 0) != 0
     torch.cuda.synchronize()
+
+
+def test_backward_without_dout_needs_the_fused_forward(lib):
+    """eld_unet_backward_ex(dout = NULL) consumes head state only eld_unet_forward_loss_ex leaves in the workspace (include/eld_amd.h): after a
+    plain forward on the same workspace, or for another shape / precision, it must return an error code instead of stale gradients; the module
+    raises before it gets that far."""
+    from eld_amd.unet import UNetSeeInDark
+    from eld_amd import _lib as L
+    net = UNetSeeInDark(4, 4).cuda()
+    N, H, W = 1, 64, 64
+    x = torch.rand(N, 4, H, W, device='cuda')
+    t = torch.rand(N, 4, H, W, device='cuda')
+    out = torch.empty_like(x)
+    loss = torch.zeros(1, device='cuda')
+    grads = torch.empty(net.flat_params.numel(), device='cuda')
+    nbytes = lib.eld_unet_workspace_bytes(N, H, W, 4, 4)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+
+    def fwd_loss(prec=0):
+        return lib.eld_unet_forward_loss_ex(L.dptr(x), L.dptr(net.flat_params), L.dptr(t), L.dptr(out), L.dptr(loss), L.dptr(ws), nbytes, N, H, W, 4, 4, prec, 1, 0, 1.0,
+                                            L.cur_stream())
+
+    def bwd(prec=0, n=N):
+        return lib.eld_unet_backward_ex(None, L.dptr(net.flat_params), L.dptr(grads), L.dptr(ws), nbytes, n, H, W, 4, 4, prec, 1, None, None, 0, L.cur_stream())
+    assert fwd_loss() == 0 and bwd() == 0               # the pair the training step issues
+    assert bwd(prec=1) != 0                             # the head state is fp32
+    assert lib.eld_unet_forward_ex(L.dptr(x), L.dptr(net.flat_params), L.dptr(out), L.dptr(ws), nbytes, N, H, W, 4, 4, 0, 1, L.cur_stream()) == 0
+    assert bwd() != 0                                   # a plain forward overwrote it
+    assert fwd_loss(prec=1) == 0 and bwd(prec=1) == 0 and bwd(prec=0) != 0
+    torch.cuda.synchronize()
+    lb = torch.zeros(1, device='cuda')
+    _, key, _ = net._engine_forward_loss(x, t, lb)
+    net._engine_forward(x, save=True)                   # same workspace key ('train', N, H, W)
+    with pytest.raises(RuntimeError):
+        net._engine_backward(None, key, (N, 4, H, W))
