@@ -24,6 +24,7 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
 // BFM = true (bf16 inputs only): the tiles stay bf16 in LDS, untransposed [pixel][channel], and the contraction runs on
@@ -458,9 +459,10 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradArgs a) {
     float4 rg[G_IT], rx[WCI][X_IT];
     const size_t g_img = (size_t)a.H * a.W * a.CA * ES;
     // A tile's rows are rows of the strip: strip row v0 + r lies in image img0 = v0 / VP (r below the end of that image's pitch) or in the next one.
-    // seam == false (the pitch is a multiple of TH: every level whose height is): a tile lies inside ONE image -- a scalar tile base plus per-thread
-    // constants, rows past the image end fall outside the one-image descriptor (zero fill): the round-3 addressing, 3 VALU instructions per load.
-    // seam == true: both operands are addressed through a two-image window at image img0; a row is in the window's first image (r < lim0), in its
+    // A tile that lies inside ONE image (always when seam == false -- the pitch is a multiple of TH -- and for every tile of a seamed strip that ends
+    // above the next image): a scalar tile base plus per-thread constants, rows past the image end fall outside the one-image descriptor (zero
+    // fill): the round-3 addressing, 3 VALU instructions per load.
+    // A tile across a seam: both operands are addressed through a two-image window at image img0; a row is in the window's first image (r < lim0), in its
     // second (r >= nxt: the same per-thread constant on a second scalar base) or in the separator (no load).  Separator rows, rows past the last
     // image and columns outside the image read as zeros -- the convolution's padding for X and "no pixel" for G.
     const unsigned g_rowc = (unsigned)(g_py0 * a.W * a.CA) * (unsigned)ES;      // this thread's row part of the G offset
@@ -469,7 +471,7 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradArgs a) {
         const int v0 = ty * TH, x0 = tx * TWT;
         const int img0 = v0 / VP, vrel = v0 - img0 * VP;
         const int wrem = a.W - x0;
-        if (!seam) {
+        if (!seam || VP - vrel > TH) {                                // no row of this tile (halo included) lies in a second image: most tiles even on a seamed strip
             const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)(static_cast<const char*>(a.g) + (size_t)img0 * g_img), 0, (int)g_img, 0x00020000);
             const int gbase = (vrel * a.W + x0) * a.CA * ES;          // rows past the image end fall outside the descriptor: zero fill
 #pragma unroll
@@ -651,11 +653,255 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradArgs a) {
     }
 }
 
+// =============================================================================================================================
+// wgrad8d_kernel (round 4) -- wgrad8_kernel for bf16 tensors with BOTH operand tiles staged by LDS-DMA.
+// bf16 operands need no conversion on the way in, yet wgrad8_kernel<bf16_t> moved every tile HBM -> VGPR -> ds_write: 109 us of staging stores
+// and 65 us of exposed loads beside 272 us of MFMA per launch of the 128 x 64 blocks (profiles/r03_ab_notes.md), two barriers per tile.  Here a
+// tile's 16-byte units travel straight to LDS (buffer_load_dwordx4 ... lds, as conv_bfd.hip): one wave instruction = 1 KiB = 16 pixels x 64 B
+// of one 32-channel block, landing linearly -- which IS the [32-channel block][pixel][32] plane layout the ds_read_b64_tr_b16 fragment reads
+// want.  Two tile buffers: the DMA of tile t+1 is issued behind the barrier that publishes tile t and flies under tile t's MFMAs; one barrier
+// per tile, no staging registers, no VALU on the data.  Zero padding (image border, separator rows of the strip, channel padding of X) =
+// out-of-range buffer offsets.  The bias gradient (column sums of G) is read back from the landed G tile by the jb == 0 blocks.
+// Tiles: TH x TWT pixels over the virtual-row strip, as wgrad8_kernel; a block of X is padded to whole 1 KiB pieces so that a DMA instruction
+// never straddles two source tensors (virtual concat [x0, x1]).
+__device__ __forceinline__ void wg_dma16(i32x4_t rsrc, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+}
+
+template <int WCO, int WCI, int WPIX, int TH, int TWT, bool LATE>
+__global__ __launch_bounds__(512, 2) void wgrad8d_kernel(const WgradArgs a) {
+    static_assert(WCO * WCI * WPIX == 8, "8 waves");
+    static_assert(TWT == 8 || TWT == 16 || TWT == 32, "tile width");
+    constexpr int WAVES = 8, THREADS = 512, TAPS = 9;
+    constexpr int COB = 32 * WCO, JBK = 32 * WCI, TPIX = TH * TWT, PW = TPIX / WPIX, KSB = PW / 16;
+    static_assert(PW % 16 == 0 && PW >= 16, "a wave's pixel slice is a whole number of 16-pixel k-steps");
+    constexpr int HW = TWT + 2, X_PIX = (TH + 2) * HW;
+    static_assert((TPIX * 4) % 64 == 0, "a block of G is whole DMA pieces");
+    constexpr int GB_PIECES = TPIX * 4 / 64, XB_PIECES = (X_PIX * 4 + 63) / 64;      // 1 KiB pieces of one 32-channel block (4 units of 16 B per pixel)
+    constexpr int G_PIECES = WCO * GB_PIECES, X_PIECES = WCI * XB_PIECES;
+    constexpr int G_IT = (G_PIECES + WAVES - 1) / WAVES, X_IT = (X_PIECES + WAVES - 1) / WAVES;
+    constexpr int GBLK = GB_PIECES * 512, XBLK = XB_PIECES * 512;                   // bf16 elements of one block plane
+    constexpr int BUF_BYTES = (G_PIECES + X_PIECES) * 1024;
+    extern __shared__ __attribute__((aligned(16))) float lds[];                    // [2 buffers][G: WCO blocks | X: WCI blocks]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31, hi = lane >> 5;
+    const int wco = wave % WCO, wci = (wave / WCO) % WCI, wpix = wave / (WCO * WCI);
+    const int IB = a.CA / COB, JBn = a.CBp / JBK;
+    int bid = blockIdx.x;
+    const int jb = bid % JBn; bid /= JBn;
+    const int ib = bid % IB;
+    const int ps = bid / IB;
+    const int i0 = ib * COB, j0 = jb * JBK;
+    const bool do_bias = a.bpart != nullptr && jb == 0;
+
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    float4 bsum4 = make_float4(0.f, 0.f, 0.f, 0.f), bsum4b = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const int ntiles = a.tiles_x * a.tiles_y;
+    const int VP = a.vp;
+    const bool seam = VP % TH != 0;
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    const unsigned lds_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(__attribute__((address_space(3))) float*)lds);
+
+    // sources of the WCI 32-channel blocks of X (virtual concat [x0, x1]); blocks beyond C0 + C1 are zero padding (no descriptor range at all)
+    const char* xs[WCI]; int xC[WCI], xc0[WCI];
+#pragma unroll
+    for (int cb = 0; cb < WCI; ++cb) {
+        const int c = j0 + cb * 32;
+        if (c < a.C0) { xs[cb] = static_cast<const char*>(a.x0); xC[cb] = a.C0; xc0[cb] = c; }
+        else if (c < a.C0 + a.C1) { xs[cb] = static_cast<const char*>(a.x1); xC[cb] = a.C1; xc0[cb] = c - a.C0; }
+        else { xs[cb] = nullptr; xC[cb] = 32; xc0[cb] = 0; }
+    }
+    // ---- which unit this lane moves in each of its wave's pieces: pieces are dealt round-robin (a duplicate rewrites identical bytes) --------
+    // G piece p: block p / GB_PIECES, units 64 (p % GB_PIECES) ..: unit -> pixel (unit >> 2) of the tile, 8-channel quarter unit & 3
+    unsigned g_c[G_IT]; int g_rc[G_IT];
+#pragma unroll
+    for (int it = 0; it < G_IT; ++it) {
+        const int piece = (wave + it * WAVES) % G_PIECES;
+        const int blk = piece / GB_PIECES, ub = (piece - blk * GB_PIECES) * 64 + lane;
+        const int pix = ub >> 2, q = ub & 3;
+        const int py = pix / TWT, px = pix - py * TWT;
+        g_c[it] = (unsigned)((py * a.W + px) * a.CA + i0 + blk * 32 + q * 8) * 2u;
+        g_rc[it] = (py << 8) | px;
+    }
+    // X piece p: block p / XB_PIECES; unit -> halo pixel (unit >> 2) = (hy, hx), quarter unit & 3; units past the halo tile move nothing
+    unsigned x_c[X_IT]; int x_rc[X_IT];
+#pragma unroll
+    for (int it = 0; it < X_IT; ++it) {
+        const int piece = (wave + it * WAVES) % X_PIECES;
+        const int blk = piece / XB_PIECES, ub = (piece - blk * XB_PIECES) * 64 + lane;
+        const int hp = ub >> 2, q = ub & 3;
+        const int hy = hp / HW, hx = hp - hy * HW;
+        int C = xC[0], c0 = xc0[0];
+#pragma unroll
+        for (int cb = 1; cb < WCI; ++cb) if (blk == cb) { C = xC[cb]; c0 = xc0[cb]; }
+        x_c[it] = (unsigned)(((hy - 1) * a.W + (hx - 1)) * C + c0 + q * 8) * 2u;      // (may wrap: always added to a base that makes it a valid offset)
+        x_rc[it] = hp < X_PIX ? ((hy << 8) | hx) : -1;
+    }
+    const size_t g_img = (size_t)a.H * a.W * a.CA * 2;
+
+    // DMA of one tile into buffer `buf` (see wgrad8_kernel::load_tile for the strip / seam rules)
+    auto issue = [&](int tile, int buf) {
+        const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+        const int v0 = ty * TH, x0 = tx * TWT;
+        const int img0 = v0 / VP, vrel = v0 - img0 * VP;
+        const int wrem = a.W - x0;
+        const bool single = !seam || VP - vrel > TH;                  // no row of the tile (halo included) lies in a second image
+        const int nimg = single ? 1 : (a.N - img0 < 2 ? a.N - img0 : 2);
+        const int lim0 = a.H - vrel, nxt = single ? (1 << 20) : VP - vrel;      // tile rows [0, lim0): first image; [nxt, nxt + H): second image
+        const int row1 = single ? 0 : a.H - nxt;                      // window row of tile row 0 if it were in the second image (may be negative)
+        const unsigned dst0 = lds_base + (unsigned)(buf * BUF_BYTES);
+        {
+            const unsigned long long gb = (unsigned long long)(static_cast<const char*>(a.g) + (size_t)img0 * g_img);
+            const i32x4_t rs = {(int)(unsigned)gb, (int)((unsigned)(gb >> 32) & 0xFFFFu), (int)(unsigned)(g_img * (size_t)nimg), 0x00020000};
+            const unsigned b0 = (unsigned)((vrel * a.W + x0) * a.CA) * 2u, b1 = (unsigned)((row1 * a.W + x0) * a.CA) * 2u;
+#pragma unroll
+            for (int it = 0; it < G_IT; ++it) {
+                const int piece = (wave + it * WAVES) % G_PIECES;
+                const int r = g_rc[it] >> 8, px = g_rc[it] & 255;
+                const bool second = r >= nxt;
+                const bool ok = (r < lim0 || (second && r - nxt < a.H)) && px < wrem;
+                wg_dma16(rs, ok ? (second ? b1 : b0) + g_c[it] : OOB, dst0 + (unsigned)(piece * 1024));
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < X_IT; ++it) {
+            const int piece = (wave + it * WAVES) % X_PIECES;
+            const int blk = piece / XB_PIECES;                        // wave-uniform
+            const char* src = xs[0]; int C = xC[0];
+#pragma unroll
+            for (int cb = 1; cb < WCI; ++cb) if (blk == cb) { src = xs[cb]; C = xC[cb]; }
+            const size_t x_img = (size_t)a.H * a.W * C * 2;
+            const unsigned long long xb = (unsigned long long)(src ? src + (size_t)img0 * x_img : nullptr);
+            const i32x4_t rs = {(int)(unsigned)xb, (int)((unsigned)(xb >> 32) & 0xFFFFu), src ? (int)(unsigned)(x_img * (size_t)nimg) : 0, 0x00020000};
+            const unsigned b0 = (unsigned)((vrel * a.W + x0) * C) * 2u, b1 = (unsigned)((row1 * a.W + x0) * C) * 2u;
+            const int r = (x_rc[it] >> 8) - 1, gx = x0 - 1 + (x_rc[it] & 255);
+            const bool second = r >= nxt;
+            const bool rok = second ? r - nxt < a.H : (unsigned)(vrel + r) < (unsigned)a.H;
+            const bool ok = x_rc[it] >= 0 && rok && (unsigned)gx < (unsigned)a.W;
+            wg_dma16(rs, ok ? (second ? b1 : b0) + x_c[it] : OOB, dst0 + (unsigned)((G_PIECES + piece) * 1024));
+        }
+    };
+
+    // fragment addresses (see wgrad_kernel): a 16-lane group reads a [4 pixels][16 channels] block per ds_read_b64_tr_b16
+    const int gi = lane & 15, gg = lane >> 4;
+    const int lq0 = wpix * PW + 8 * hi + (gi >> 2);
+    const int pyq = lq0 / TWT, pxq = lq0 - pyq * TWT;
+    const bf16_t* ldsG = reinterpret_cast<const bf16_t*>(lds);
+    const bf16_t* gq0 = ldsG + wco * GBLK + lq0 * 32 + (gg & 1) * 16 + (gi & 3) * 4;
+    const bf16_t* xq0 = ldsG + G_PIECES * 512 + wci * XBLK + (pyq * HW + pxq) * 32 + (gg & 1) * 16 + (gi & 3) * 4;
+    auto tr8 = [](const bf16_t* p0) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+        const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 4 * 32));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    // bias sums: thread -> 8-channel group g_part of the block's COB channels (as wgrad8_kernel), pixels tid / G_Q + k * (512 / G_Q)
+    constexpr int G_Q = COB / 8, B_STEP = THREADS / G_Q, B_IT = TPIX / B_STEP;
+    static_assert(TPIX % B_STEP == 0, "bias pass covers the tile");
+    const int g_part = tid % G_Q;
+    const bf16_t* bq0 = ldsG + (g_part >> 2) * GBLK + (tid / G_Q) * 32 + (g_part & 3) * 8;
+
+    int buf = 0;
+    if (ps < ntiles) issue(ps, 0);
+    for (int tile = ps; tile < ntiles; tile += a.psplit) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's pieces of the tile have landed ...
+        __syncthreads();                                              // ... and everybody else's; the other buffer is no longer read
+        // LATE: a piece costs its wave 100-200 cycles of issue time; waves 0-3 issue behind the barrier, their SIMD partners 4-7 after their first
+        // k-step, so that one wave of every SIMD feeds the matrix pipe while the other one issues (as conv_bfd_kernel)
+        const bool more = tile + a.psplit < ntiles;
+        if (more && (!LATE || wave < 4)) issue(tile + a.psplit, buf ^ 1);
+        const int bo = buf * (BUF_BYTES / 2);                        // buffer offset in bf16 elements
+        if (do_bias) {
+#pragma unroll
+            for (int k = 0; k < B_IT; ++k) {
+                const uint4 q = *reinterpret_cast<const uint4*>(bq0 + bo + k * B_STEP * 32);
+                const float4 lo = unpack_bf4(make_uint2(q.x, q.y)), hi4 = unpack_bf4(make_uint2(q.z, q.w));
+                bsum4.x += lo.x; bsum4.y += lo.y; bsum4.z += lo.z; bsum4.w += lo.w;
+                bsum4b.x += hi4.x; bsum4b.y += hi4.y; bsum4b.z += hi4.z; bsum4b.w += hi4.w;
+            }
+        }
+        const bf16_t* gq = gq0 + bo;
+        const bf16_t* xq = xq0 + bo;
+#pragma unroll
+        for (int ks = 0; ks < KSB; ++ks) {
+            const int lrel = ks * 16;
+            const int dy0 = lrel / TWT, dxp = lrel - dy0 * TWT;
+            const bf16x8 ga = tr8(gq + lrel * 32);
+#pragma unroll
+            for (int t0 = 0; t0 < TAPS; t0 += 3) {
+                bf16x8 xb[3];
+#pragma unroll
+                for (int tt = 0; tt < 3; ++tt) xb[tt] = tr8(xq + ((dy0 + t0 / 3) * HW + dxp + tt) * 32);
+#pragma unroll
+                for (int tt = 0; tt < 3; ++tt) acc[t0 + tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, xb[tt], acc[t0 + tt], 0, 0, 0);
+            }
+            if (LATE && ks == 0 && more && wave >= 4) issue(tile + a.psplit, buf ^ 1);
+        }
+        buf ^= 1;
+    }
+
+    // ---- reduce the WPIX pixel slices through LDS, one tap at a time; slice 0 writes the partial (as wgrad8_kernel) -----------------------
+    __syncthreads();
+    float* red = lds;                                                  // [(WPIX-1)][WCO*WCI][16][64]
+    const size_t pbase = (size_t)ps * TAPS * a.CA * a.CBp;
+    const int wt = wci * WCO + wco;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+        if (WPIX > 1) {
+            if (wpix > 0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) red[(((wpix - 1) * (WCO * WCI) + wt) * 16 + i) * 64 + lane] = acc[t][i];
+            }
+            __syncthreads();
+            if (wpix == 0) {
+                for (int w = 0; w < WPIX - 1; ++w)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[t][i] += red[((w * (WCO * WCI) + wt) * 16 + i) * 64 + lane];
+            }
+            __syncthreads();
+        }
+        if (wpix == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = (i & 3) + 8 * (i >> 2) + 4 * hi;
+                a.part[pbase + ((size_t)t * a.CA + i0 + wco * 32 + row) * a.CBp + j0 + wci * 32 + m] = acc[t][i];
+            }
+        }
+    }
+    if (do_bias) {                                                     // thread -> 8-channel group g_part; 512 / G_Q threads per group, fixed order
+        __syncthreads();
+        reinterpret_cast<float4*>(red)[2 * tid] = bsum4; reinterpret_cast<float4*>(red)[2 * tid + 1] = bsum4b;
+        __syncthreads();
+        if (tid < COB) {
+            const int q = tid / 8, comp = tid % 8;
+            float s_ = 0.f;
+            for (int k = 0; k < THREADS / G_Q; ++k) s_ += red[(q + k * G_Q) * 8 + comp];
+            a.bpart[(size_t)ps * a.CA + i0 + tid] = s_;
+        }
+    }
+}
+
 // block shape of wgrad8_kernel for a layer (CA out-channels of G, CBp padded in-channels of X); false: the layer stays on wgrad_kernel.
 // bf16 inputs keep one plane per operand (a third of the LDS of the three-piece tiles), so every block shape takes 256-pixel tiles:
 // halo overhead of X 1.33x instead of 1.6x and a quarter of the barriers per pixel.  The 128 x 64 blocks take tiles 8 pixels wide (round 4):
 // the levels they run on are 532, 266, 133 pixels wide -- 536 / 272 / 136 columns of 8-wide tiles against 544 / 288 / 160 of 32-wide ones --
 // and the halo of a 64-pixel tile shrinks from 4 x 34 to 10 x 10 pixels.
+// The 128 x 64 blocks of bf16 tensors run wgrad8d_kernel (both tiles by LDS-DMA, two tile buffers; ELD_WGRAD_DMA=0: back on wgrad8_kernel<bf16_t>
+// with its 256-pixel register-staged tiles).  The smaller blocks stay on wgrad8_kernel: they are the 32 / 64-channel layers, at the HBM roofline
+// already (conv1_2: 3.5 GB per launch in 0.65 ms = 5.4 TB/s); their DMA variants (16 x 16 tiles) measured 3 ... 17 % slower.
+static int wgrad8_dma() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("ELD_WGRAD_DMA"); on = e ? (atoi(e) != 0) : 1; }
+    return on;
+}
 bool wgrad8_shape(int CA, int CBp, int& COB, int& JBK, int& TH, int& TWo, bool bf16) {
     if (CA % 32 || CBp % 32) return false;
     TWo = 32;
@@ -665,6 +911,7 @@ bool wgrad8_shape(int CA, int CBp, int& COB, int& JBK, int& TH, int& TWo, bool b
     else if (CBp % 64 == 0) { COB = 32; JBK = 64; TH = 4; }
     else { COB = 32; JBK = 32; TH = 4; }
     if (bf16) TH = 8;
+    if (bf16 && wgrad8_dma() && COB == 128) { TH = 16; TWo = 8; return true; }
     // the 128 x 64 blocks are the >= 128-channel layers = the ragged levels (356 x 532 and below): 8-wide tiles of the same pixel count.  The
     // 32 / 64-channel layers sit on 2128- and 1064-pixel rows (nothing to win) and are bound by their staging traffic: 8-wide tiles measured
     // 3 ... 19 % slower there (profiles/r04_ab_notes.md)
@@ -698,6 +945,26 @@ static int launch_w8(WgradArgs a, hipStream_t st) {
     return 0;
 }
 
+template <int WCO, int WCI, int WPIX, int TH, int TWT, bool LATE>
+static int launch_w8d(WgradArgs a, hipStream_t st) {
+    constexpr int COB = 32 * WCO, JBK = 32 * WCI;
+    a.vp = vrow_pitch(a.N, a.H, TH);
+    a.tiles_x = (a.W + TWT - 1) / TWT;
+    a.tiles_y = (vrow_extent(a.N, a.H, a.vp) + TH - 1) / TH;
+    constexpr int PIECES = WCO * (TH * TWT * 4 / 64) + WCI * (((TH + 2) * (TWT + 2) * 4 + 63) / 64);
+    size_t lds_bytes = (size_t)2 * PIECES * 1024;
+    const size_t red_bytes = (size_t)7 * 16 * 64 * sizeof(float);
+    if (lds_bytes < red_bytes) lds_bytes = red_bytes;
+    const long long blocks = (long long)(a.CA / COB) * (a.CBp / JBK) * a.psplit;
+    if (blocks <= 0) return 0;
+    auto kern = wgrad8d_kernel<WCO, WCI, WPIX, TH, TWT, LATE>;
+    static EldAttrOnce once;
+    { const int rc = once.ensure(kern, lds_bytes); if (rc) return rc; }
+    ELD_LAUNCH(kern, dim3((unsigned)blocks), dim3(512), lds_bytes, st, a);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
 static int launch_wgrad8(const WgradArgs& a, hipStream_t st) {
     const bool bf16 = a.dtype == DT_BF16;
     const size_t es = bf16 ? 2 : 4;
@@ -707,6 +974,10 @@ static int launch_wgrad8(const WgradArgs& a, hipStream_t st) {
     // both operands are addressed through a window of two images (virtual rows): it must fit a buffer descriptor with 32-bit offsets
     const size_t win = a.N > 1 ? 2 : 1;
     if ((size_t)a.H * a.W * a.CA * es * win >= 0xFFFFFFF0ull || (size_t)a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) * es * win >= 0xFFFFFFF0ull) return ELD_ENOTSUP;
+    if (bf16 && wgrad8_dma() && COB == 128) {
+        // (measured on the same box, profiles/r04_ab_notes.md: waves 4-7 issuing their pieces behind their first k-step +1.3 %, 20 x 8 tiles +5.5 %)
+        return launch_w8d<4, 2, 1, 16, 8, false>(a, st);
+    }
     if (bf16) {
         if (COB == 128) return launch_w8<bf16_t, 4, 2, 1, 32, 8>(a, st);
         if (COB == 64 && JBK == 64) return launch_w8<bf16_t, 2, 2, 2, 8, 32>(a, st);

@@ -1,8 +1,8 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/t5
-( timeout 900 python -m pytest tests -m gpu -q ) > gpurun_out/t5/pytest.log 2>&1; grep -n "passed\|failed" gpurun_out/t5/pytest.log | tail -2
+mkdir -p gpurun_out/t6
+( timeout 900 python -m pytest tests -m gpu -q ) > gpurun_out/t6/pytest.log 2>&1; grep -n "passed\|failed" gpurun_out/t6/pytest.log | tail -2
 export ELD_AMD_ANY_PHILOX=1
-bash tools/gpu_ab.sh t5/ab_fp32 "conv_x3d,wgrad8,conv_x3_kernel,noise" fp32 eld_amd/libeld_amd.so tools/probe/lib_r03.so 2>&1 | tee gpurun_out/t5/ab_fp32.txt
-bash tools/gpu_ab.sh t5/ab_bf16 "conv_bfd,wgrad8,noise" bf16 eld_amd/libeld_amd.so tools/probe/lib_r03.so 2>&1 | tee gpurun_out/t5/ab_bf16.txt
-for lib in eld_amd/libeld_amd.so tools/probe/lib_r03.so; do ELD_AMD_ANY_PHILOX=1 ELD_AMD_LIB=$GRAFT_REPO_ROOT/$lib timeout 200 python tools/noise_microbench.py 8 2>&1 | tail -8; done | tee gpurun_out/t5/noise.txt
+bash tools/gpu_ab.sh t6/ab_fp32 "conv_x3d,wgrad8,conv_x3_kernel,noise" fp32 eld_amd/libeld_amd.so tools/probe/lib_r03.so 2>&1 | tee gpurun_out/t6/ab_fp32.txt
+bash tools/gpu_ab.sh t6/ab_bf16 "conv_bfd,wgrad8,noise" bf16 eld_amd/libeld_amd.so tools/probe/lib_r03.so 2>&1 | tee gpurun_out/t6/ab_bf16.txt
+for lib in eld_amd/libeld_amd.so tools/probe/lib_r03.so; do ELD_AMD_ANY_PHILOX=1 ELD_AMD_LIB=$GRAFT_REPO_ROOT/$lib timeout 200 python tools/noise_microbench.py 8 2>&1 | tail -8; done | tee gpurun_out/t6/noise.txt
