@@ -303,4 +303,4 @@ bool wgrad8_shape(int CA, int CBp, int& COB, int& JB, int& TH, int& TWo, bool bf
 int wgrad8_ntiles(int CA, int CBp, int N, int H, int W, bool bf16);
 // out[(i*CBr + j)*T + tap] = sum_s part[s][tap][i][j]   (OIHW / (Cin,Cout,2,2) layouts);  bgrad[i] = sum_s bpart[s][i]
 int launch_wgrad_reduce(const float* part, const float* bpart, float* wgrad, float* bgrad, int psplit, int T, int CA,
-                        int CBp, int CBr, hipStream_t st);
+                        int CBp, int CBr, hipStream_t st, int bias_n = 0);      // bias_n > 0: bpart is [psplit][bias_n] (default [psplit][CA])

@@ -1058,22 +1058,22 @@ int launch_wgrad(const WgradArgs& a, int mode, hipStream_t st) {
 // same way.
 template <int T>
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bpart, float* __restrict__ wgrad,
-                                                            float* __restrict__ bgrad, int psplit, int CA, int CBp, int CBr, int pair_blocks) {
+                                                            float* __restrict__ bgrad, int psplit, int CA, int CBp, int CBr, int pair_blocks, int NB) {
     extern __shared__ float sh[];                 // [NW][T][64]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, NW = blockDim.x >> 6;
     const size_t pairs = (size_t)CA * CBp, plane = pairs * T;
-    if ((int)blockIdx.x >= pair_blocks) {         // bias block: 64 channels
+    if ((int)blockIdx.x >= pair_blocks) {         // bias block: 64 of the NB bias channels (bpart is [psplit][NB])
         const int c = ((int)blockIdx.x - pair_blocks) * 64 + lane;
         float b = 0.f;
-        if (c < CA) {
+        if (c < NB) {
             int k = w;
             for (; k + 3 * NW < psplit; k += 4 * NW)
-                b += (bpart[(size_t)k * CA + c] + bpart[(size_t)(k + NW) * CA + c]) + (bpart[(size_t)(k + 2 * NW) * CA + c] + bpart[(size_t)(k + 3 * NW) * CA + c]);
-            for (; k < psplit; k += NW) b += bpart[(size_t)k * CA + c];
+                b += (bpart[(size_t)k * NB + c] + bpart[(size_t)(k + NW) * NB + c]) + (bpart[(size_t)(k + 2 * NW) * NB + c] + bpart[(size_t)(k + 3 * NW) * NB + c]);
+            for (; k < psplit; k += NW) b += bpart[(size_t)k * NB + c];
         }
         sh[w * 64 + lane] = b;
         __syncthreads();
-        if (w == 0 && c < CA) {
+        if (w == 0 && c < NB) {
             for (int ww = 1; ww < NW; ++ww) b += sh[ww * 64 + lane];
             bgrad[c] = b;
         }
@@ -1120,16 +1120,17 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
 }
 
 int launch_wgrad_reduce(const float* part, const float* bpart, float* wgrad, float* bgrad, int psplit, int T, int CA,
-                        int CBp, int CBr, hipStream_t st) {
+                        int CBp, int CBr, hipStream_t st, int bias_n) {
+    const int NB = bias_n > 0 ? bias_n : CA;      // channels of the bias partials (transposed convs: the column sums of the gathered operand, CBp of them)
     if (T != 9 && T != 4) return ELD_EINVAL;
     int NW = 1;
     while (NW < 16 && NW < psplit) NW <<= 1;
     const size_t pairs = (size_t)CA * CBp;
     const int pair_blocks = (int)((pairs + 63) / 64);
-    const int blocks = pair_blocks + (bgrad ? (CA + 63) / 64 : 0);
+    const int blocks = pair_blocks + (bgrad ? (NB + 63) / 64 : 0);
     const size_t lds = (size_t)NW * T * 64 * sizeof(float);
-    if (T == 9) ELD_LAUNCH((wgrad_reduce_kernel<9>), dim3(blocks), dim3(64 * NW), lds, st, part, bpart, wgrad, bgrad, psplit, CA, CBp, CBr, pair_blocks);
-    else ELD_LAUNCH((wgrad_reduce_kernel<4>), dim3(blocks), dim3(64 * NW), lds, st, part, bpart, wgrad, bgrad, psplit, CA, CBp, CBr, pair_blocks);
+    if (T == 9) ELD_LAUNCH((wgrad_reduce_kernel<9>), dim3(blocks), dim3(64 * NW), lds, st, part, bpart, wgrad, bgrad, psplit, CA, CBp, CBr, pair_blocks, NB);
+    else ELD_LAUNCH((wgrad_reduce_kernel<4>), dim3(blocks), dim3(64 * NW), lds, st, part, bpart, wgrad, bgrad, psplit, CA, CBp, CBr, pair_blocks, NB);
     ELD_LAUNCH_CHECK();
     return 0;
 }

@@ -67,7 +67,8 @@ __device__ __forceinline__ int stage_row(int r, int limit) {
 // [N, H/2, W/2, Nout].  H and W are even (checked by the launcher), so a window is never split by the image border.  Every lane of the wave runs
 // the exchange; only the stores are predicated.
 template <int RPW, int NT, int BN>
-__device__ __forceinline__ void pool_epilogue(const ConvArgs& a, const f32x16 (&acc)[RPW][NT], int img, int nb, int yb /* first row of the lane */, int x, int hi) {
+__device__ __forceinline__ void pool_epilogue(const ConvArgs& a, const f32x16 (&acc)[RPW][NT], const int (&img_p)[RPW / 2], int nb,
+                                              const int (&y_p)[RPW / 2] /* first row of each of the lane's row pairs; >= H: none */, int x, int hi) {
     static_assert(RPW % 2 == 0, "row pairs per lane");
     const int Hp = a.H >> 1, Wp = a.W >> 1;
 #pragma unroll
@@ -75,7 +76,7 @@ __device__ __forceinline__ void pool_epilogue(const ConvArgs& a, const f32x16 (&
         const int nbase = nb * BN + tt * 32 + 4 * hi;
 #pragma unroll
         for (int rp = 0; rp < RPW / 2; ++rp) {
-            const int y = yb + 2 * rp;
+            const int y = y_p[rp], img = img_p[rp];
             if (y >= a.H) continue;                                 // wave-uniform
             float4 pv[4];
 #pragma unroll
@@ -330,7 +331,12 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
                 }
             }
         }
-        if (a.epi == EPI_FWD && a.pool_out != nullptr) pool_epilogue<RPW, NT, BN>(a, acc, img, nb, y0 + wave * RPW, x0 + m, hi);
+        if (a.epi == EPI_FWD && a.pool_out != nullptr) {
+            int img_p[RPW / 2], y_p[RPW / 2];
+#pragma unroll
+            for (int rp = 0; rp < RPW / 2; ++rp) { img_p[rp] = img; y_p[rp] = y0 + wave * RPW + 2 * rp; }
+            pool_epilogue<RPW, NT, BN>(a, acc, img_p, nb, y_p, x0 + m, hi);
+        }
         if (t_next >= total_tiles) break;
         t = t_next;
     }
@@ -648,9 +654,14 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
             }
         }
         if (KS == 1 && a.epi == EPI_FWD && a.pool_out != nullptr) {     // pooled launches run TH x 32 tiles (launcher): slot m of column r = tile pixel (wave * RPW + r, m)
-            int dimg, y;
-            const bool rok = strip_row(vrel + wave * RPW, dimg, y) && img0 + dimg < a.N;
-            pool_epilogue<RPW, NT, BN>(a, acc, img0 + dimg, nb, rok ? y : a.H, x0 + m, hi);
+            int img_p[RPW / 2], y_p[RPW / 2];                           // (a lane's row pairs may lie on both sides of a seam of the strip)
+#pragma unroll
+            for (int rp = 0; rp < RPW / 2; ++rp) {
+                int dimg, y;
+                const bool rok = strip_row(vrel + wave * RPW + 2 * rp, dimg, y) && img0 + dimg < a.N;
+                img_p[rp] = img0 + dimg; y_p[rp] = rok ? y : a.H;
+            }
+            pool_epilogue<RPW, NT, BN>(a, acc, img_p, nb, y_p, x0 + m, hi);
         }
         if (t_next >= total_tiles) break;
         t = t_next;
@@ -961,6 +972,9 @@ int launch_x3d(ConvArgs a, hipStream_t st) {
     if (grid > tiles) grid = tiles;
     ELD_LAUNCH(kern, dim3((unsigned)grid), dim3(64 * WAVES), lds_bytes, st, a);
     ELD_LAUNCH_CHECK();
+    // (Folding this finish into the last workgroup to deliver a part of a tile -- one arrival counter per tile behind a __threadfence() -- was built
+    // and measured in round 4: the release fence writes the XCD's L2 back on every work item and conv_x3d_kernel<64,2,4> went from 36.6 to 88.3 us
+    // per launch, 3.1 -> 4.3 ms per 512 x 512 step.  The kernel boundary is the cheap way to publish partial sums across XCDs.)
     if (a.ksplit > 1) return launch_x3_splitk_finish(a, st);
     return 0;
 }
@@ -999,6 +1013,15 @@ void conv_x3_set_prof(unsigned long long*) {}       // the s_memtime stage profi
 // (conv5_x of a 512 x 512 patch: 8 -> 32 workgroups).  The pack kernel lays the slabs out for the same choice (same function, same arguments).
 int x3_slab_bn(int Nout, int N, int H, int W, int* waves) {
     if (waves) *waves = 8;
+    // 32 output channels (round 4, opt-in ELD_X3D_32=1): conv_x3d_kernel<32, 4, 8> -- 32-row x 32-pixel tiles, the layer's pre-split weight slabs by
+    // LDS-DMA instead of a cut of the fp32 weights per stage and tile (a third of conv_x3_kernel<32, 4>'s staging work).  Measured 6 % SLOWER than
+    // conv_x3_kernel<32, 4> (3087 vs 2917 us per launch, same box): one 8-wave workgroup per CU loses more to its barriers than the two 4-wave
+    // workgroups of the register-staged kernel lose to the weight cut.  Off by default.
+    if (Nout == 32) {
+        static int on = -1;
+        if (on < 0) { const char* e = getenv("ELD_X3D_32"); on = e ? atoi(e) : 0; }
+        return (on && conv_tile_count(N, H, W, 32, false) >= 2 * eld_num_cus()) ? 32 : 0;
+    }
     if (Nout % 64) return 0;
     const long long px_tiles = conv_tile_count(N, H, W, 16, false);
     const int cus = eld_num_cus();
@@ -1018,6 +1041,7 @@ int launch_conv_x3(const ConvArgs& a_in, hipStream_t st) {
     // conv_x3d_kernel addresses a two-image window (virtual rows)
     if (bn0 && a.N > 1 && (size_t)a.H * a.W * a.C0 * 8 >= 0xFFFFFFF0ull) return ELD_ENOTSUP;
     const int bn = x3_slab_bn(a.Nout, a.N, a.H, a.W, &waves);
+    if (bn == 32) return launch_x3d<32, 4, 8, false>(a, st);
     if (bn == 128) return launch_x3d<128, 2, 8, false>(a, st);      // weights pre-split in slab layout: LDS-DMA kernel
     if (bn == 64) return waves == 8 ? launch_x3d<64, 2, 8, false>(a, st) : launch_x3d<64, 2, 4, false>(a, st);
     return launch_x3<32, 4, false>(a, st);

@@ -172,9 +172,9 @@ int convt_wgrad(const float* in, const float* dout, float* dw, float* db, float*
     take_amax(a);
     int rc = launch_wgrad(a, CONV_GATHER2X2, st);
     if (rc) return rc;
-    rc = launch_wgrad_reduce(part, nullptr, dw, nullptr, q.psplit, q.T, q.CA, q.CBp, Cout, st);
-    if (rc || !db) return rc;
-    if (fused_bias) return launch_colsum_reduce(a.xbpart, db, q.psplit, Cout, st);
+    // (the bias partials ride in the same reduction launch: one launch less per transposed conv)
+    rc = launch_wgrad_reduce(part, fused_bias ? a.xbpart : nullptr, dw, fused_bias ? db : nullptr, q.psplit, q.T, q.CA, q.CBp, Cout, st, q.CBp);
+    if (rc || !db || fused_bias) return rc;
     return launch_colsum(dout, db, part, (size_t)N * 4 * H * W, Cout, st);
 }
 
@@ -568,8 +568,7 @@ int unet_backward_bf16(const Plan& P, const float* dout, const float* prm, float
             a.part = part; a.bpart = nullptr; a.CBp = q.CBp; a.psplit = q.psplit;
             a.xbpart = part + (size_t)q.psplit * q.T * q.CA * q.CBp;          // bias gradient = column sums of d_up, from the staging registers
             RC(launch_wgrad(a, CONV_GATHER2X2, st));
-            RC(launch_wgrad_reduce(part, nullptr, grd + P.L[iu].w_off, nullptr, q.psplit, q.T, q.CA, q.CBp, C, st));
-            RC(launch_colsum_reduce(a.xbpart, grd + P.L[iu].b_off, q.psplit, C, st));
+            RC(launch_wgrad_reduce(part, a.xbpart, grd + P.L[iu].w_off, grd + P.L[iu].b_off, q.psplit, q.T, q.CA, q.CBp, C, st, q.CBp));
             RC(marks.done(P, iu, st));
             ConvArgs c = {};
             c.in0 = cur; c.C0 = C; c.wp = B(P.wp_bwd[iu]); c.N = N; c.H = Hi; c.W = Wi; c.Nout = 2 * C;

@@ -134,6 +134,58 @@ def test_conv3x3_backward_weight(lib, N, H, W, C0, C1, Cout, algo):
     close(db, gy.double().sum(dim=(0, 2, 3)), tol=2e-6, scale=gy.double().abs().sum(dim=(0, 2, 3)))
 
 
+@pytest.mark.parametrize('N,H,W,C,Cout', [(3, 45, 77, 64, 64), (5, 21, 40, 128, 128), (4, 34, 50, 64, 128), (2, 16, 64, 64, 64)])
+def test_batch_strip_tiling_is_image_independent(lib, N, H, W, C, Cout):
+    """Round 4: the 3x3 kernels tile the batch as ONE strip of rows (csrc/conv.h vrow_*: image i's row y at strip row i * (H + S) + y), so a
+    tile may hold the last rows of one image and the first rows of the next, and the weight gradient walks tiles across image seams.  Whatever
+    the strip / tile shape, every image of a batch must come out exactly as it does alone: forward and backward-data bit for bit (odd and even
+    heights: S = 1 / 2; a height that is a multiple of the tile: no seam), and the batch weight gradient == the sum over images (fp32 summation
+    order differs: 2e-6 of the accumulated magnitude)."""
+    from eld_amd import _lib as L
+    g = torch.Generator().manual_seed(N * H + W)
+    x = torch.randn(N, H, W, C, generator=g).cuda()
+    gy = torch.randn(N, H, W, Cout, generator=g).cuda()
+    act = torch.randn(N, H, W, C, generator=g).cuda()
+    w = (torch.randn(Cout, C, 3, 3, generator=g) / np.sqrt(9 * C)).cuda()
+    b = torch.randn(Cout, generator=g).cuda()
+
+    def fwd(xx):
+        n = xx.shape[0]
+        out = torch.empty(n, H, W, Cout, device='cuda')
+        ws = ws_for(lib, n, H, W, C, Cout)
+        L.check(lib.eld_conv3x3_forward(L.dptr(xx), C, None, 0, L.dptr(w), L.dptr(b), L.dptr(out), n, H, W, Cout, 1, L.dptr(ws), ws.numel(), L.cur_stream()))
+        torch.cuda.synchronize()
+        return out
+
+    def bwd(gg, aa):
+        n = gg.shape[0]
+        d = torch.empty(n, H, W, C, device='cuda')
+        ws = ws_for(lib, n, H, W, C, Cout)
+        L.check(lib.eld_conv3x3_backward_data(L.dptr(gg), L.dptr(w), L.dptr(d), None, C, L.dptr(aa), None, n, H, W, C, Cout, L.dptr(ws), ws.numel(), L.cur_stream()))
+        torch.cuda.synchronize()
+        return d
+
+    def wgrad(gg, xx):
+        n = gg.shape[0]
+        dw = torch.empty(Cout, C, 3, 3, device='cuda'); db = torch.empty(Cout, device='cuda')
+        ws = ws_for(lib, n, H, W, C, Cout)
+        L.check(lib.eld_conv3x3_backward_weight(L.dptr(gg), L.dptr(xx), C, None, 0, L.dptr(dw), L.dptr(db), n, H, W, Cout, L.dptr(ws), ws.numel(), L.cur_stream()))
+        torch.cuda.synchronize()
+        return dw.double().cpu(), db.double().cpu()
+    out, din = fwd(x), bwd(gy, act)
+    dw, db = wgrad(gy, x)
+    dw_sum, db_sum = torch.zeros_like(dw), torch.zeros_like(db)
+    for i in range(N):
+        xi, gi, ai = x[i:i + 1].contiguous(), gy[i:i + 1].contiguous(), act[i:i + 1].contiguous()
+        assert torch.equal(fwd(xi)[0], out[i]), 'forward: image %d of the batch differs from the image alone' % i
+        assert torch.equal(bwd(gi, ai)[0], din[i]), 'backward-data: image %d of the batch differs from the image alone' % i
+        a, c = wgrad(gi, xi)
+        dw_sum += a; db_sum += c
+    mag = torch.nn.grad.conv2d_weight(nchw(x).double().abs().cpu(), (Cout, C, 3, 3), nchw(gy).double().abs().cpu(), padding=1)
+    assert float(((dw - dw_sum).abs() / (1.0 + mag)).max()) <= 2e-6
+    assert float((db - db_sum).abs().max()) <= 2e-6 * (1.0 + float(gy.double().abs().sum(dim=(0, 1, 2)).max()))
+
+
 @pytest.mark.parametrize('N,H,W,Cin,Cout', [(2, 10, 19, 64, 32), (1, 5, 33, 512, 256), (1, 8, 8, 128, 64)])
 def test_conv_transpose2x2(lib, N, H, W, Cin, Cout, algo):
     from eld_amd import _lib as L
