@@ -218,10 +218,24 @@ __host__ __device__ inline int vrow_pitch(int N, int H, int TH) {
     return (vrow_extent(N, H, flat) + TH - 1) / TH < (vrow_extent(N, H, own) + TH - 1) / TH ? flat : own;
 }
 
-// Tile shape (rows x columns) of conv_x3d_kernel / conv_bfd_kernel for a launch over N images of H x W: the one that covers the strip with
-// the fewest tiles among th * tw <= TH * 32 pixel slots and (th + 2)(tw + 2) <= (TH + 2) * 34 halo pixels (what the kernels' LDS holds);
-// ties go to the standard TH x 32.  `pooled` launches (fused 2x2 max-pool) keep TH x 32.  conv_tile_count = tiles of that shape.
+// Tile shape (rows x columns) of conv_x3d_kernel / conv_bfd_kernel for a launch over N images of H x W, among th * tw <= TH * 32 pixel slots and
+// (th + 2)(tw + 2) <= (TH + 2) * 34 halo pixels (what the kernels' LDS holds): the one with the lowest cost = tiles x (1 + 0.01 (c - 1)), c = the LDS
+// cycles of an activation-fragment read relative to a conflict-free one.  A ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27} and
+// {4-11,16-19,28-31} (+32), and the 16 halo pixels of a group fall on distinct banks only if their linear indices are distinct modulo 16: true
+// for 16 consecutive pixels of a row, false where a group's pixels wrap to the next tile row (the halo row is 2 pixels longer than the tile
+// row).  So non-standard shapes number their slots group by group (conv_slot_of_lane: lanes of group 0 -> slots 0..15, group 1 -> 16..31; widths
+// that are multiples of 16 are then conflict-free: SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS of conv_x3d_kernel<128> fell from 0.90 to 0.06) and the
+// cost charges what is left only as a tie-break: with the grouped numbering the fewest-tiles choice and a conflict-weighted one measured the same
+// time (profiles/r04_ab_notes.md), so the executed MFMA work decides.  `pooled` launches (fused 2x2 max-pool) keep TH x 32.  conv_tile_count = tiles of that shape.
 void conv_tile_shape(int N, int H, int W, int TH, bool pooled, int& th, int& tw);
+// pixel slot (0..31 of its MFMA column) of lane m = lane & 31 under the grouped numbering / the identity of the standard TH x 32 tiles
+__host__ __device__ inline int conv_slot_of_lane(int m, bool grouped) {
+    if (!grouped) return m;
+    const int q = m >> 2;                       // quads 0..7 -> slot quads {0, 4, 5, 1, 6, 2, 3, 7}
+    const int sq = q == 0 ? 0 : q == 1 ? 4 : q == 2 ? 5 : q == 3 ? 1 : q == 4 ? 6 : q == 5 ? 2 : q == 6 ? 3 : 7;
+    return sq * 4 + (m & 3);
+}
+__host__ __device__ inline bool conv_slots_grouped(int th, int tw, int TH) { return !(th == TH && tw == 32); }
 long long conv_tile_count(int N, int H, int W, int TH, bool pooled);
 
 // f32_line_store for pixel slots whose pixels are per-lane: p0 / p1 = channel 0 of the 32-channel block in the pixels of slot lane & 15 and slot

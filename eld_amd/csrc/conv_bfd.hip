@@ -72,6 +72,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
     const int THL = a.tile_h, TWL = a.tile_w, HWL = TWL + 2;              // the launch's tile shape; halo row = TWL + 2 pixels
     const int APX = (THL + 2) * HWL, NPX = THL * TWL, VP = a.vp;          // halo pixels / tile pixels in use (<= A_PIX / TH * TW)
     const bool seam = VP % THL != 0;                                      // tiles may straddle two images (conv.h vrow_pitch)
+    const bool grouped = conv_slots_grouped(THL, TWL, TH);                // slots numbered lane group by lane group (conv.h conv_tile_shape)
 
     const unsigned lds_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(size_t)(__attribute__((address_space(3))) char*)lds);
     const unsigned ldsB_addr = lds_base, ldsA_addr = lds_base + NBB * B_BYTES;
@@ -146,11 +147,12 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
     };
 
     // ---- fragment addresses: per lane, per (kx, k-block); rows / taps / buffers are uniform or immediate offsets ---------------
-    // slot p = (wave * RPW + r) * 32 + m of the workgroup is tile pixel (p / TWL, p % TWL); slots beyond the tile's pixel count compute on pixel 0
+    // slot p = (wave * RPW + r) * 32 + s(m) of the workgroup is tile pixel (p / TWL, p % TWL), s = conv_slot_of_lane; slots beyond the tile's pixel
+    // count compute on pixel 0
     unsigned fx_off[RPW][3][2], fw_off[2];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
-        int p = (wave * RPW + r) * 32 + m;
+        int p = (wave * RPW + r) * 32 + conv_slot_of_lane(m, grouped);
         p = p < NPX ? p : 0;
         const int tr = p / TWL, tc = p - tr * TWL;
 #pragma unroll
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
     for (int r = 0; r < RPW; ++r)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int p = (wave * RPW + r) * 32 + (lane & 15) + 16 * h;
+            const int p = (wave * RPW + r) * 32 + conv_slot_of_lane((lane & 15) + 16 * h, grouped);      // MFMA column (lane & 15) + 16 h of column-of-32 r
             const int tr = p / TWL, tc = p - tr * TWL;
             ep_rc[r][h] = p < NPX ? (unsigned)((tr << 8) | tc) : 0xFFFFu;
         }

@@ -433,10 +433,31 @@ static long long tile_count(int N, int H, int W, int th, int tw) {
     const int vp = vrow_pitch(N, H, th);
     return (long long)((W + tw - 1) / tw) * ((vrow_extent(N, H, vp) + th - 1) / th);
 }
+// LDS cycles of one activation-fragment ds_read_b128 of a th x tw tile under the grouped slot numbering, relative to conflict-free (1.0): the halo
+// pixels a lane group touches must be distinct modulo 16 (conv_x3d: 112-byte pixel rows, 28 P mod 64 words; conv_bfd: 64-byte rows with the octet
+// XOR -- the same condition); every pair of a group that collides costs the group one more cycle.  Averaged over the waves / rows of a workgroup.
+static float tile_conflict_factor(int th, int tw, int TH) {
+    const int cols = TH, hw = tw + 2, npx = th * tw;             // TH columns of 32 slots per workgroup (waves x rows per wave)
+    long long cyc = 0, n = 0;
+    for (int col = 0; col < cols; ++col)
+        for (int grp = 0; grp < 2; ++grp) {
+            int cntm[16] = {0};
+            for (int s = 0; s < 16; ++s) {
+                int p = col * 32 + grp * 16 + s;
+                if (p >= npx) p = 0;
+                const int tr = p / tw, tc = p - tr * tw;
+                ++cntm[(tr * hw + tc) & 15];
+            }
+            int mx = 1;
+            for (int i = 0; i < 16; ++i) mx = cntm[i] > mx ? cntm[i] : mx;
+            cyc += mx; ++n;
+        }
+    return (float)cyc / (float)n;
+}
 void conv_tile_shape(int N, int H, int W, int TH, bool pooled, int& th, int& tw) {
     th = TH; tw = 32;
     // ELD_CONV_TILES (A/B runs of the tile choice; virtual rows stay): f = TH x 32 everywhere, p = widths 8/16/32/64 only, m<k> = widths >= k,
-    // q<k> = widths that are multiples of k
+    // q<k> = widths that are multiples of k, t = fewest tiles (no conflict term)
     static int mode = -1, marg = 0;
     if (mode < 0) {
         const char* e = getenv("ELD_CONV_TILES");
@@ -445,18 +466,26 @@ void conv_tile_shape(int N, int H, int W, int TH, bool pooled, int& th, int& tw)
         if (e && e[0] == 'p') mode = 2;
         if (e && e[0] == 'm') { mode = 3; marg = atoi(e + 1); }
         if (e && e[0] == 'q') { mode = 4; marg = atoi(e + 1) > 0 ? atoi(e + 1) : 1; }
+        if (e && e[0] == 't') mode = 5;
     }
-    if (pooled || mode == 1 || N <= 0 || H <= 0 || W <= 0) return;
+    if (pooled || mode == 1 || N <= 0 || H <= 0 || W <= 0 || (TH != 8 && TH != 16 && TH != 32)) return;
+    static float cf[3][65];                                  // conflict factor per width, per TH in {8, 16, 32}; filled once (shape-independent)
+    static bool cf_ready[3] = {false, false, false};
+    const int ti = TH == 8 ? 0 : (TH == 16 ? 1 : 2);
     const int slots = TH * 32, halo = (TH + 2) * 34;
-    long long best = tile_count(N, H, W, th, tw);
+    auto height = [&](int w) { int h = slots / w; while (h > 1 && (h + 2) * (w + 2) > halo) --h; return h > 128 ? 128 : h; };
+    if (!cf_ready[ti]) {
+        for (int w = 8; w <= 64; ++w) cf[ti][w] = tile_conflict_factor(height(w), w, TH);
+        cf_ready[ti] = true;
+    }
+    double best = (double)tile_count(N, H, W, th, tw);       // the standard shape is conflict-free
     for (int w = 8; w <= 64; ++w) {                          // narrower than 8 pixels: a halo row is no longer a few whole 64-byte DMA units
         if (mode == 2 && (w & (w - 1))) continue;
         if (mode == 3 && w < marg) continue;
         if (mode == 4 && w % marg) continue;
-        int h = slots / w;
-        while (h > 1 && (h + 2) * (w + 2) > halo) --h;
-        if (h > 128) h = 128;
-        const long long c = tile_count(N, H, W, h, w);
+        const int h = height(w);
+        if (h == TH && w == 32) continue;
+        const double c = (double)tile_count(N, H, W, h, w) * (mode == 5 ? 1.0 : 1.0 + 0.01 * ((double)cf[ti][w] - 1.0));
         if (c < best) { best = c; th = h; tw = w; }
     }
 }

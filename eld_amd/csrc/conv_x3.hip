@@ -397,6 +397,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
     const int THL = a.tile_h, TWL = a.tile_w, HWL = TWL + 2;
     const int APX = (THL + 2) * HWL, NPX = THL * TWL, VP = a.vp;
     const bool seam = VP % THL != 0;
+    const bool grouped = conv_slots_grouped(THL, TWL, TH);                  // slots numbered lane group by lane group (conv.h conv_tile_shape)
     const unsigned mag_hw = (unsigned)((0x100000000ull + (unsigned)HWL - 1) / (unsigned)HWL);      // x / HWL == umulhi(x, mag_hw) for x < 2^16
     const unsigned mag_tw = (unsigned)((0x100000000ull + (unsigned)TWL - 1) / (unsigned)TWL);
 
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
     int pb[RPW];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
-        int p = (wave * RPW + r) * 32 + m;
+        int p = (wave * RPW + r) * 32 + conv_slot_of_lane(m, grouped);
         p = p < NPX ? p : 0;
         const int tr = (int)__umulhi((unsigned)p, mag_tw);
         pb[r] = (tr * HWL + (p - tr * TWL)) * PX + hi * 4;
@@ -579,8 +580,8 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
 
         // ---- epilogue: lane (m, hi) owns pixel slot m of MFMA column r and channels 8q+4hi..+3 of each 32-block (as conv_x3_kernel) ----
         // slot of column r -> NHW pixel index; false: no such pixel (slot beyond the tile, separator row, outside the image)
-        auto slot_pixel = [&](int r, int sl, size_t& pix) -> bool {
-            const int p = (wave * RPW + r) * 32 + sl;
+        auto slot_pixel = [&](int r, int col, size_t& pix) -> bool {       // col: MFMA column (lane & 31 of the lane that computed it)
+            const int p = (wave * RPW + r) * 32 + conv_slot_of_lane(col, grouped);
             const int tr = (int)__umulhi((unsigned)p, mag_tw), x = x0 + p - tr * TWL;
             int dimg, y;
             const bool ok = strip_row(vrel + tr, dimg, y) && p < NPX && img0 + dimg < a.N && x < a.W;

@@ -43,14 +43,14 @@ def main():
         b = sum(2.0 * f[k] * 1024.0 + w.get(k, 0.0) * 1024.0 for k in noise)
         out['sampler_bytes_per_pixel'] = b / px
     passes = sum(fc[k] for k in f if 'head_fwd_kernel' in k or 'head_train_kernel' in k)      # one head launch per forward pass (fused training head or plain)
-    conv = [k for k in f if any(s in k for s in ('conv_igemm_kernel', 'conv_x3', 'wgrad_kernel', 'conv_first', 'wgrad_reduce'))]
+    conv = [k for k in f if any(s in k for s in ('conv_igemm_kernel', 'conv_x3', 'wgrad_kernel', 'wgrad8_kernel', 'conv_first', 'wgrad_reduce'))]
     if passes and conv:
         out['unet_passes'] = passes
         out['frames_per_pass'] = int(sys.argv[4]) if len(sys.argv) > 4 else 8
         out['unet_conv_bytes_per_pass'] = sum(2.0 * f[k] * 1024.0 + w.get(k, 0.0) * 1024.0 for k in conv) / passes
     if len(sys.argv) > 5 and sys.argv[5] == 'bf16':
         passes = sum(fc[k] for k in f if 'head_fwd_kernel' in k or 'head_train_kernel' in k)
-        conv = [k for k in f if any(s_ in k for s_ in ('conv_igemm_kernel', 'conv_bf', 'wgrad8_kernel', 'wgrad_kernel', 'conv_first', 'wgrad_reduce'))]
+        conv = [k for k in f if any(s_ in k for s_ in ('conv_igemm_kernel', 'conv_bf', 'wgrad8_kernel', 'wgrad8d_kernel', 'wgrad_kernel', 'conv_first', 'wgrad_reduce'))]
         try:
             base = json.load(open(sys.argv[3]))
         except Exception:
