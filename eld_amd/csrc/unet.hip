@@ -268,9 +268,15 @@ int make_plan(Plan& P, int N, int H, int W, int in_ch, int out_ch) {
     return 0;
 }
 
-int pack_weights(const Plan& P, const float* params, float* ws, bool for_backward, hipStream_t st, bool bf16 = false, float* amax = nullptr) {
+// dir: PACK_FWD / PACK_BWD = the layouts one direction reads; PACK_BOTH = both in ONE launch (the fused training forward: the backward that follows
+// with dout == NULL then skips its own pack launch -- the parameters it differentiates are by construction the ones the forward ran with)
+enum { PACK_FWD = 0, PACK_BWD = 1, PACK_BOTH = 2 };
+int pack_weights(const Plan& P, const float* params, float* ws, int dir, hipStream_t st, bool bf16 = false, float* amax = nullptr) {
     PackJobs jobs;
     jobs.n = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+    const bool for_backward = pass == 1;
+    if ((dir == PACK_FWD && for_backward) || (dir == PACK_BWD && !for_backward)) continue;
     for (int i = 0; i < NLAYERS; ++i) {
         const LayerDef& d = P.L[i];
         PackJob J = {};
@@ -301,6 +307,7 @@ int pack_weights(const Plan& P, const float* params, float* ws, bool for_backwar
                                                         : bfg_slab_bn(false, 4 * d.cout, d.cin, d.cout, P.N, P.Hl[lev + 1], P.Wl[lev + 1])) : 0;
         jobs.job[jobs.n++] = J;
     }
+    }
     return launch_pack_all(jobs, params, ws, st, amax);
 }
 
@@ -328,6 +335,10 @@ struct BucketMarks {
 // hl != null: the training step's fused head (output + loss + head backward), see launch_head_train
 struct HeadLoss { const float* target; float* loss; int mse; float grad_scale; };
 
+// What eld_unet_forward_loss_ex leaves for the backward that follows it with dout == NULL (besides the head's partials): both pack directions done, and
+// -- when the first layer reads the NCHW input directly -- the caller's input tensor itself instead of a copy in the workspace (8 frames: 388 MB, 0.13 ms).
+struct FusedFwd { bool packed = false; const float* x = nullptr; };
+
 int unet_forward(const Plan& P, const float* x, const float* prm, float* out, float* ws, hipStream_t st, const HeadLoss* hl = nullptr) {
     const int N = P.N;
     KPartScope kp(ws + P.part, P.part_floats);
@@ -338,9 +349,11 @@ int unet_forward(const Plan& P, const float* x, const float* prm, float* out, fl
         g_am.in0 = am + in0; g_am.in1 = in1 >= 0 ? am + in1 : nullptr; g_am.w = am + w; g_am.out0 = am + out0;
     };
     if (h2 && hipMemsetAsync(am, 0, S_COUNT * sizeof(float), st) != hipSuccess) return (int)hipGetLastError();
-    RC(pack_weights(P, prm, ws, false, st, false, h2 ? am : nullptr));
+    RC(pack_weights(P, prm, ws, hl ? PACK_BOTH : PACK_FWD, st, false, h2 ? am : nullptr));
     const bool first_direct = P.in_ch <= 4;        // conv1_1 straight from the NCHW planes (conv_first.hip)
-    if (first_direct) {
+    if (first_direct && hl) {
+        // fused training forward: the backward reads the caller's x (include/eld_amd.h: it must stay valid and unchanged until that call)
+    } else if (first_direct) {
         // keep the input for the backward's weight gradient (the backward entry point does not receive x)
         hipError_t e = hipMemcpyAsync(ws + P.x16, x, (size_t)N * P.in_ch * P.H * P.W * sizeof(float), hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return (int)e;
@@ -398,8 +411,8 @@ int conv_fwd_bf16(const bf16_t* in0, int C0, const bf16_t* in1, int C1, const bf
 int unet_forward_bf16(const Plan& P, const float* x, const float* prm, float* out, float* ws, hipStream_t st, const HeadLoss* hl = nullptr) {
     const int N = P.N;
     if (P.in_ch > 4) return ELD_ENOTSUP;
-    RC(pack_weights(P, prm, ws, false, st, true));
-    {   // keep the fp32 input for the first layer's weight gradient
+    RC(pack_weights(P, prm, ws, hl ? PACK_BOTH : PACK_FWD, st, true));
+    if (!hl) {   // keep the fp32 input for the first layer's weight gradient (the fused training forward leaves it with the caller: see FusedFwd)
         hipError_t e = hipMemcpyAsync(ws + P.x16, x, (size_t)N * P.in_ch * P.H * P.W * sizeof(float), hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return (int)e;
     }
@@ -434,13 +447,13 @@ int unet_forward_bf16(const Plan& P, const float* x, const float* prm, float* ou
     return 0;
 }
 
-int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd, float* ws, hipStream_t st, BucketMarks& marks) {
+int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd, float* ws, hipStream_t st, BucketMarks& marks, const FusedFwd& fused) {
     const int N = P.N;
     KPartScope kp(ws + P.part, P.part_floats);
     const bool h2 = g_algo == 2;
     float* am = ws + P.amax;
     if (h2 && hipMemsetAsync(am + S_GA, 0, (S_COUNT - S_GA) * sizeof(float), st) != hipSuccess) return (int)hipGetLastError();
-    RC(pack_weights(P, prm, ws, true, st, false, h2 ? am : nullptr));
+    if (!fused.packed) RC(pack_weights(P, prm, ws, PACK_BWD, st, false, h2 ? am : nullptr));
     float* gA = ws + P.gA; float* gB = ws + P.gB; float* part = ws + P.part;
     auto gs = [&](const float* buf) { return buf == gA ? (int)S_GA : (int)S_GB; };                 // slot of a ping-pong gradient buffer
     auto fresh = [&](int slot) -> int {                                                               // zero a slot before its tensor is rewritten
@@ -494,7 +507,7 @@ int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd
         { float* t = cur; cur = oth; oth = t; }
         if (l == 0) {
             if (P.in_ch <= 4)
-                RC(launch_conv_first_wgrad(cur, ws + P.x16, grd + P.L[ia].w_off, grd + P.L[ia].b_off, part, N, P.in_ch, H, W, st));
+                RC(launch_conv_first_wgrad(cur, fused.x ? fused.x : ws + P.x16, grd + P.L[ia].w_off, grd + P.L[ia].b_off, part, N, P.in_ch, H, W, st));
             else {
                 WG(gs(cur), S_X, -1);
                 RC(conv_wgrad(cur, C, ws + P.x16, 16, nullptr, 0, P.in_ch, grd + P.L[ia].w_off, grd + P.L[ia].b_off, part, N, H, W, st));
@@ -537,10 +550,10 @@ int conv_wgrad_bf16(const bf16_t* g, int Cout, const bf16_t* x0, int C0, const b
     return launch_wgrad_reduce(part, a.bpart, dw, db, q.psplit, q.T, q.CA, q.CBp, C0 + C1, st);
 }
 
-int unet_backward_bf16(const Plan& P, const float* dout, const float* prm, float* grd, float* ws, hipStream_t st, BucketMarks& marks) {
+int unet_backward_bf16(const Plan& P, const float* dout, const float* prm, float* grd, float* ws, hipStream_t st, BucketMarks& marks, const FusedFwd& fused) {
     const int N = P.N;
     if (P.in_ch > 4) return ELD_ENOTSUP;
-    RC(pack_weights(P, prm, ws, true, st, true));
+    if (!fused.packed) RC(pack_weights(P, prm, ws, PACK_BWD, st, true));
     auto B = [&](size_t off) { return reinterpret_cast<bf16_t*>(ws + off); };
     bf16_t* cur = B(P.gA); bf16_t* oth = B(P.gB); float* part = ws + P.part;
     const LayerDef& Hd = P.L[L_HEAD];
@@ -585,7 +598,7 @@ int unet_backward_bf16(const Plan& P, const float* dout, const float* prm, float
         RC(conv_bwd_data_bf16(cur, B(P.wp_bwd[ib]), oth, nullptr, C, B(P.ea[l]), nullptr, N, H, W, C, C, st));
         swap();
         if (l == 0) {
-            RC(launch_conv_first_wgrad_bf16(cur, ws + P.x16, grd + P.L[ia].w_off, grd + P.L[ia].b_off, part, N, P.in_ch, H, W, st));
+            RC(launch_conv_first_wgrad_bf16(cur, fused.x ? fused.x : ws + P.x16, grd + P.L[ia].w_off, grd + P.L[ia].b_off, part, N, P.in_ch, H, W, st));
             RC(marks.done(P, ia, st));
             break;
         }
@@ -624,7 +637,7 @@ extern "C" size_t eld_unet_workspace_bytes(int N, int H, int W, int in_ch, int o
 // the gradient buffer and the head partials that ONLY eld_unet_forward_loss_ex leaves there, for exactly its N / H / W / precision.  Keyed by the
 // workspace pointer; a plain forward on the same workspace clears the entry.  Host bookkeeping only: no device read, no synchronisation.
 namespace {
-struct HeadState { int N, H, W, in_ch, out_ch, precision; };
+struct HeadState { int N, H, W, in_ch, out_ch, precision; const float* x; };
 std::mutex g_head_mu;
 std::unordered_map<const void*, HeadState> g_head;
 void head_state_set(const void* ws, const HeadState* st) {
@@ -634,12 +647,14 @@ void head_state_set(const void* ws, const HeadState* st) {
         g_head[ws] = *st;
     } else g_head.erase(ws);
 }
-bool head_state_is(const void* ws, const HeadState& want) {
+bool head_state_is(const void* ws, HeadState& want) {      // fills want.x (the fused forward's input tensor) on a match
     std::lock_guard<std::mutex> lk(g_head_mu);
     const auto it = g_head.find(ws);
     if (it == g_head.end()) return false;
     const HeadState& h = it->second;
-    return h.N == want.N && h.H == want.H && h.W == want.W && h.in_ch == want.in_ch && h.out_ch == want.out_ch && h.precision == want.precision;
+    if (!(h.N == want.N && h.H == want.H && h.W == want.W && h.in_ch == want.in_ch && h.out_ch == want.out_ch && h.precision == want.precision)) return false;
+    want.x = h.x;
+    return true;
 }
 }  // namespace
 
@@ -671,7 +686,7 @@ extern "C" int eld_unet_forward_loss_ex(const float* x, const float* params, con
     const HeadLoss hl = {target, loss, loss_kind, grad_scale};
     head_state_set(ws, nullptr);
     const int rc = precision == 1 ? unet_forward_bf16(P, x, params, out, (float*)ws, as_stream(stream), &hl) : unet_forward(P, x, params, out, (float*)ws, as_stream(stream), &hl);
-    if (rc == 0) { const HeadState hs = {N, H, W, in_ch, out_ch, precision}; head_state_set(ws, &hs); }
+    if (rc == 0) { const HeadState hs = {N, H, W, in_ch, out_ch, precision, x}; head_state_set(ws, &hs); }
     return rc;
 }
 extern "C" int eld_unet_backward_ex(const float* dout, const float* params, float* grads, void* ws, size_t ws_bytes, int N, int H, int W,
@@ -684,14 +699,20 @@ extern "C" int eld_unet_backward_ex(const float* dout, const float* params, floa
     if (n_buckets < 0 || (n_buckets > 0 && (!bucket_start || !bucket_event))) return ELD_EINVAL;
     // dout == NULL is only meaningful right after eld_unet_forward_loss_ex on this workspace with the same problem: anything else would hand back
     // stale head gradients without a sign of trouble
-    if (!dout) { const HeadState hs = {N, H, W, in_ch, out_ch, precision}; if (!head_state_is(ws, hs)) return ELD_EINVAL; }
+    FusedFwd fused;
+    if (!dout) {
+        HeadState hs = {N, H, W, in_ch, out_ch, precision, nullptr};
+        if (!head_state_is(ws, hs)) return ELD_EINVAL;
+        fused.packed = true;
+        fused.x = in_ch <= 4 ? hs.x : nullptr;      // (more input planes: the forward converted x to NHWC16 in the workspace)
+    }
     for (int k = 0; k < n_buckets; ++k)
         if (!bucket_event[k] || bucket_start[k] < 0 || (k > 0 && bucket_start[k] <= bucket_start[k - 1]) || (size_t)bucket_start[k] >= P.nparams) return ELD_EINVAL;
     BucketMarks marks;
     marks.start = bucket_start; marks.event = bucket_event; marks.n = n_buckets;
     AlgoScope scope(fp32_algo);
-    const int rc = precision == 1 ? unet_backward_bf16(P, dout, params, grads, (float*)ws, as_stream(stream), marks)
-                                  : unet_backward(P, dout, params, grads, (float*)ws, as_stream(stream), marks);
+    const int rc = precision == 1 ? unet_backward_bf16(P, dout, params, grads, (float*)ws, as_stream(stream), marks, fused)
+                                  : unet_backward(P, dout, params, grads, (float*)ws, as_stream(stream), marks, fused);
     if (rc) return rc;
     return marks.next == n_buckets ? 0 : ELD_EINVAL;
 }

@@ -21,7 +21,7 @@ int launch_colsum(const float* x, float* out, float* part, size_t P, int C, hipS
 int launch_colsum_reduce(const float* part, float* out, int nblocks, int C, hipStream_t st);
 int launch_pack(const float* src, float* dst, int kind, int Cout, int Cin, int Cinp, int T, hipStream_t st, int x3bn = 0);
 struct PackJob { size_t src_off, dst_off; int kind, Cout, Cin, Cinp, T, first_block, bf16, amax_slot, x3bn, bfdbn, bfgbn; };   // bfgbn: 0 or the transposed-conv slab BN (conv_bfg.hip)   // bfdbn: 0 or the bf16 DMA slab BN (conv_bfd.hip)   // x3bn: 0 or the slab BN (pre-split slab layout)   // dst_off in floats; bf16: write bf16_t
-struct PackJobs { int n; PackJob job[24]; };
+struct PackJobs { int n; PackJob job[48]; };      // both directions of all 22 packed layers fit one launch (3 KB of kernel arguments)
 int launch_pack_all(PackJobs& jobs, const float* params, float* ws, hipStream_t st, float* amax = nullptr);      // amax: per-layer max|w| slots
 int launch_absmax(const float* x, size_t n, float* slot, hipStream_t st);
 size_t l1_ws_floats();

@@ -185,7 +185,11 @@ int eld_unet_backward_buckets(const float* dout, const float* params, float* gra
  * nn.MSELoss, models/losses.py:30-34; mean over all elements, written to *loss on the device) and the head's own backward run as ONE pass over
  * conv9_2's output: `out` is written, the output gradient never touches memory, the gradient of conv9_2's output and the head's weight-gradient
  * partials stay in the workspace.  Follow with eld_unet_backward_ex(dout = NULL, same workspace, same shape / precision), which finishes the
- * head's dW / db and runs the rest of the backward.  grad_scale multiplies dLoss/dout (1 for a plain mean loss). */
+ * head's dW / db and runs the rest of the backward.  grad_scale multiplies dLoss/dout (1 for a plain mean loss).
+ * The pair shares more than the head: the forward packs the weights for both directions in one launch (the backward differentiates at the
+ * parameters the forward ran with), and the backward's first-layer weight gradient reads `x` where the forward read it -- no copy of the input is
+ * kept in the workspace.  `x` (and `params`) must therefore stay valid and unchanged until the matching eld_unet_backward_ex(dout = NULL) has
+ * been enqueued on the same stream. */
 int eld_unet_forward_loss_ex(const float* x, const float* params, const float* target, float* out, float* loss, void* ws, size_t ws_bytes,
                              int N, int H, int W, int in_ch, int out_ch, int precision, int fp32_algo, int loss_kind, float grad_scale, void* stream);
 /* The same two calls with everything per call: precision 0 = fp32 / 1 = bf16 activations; fp32_algo names the fp32 product
