@@ -900,7 +900,7 @@ __global__ __launch_bounds__(512, 2) void wgrad8d_kernel(const WgradArgs a) {
 static int wgrad8_dma() {
     static int on = -1;
     if (on < 0) { const char* e = getenv("ELD_WGRAD_DMA"); on = e ? (atoi(e) != 0) : 1; }
-    return on;
+    return on && !(debug_kernel_mask(-1) & 16);      // test hook (eld_debug_kernel_mask bit 4): back on the register-staged kernel
 }
 bool wgrad8_shape(int CA, int CBp, int& COB, int& JBK, int& TH, int& TWo, bool bf16) {
     if (CA % 32 || CBp % 32) return false;

@@ -540,6 +540,38 @@ def test_bf16_specialised_kernels_equal_the_generic_kernel_bit_for_bit(lib, shap
         assert worst[n] <= 1e-2, (n, worst[n])
 
 
+@pytest.mark.parametrize('shape', [(3, 4, 272, 560), (1, 4, 1424, 2128)])
+def test_bf16_dma_weight_gradient_equals_the_register_staged_kernel(lib, shape):
+    """wgrad8d_kernel (round 4: both operand tiles of the 128 x 64 weight-gradient blocks by LDS-DMA, two tile buffers, 16 x 8 tiles on the
+    virtual-row strip, bias sums read back from the landed tile) against wgrad8_kernel<bf16> (register-staged, 32 x 8 tiles) on the same
+    activations: the two sum the same bf16 products in fp32 over the pixels in a different order, so every parameter gradient must agree to
+    1e-4 relative L2 (measured ~1e-6); a tile published before its DMA pieces landed, or a wrong seam row, is off by orders of magnitude.
+    Three images of odd-height levels (17 x 35 at the deepest level: strip seams inside tiles) and the full frame."""
+    from eld_amd.unet import UNetSeeInDark
+    torch.manual_seed(5)
+    net = UNetSeeInDark(4, 4).cuda()
+    net.train_precision = net.inference_precision = 'bf16'
+    g = torch.Generator(device='cuda').manual_seed(9)
+    x = torch.rand(*shape, device='cuda', generator=g)
+    t = torch.rand(*shape, device='cuda', generator=g)
+    res = {}
+    for mask in (0, 16):
+        prev = lib.eld_debug_kernel_mask(mask)
+        try:
+            net.zero_grad()
+            out = net(x)
+            torch.nn.functional.l1_loss(out, t).backward()
+            res[mask] = (out.detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters()})
+        finally:
+            lib.eld_debug_kernel_mask(prev)
+    assert torch.equal(res[0][0], res[16][0])                      # the forward does not depend on the weight-gradient kernel
+    for n in res[0][1]:
+        a, b = res[0][1][n].double(), res[16][1][n].double()
+        assert float((a - b).norm() / b.norm().clamp_min(1e-300)) <= 1e-4, n
+    # the 128-channel layers are the ones that switched kernels: their gradients must not be bit-identical by accident of routing
+    assert any(not torch.equal(res[0][1][n], res[16][1][n]) for n in res[0][1] if n.startswith(('conv3', 'conv4', 'conv5', 'conv6', 'conv7')))
+
+
 def test_unet_full_frame_properties(lib):
     """BASELINE.json configs[1] size (1 x 4 x 1424 x 2128), where the fp64 oracle is out of reach: size-independent properties.
       * crop consistency: away from the crop border (beyond the receptive field) the output of a 16-aligned 512x512 crop
