@@ -1,4 +1,4 @@
-# round-4 evidence run: full test suite, profile set, parity tables, end-metric training parity, eval sweep, unmodified train_syn.py
+# evidence run of a round (usage: gpurun --timeout 3600 -- "bash tools/gpu_round_evidence.sh <tag>"): full test suite, profile set, parity tables, end-metric training parity, eval sweep, unmodified train_syn.py
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 T=${1:-r04f}
