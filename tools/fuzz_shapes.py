@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Shape fuzz of the strip tiling / free tile shapes (dev check, GPU): random (N, H, W) -- heights and widths that are NOT multiples of the tiles, many
+images, tiny deep levels -- through the whole U-Net step.
+  bf16: the specialised kernels (mask 8) against the generic conv_igemm_kernel<bf16> (mask 15, untouched by the strip tiling): output and every gradient
+        bit for bit; wgrad8d vs wgrad8 (mask 16) to 1e-4.
+  fp32: the default three-piece scheme against the fp32-MFMA scheme (algo 0: conv_igemm_kernel<float> / wgrad_kernel, per-image tiles) to 2e-4 of max|ref|
+        per tensor (two different exact-to-fp32 accumulations)."""
+import os, sys, random
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import eld_amd
+lib = eld_amd.load_library()
+from eld_amd.unet import UNetSeeInDark
+
+def step(net, x, t):
+    net.zero_grad()
+    out = net(x)
+    torch.nn.functional.l1_loss(out, t).backward()
+    return out.detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+
+def main(n_cases=24, seed=0, big=1):
+    rnd = random.Random(seed)
+    torch.manual_seed(5)
+    net = UNetSeeInDark(4, 4).cuda()
+    bad = 0
+    for case in range(n_cases):
+        N = rnd.choice([1, 2, 3, 5, 8, 9])
+        H = 16 * rnd.randint(1, big * (24 if N <= 3 else 12))
+        W = 16 * rnd.randint(1, big * (24 if N <= 3 else 12))
+        g = torch.Generator(device='cuda').manual_seed(case)
+        x = torch.rand(N, 4, H, W, device='cuda', generator=g)
+        t = torch.rand(N, 4, H, W, device='cuda', generator=g)
+        msg = []
+        # ---- bf16: specialised vs generic, bit for bit
+        net.train_precision = net.inference_precision = 'bf16'
+        res = {}
+        for mask in (8, 15, 16):
+            prev = lib.eld_debug_kernel_mask(mask)
+            try: res[mask] = step(net, x, t)
+            finally: lib.eld_debug_kernel_mask(prev)
+        if not torch.equal(res[8][0], res[15][0]): msg.append('bf16 out')
+        for n_ in res[8][1]:
+            if not torch.equal(res[8][1][n_], res[15][1][n_]): msg.append('bf16 grad ' + n_)
+        prev = lib.eld_debug_kernel_mask(0)
+        r0 = step(net, x, t)
+        lib.eld_debug_kernel_mask(prev)
+        for n_ in r0[1]:
+            a, b = r0[1][n_].double(), res[16][1][n_].double()
+            if float((a - b).norm()) > 1e-4 * float(b.norm()) + 1e-30: msg.append('wgrad8d ' + n_)
+        # ---- fp32: default scheme vs fp32 MFMA scheme
+        net.train_precision = net.inference_precision = 'fp32'
+        r = {}
+        for algo in (1, 0):
+            prev = lib.eld_conv_fp32_algo(algo)
+            try: r[algo] = step(net, x, t)
+            finally: lib.eld_conv_fp32_algo(prev)
+        if float((r[1][0] - r[0][0]).abs().max()) > 1e-5 * (1 + float(r[0][0].abs().max())): msg.append('fp32 out')
+        for n_ in r[1][1]:
+            a, b = r[1][1][n_].double(), r[0][1][n_].double()
+            if float((a - b).abs().max()) > 1e-3 * float(b.abs().max()) + 1e-30: msg.append('fp32 grad %s %.2e' % (n_, float((a - b).abs().max()) / float(b.abs().max())))
+        torch.cuda.synchronize()
+        print('case %2d  N=%d H=%d W=%d  %s' % (case, N, H, W, 'ok' if not msg else 'MISMATCH: ' + '; '.join(msg[:6])), flush=True)
+        bad += bool(msg)
+    print('%d / %d cases with mismatches' % (bad, n_cases))
+    return bad
+
+if __name__ == '__main__':
+    a = [int(v) for v in sys.argv[1:4]] + [24, 0, 1][len(sys.argv) - 1:]
+    sys.exit(1 if main(*a) else 0)
