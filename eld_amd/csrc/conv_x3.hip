@@ -953,7 +953,9 @@ int launch_x3d(ConvArgs a, hipStream_t st) {
     // split K where the smallest tiles still leave most of the chip idle (single patches: conv5_x of a 512 x 512 input is 32 workgroups) and the
     // caller provided room for the partial sums
     a.ksplit = 1;
-    if (WAVES == 4 && a.kpart != nullptr) {
+    static int no_splitk = -1;                                   // dev switch (ELD_NO_SPLITK=1): small problems without the K split
+    if (no_splitk < 0) { const char* e = getenv("ELD_NO_SPLITK"); no_splitk = e ? atoi(e) : 0; }
+    if (WAVES == 4 && a.kpart != nullptr && !no_splitk) {
         const int nch = (a.C0 + a.C1) / 16;
         const size_t plane = (size_t)a.N * a.H * a.W * a.Nout;
         int ks = (int)(eld_num_cus() / tiles);

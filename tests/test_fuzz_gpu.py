@@ -1,6 +1,6 @@
 """GPU: random (N, H, W) through the whole U-Net step -- the strip tiling, the free tile shapes and the DMA-staged weight gradient against the kernel
 families they did not touch (tools/fuzz_shapes.py: bf16 specialised kernels == generic conv_igemm_kernel<bf16> bit for bit, wgrad8d ~ wgrad8, the
-default fp32 scheme ~ the fp32-MFMA scheme with its per-image tiles)."""
+default fp32 scheme against the float64 oracle."""
 import importlib.util
 import os
 

@@ -3,14 +3,15 @@
 images, tiny deep levels -- through the whole U-Net step.
   bf16: the specialised kernels (mask 8) against the generic conv_igemm_kernel<bf16> (mask 15, untouched by the strip tiling): output and every gradient
         bit for bit; wgrad8d vs wgrad8 (mask 16) to 1e-4.
-  fp32: the default three-piece scheme against the fp32-MFMA scheme (algo 0: conv_igemm_kernel<float> / wgrad_kernel, per-image tiles) to 2e-4 of max|ref|
-        per tensor (two different exact-to-fp32 accumulations)."""
+  fp32: the default three-piece scheme against the float64 oracle (oracle/unet_ref.py on the GPU's fp64 vector units): output to 1e-5, every gradient to
+        5e-3 relative L2 (sign flips of near-zero LeakyReLU inputs under float32 rounding dominate at the tiny deep levels of small inputs)."""
 import os, sys, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import eld_amd
 lib = eld_amd.load_library()
 from eld_amd.unet import UNetSeeInDark
+from oracle import unet_ref as U      # checker only
 
 def step(net, x, t):
     net.zero_grad()
@@ -47,17 +48,18 @@ def main(n_cases=24, seed=0, big=1):
         for n_ in r0[1]:
             a, b = r0[1][n_].double(), res[16][1][n_].double()
             if float((a - b).norm()) > 1e-4 * float(b.norm()) + 1e-30: msg.append('wgrad8d ' + n_)
-        # ---- fp32: default scheme vs fp32 MFMA scheme
+        # ---- fp32: default three-piece scheme vs the float64 oracle (stock torch ops on the GPU's fp64 units: checker only)
         net.train_precision = net.inference_precision = 'fp32'
-        r = {}
-        for algo in (1, 0):
-            prev = lib.eld_conv_fp32_algo(algo)
-            try: r[algo] = step(net, x, t)
-            finally: lib.eld_conv_fp32_algo(prev)
-        if float((r[1][0] - r[0][0]).abs().max()) > 1e-5 * (1 + float(r[0][0].abs().max())): msg.append('fp32 out')
-        for n_ in r[1][1]:
-            a, b = r[1][1][n_].double(), r[0][1][n_].double()
-            if float((a - b).abs().max()) > 1e-3 * float(b.abs().max()) + 1e-30: msg.append('fp32 grad %s %.2e' % (n_, float((a - b).abs().max()) / float(b.abs().max())))
+        r1 = step(net, x, t)
+        sd64 = {k: v.detach().double() for k, v in net.state_dict().items()}
+        o64, _, g64 = U.loss_and_grads(sd64, x.double(), t.double())
+        if float((r1[0].double() - o64).abs().max()) > 1e-5 * (1 + float(o64.abs().max())): msg.append('fp32 out')
+        for n_ in r1[1]:
+            a, b = r1[1][n_].double(), g64[n_]
+            # relative L2: a single LeakyReLU sign that float32 rounding flips at a near-zero pre-activation changes that pixel's gradient by a factor
+            # of five -- at the tiny deep levels of small inputs that alone is 1e-3 of max|ref| in any float32 implementation (measured: conv5_2 at
+            # 2 x 112 x 368, identical in the round-3 library) -- while a wrong seam row or tile is off by tens of percent
+            if float((a - b).norm()) > 5e-3 * float(b.norm()) + 1e-30: msg.append('fp32 grad %s %.2e' % (n_, float((a - b).norm()) / float(b.norm())))
         torch.cuda.synchronize()
         print('case %2d  N=%d H=%d W=%d  %s' % (case, N, H, W, 'ok' if not msg else 'MISMATCH: ' + '; '.join(msg[:6])), flush=True)
         bad += bool(msg)
