@@ -670,7 +670,7 @@ __device__ __forceinline__ void wg_dma16(i32x4_t rsrc, unsigned voff, unsigned l
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
 }
 
-template <int WCO, int WCI, int WPIX, int TH, int TWT, bool LATE>
+template <int WCO, int WCI, int WPIX, int TH, int TWT>
 __global__ __launch_bounds__(512, 2) void wgrad8d_kernel(const WgradArgs a) {
     static_assert(WCO * WCI * WPIX == 8, "8 waves");
     static_assert(TWT == 8 || TWT == 16 || TWT == 32, "tile width");
@@ -814,10 +814,8 @@ __global__ __launch_bounds__(512, 2) void wgrad8d_kernel(const WgradArgs a) {
     for (int tile = ps; tile < ntiles; tile += a.psplit) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's pieces of the tile have landed ...
         __syncthreads();                                              // ... and everybody else's; the other buffer is no longer read
-        // LATE: a piece costs its wave 100-200 cycles of issue time; waves 0-3 issue behind the barrier, their SIMD partners 4-7 after their first
-        // k-step, so that one wave of every SIMD feeds the matrix pipe while the other one issues (as conv_bfd_kernel)
-        const bool more = tile + a.psplit < ntiles;
-        if (more && (!LATE || wave < 4)) issue(tile + a.psplit, buf ^ 1);
+        // (waves 4-7 issuing their pieces behind their first k-step, as conv_bfd_kernel does, measured +1.3 % here: profiles/r04_ab_notes.md)
+        if (tile + a.psplit < ntiles) issue(tile + a.psplit, buf ^ 1);
         const int bo = buf * (BUF_BYTES / 2);                        // buffer offset in bf16 elements
         if (do_bias) {
 #pragma unroll
@@ -843,7 +841,6 @@ __global__ __launch_bounds__(512, 2) void wgrad8d_kernel(const WgradArgs a) {
 #pragma unroll
                 for (int tt = 0; tt < 3; ++tt) acc[t0 + tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, xb[tt], acc[t0 + tt], 0, 0, 0);
             }
-            if (LATE && ks == 0 && more && wave >= 4) issue(tile + a.psplit, buf ^ 1);
         }
         buf ^= 1;
     }
@@ -945,7 +942,7 @@ static int launch_w8(WgradArgs a, hipStream_t st) {
     return 0;
 }
 
-template <int WCO, int WCI, int WPIX, int TH, int TWT, bool LATE>
+template <int WCO, int WCI, int WPIX, int TH, int TWT>
 static int launch_w8d(WgradArgs a, hipStream_t st) {
     constexpr int COB = 32 * WCO, JBK = 32 * WCI;
     a.vp = vrow_pitch(a.N, a.H, TH);
@@ -957,7 +954,7 @@ static int launch_w8d(WgradArgs a, hipStream_t st) {
     if (lds_bytes < red_bytes) lds_bytes = red_bytes;
     const long long blocks = (long long)(a.CA / COB) * (a.CBp / JBK) * a.psplit;
     if (blocks <= 0) return 0;
-    auto kern = wgrad8d_kernel<WCO, WCI, WPIX, TH, TWT, LATE>;
+    auto kern = wgrad8d_kernel<WCO, WCI, WPIX, TH, TWT>;
     static EldAttrOnce once;
     { const int rc = once.ensure(kern, lds_bytes); if (rc) return rc; }
     ELD_LAUNCH(kern, dim3((unsigned)blocks), dim3(512), lds_bytes, st, a);
@@ -976,7 +973,7 @@ static int launch_wgrad8(const WgradArgs& a, hipStream_t st) {
     if ((size_t)a.H * a.W * a.CA * es * win >= 0xFFFFFFF0ull || (size_t)a.H * a.W * (a.C0 > a.C1 ? a.C0 : a.C1) * es * win >= 0xFFFFFFF0ull) return ELD_ENOTSUP;
     if (bf16 && wgrad8_dma() && COB == 128) {
         // (measured on the same box, profiles/r04_ab_notes.md: waves 4-7 issuing their pieces behind their first k-step +1.3 %, 20 x 8 tiles +5.5 %)
-        return launch_w8d<4, 2, 1, 16, 8, false>(a, st);
+        return launch_w8d<4, 2, 1, 16, 8>(a, st);
     }
     if (bf16) {
         if (COB == 128) return launch_w8<bf16_t, 4, 2, 1, 32, 8>(a, st);
