@@ -272,7 +272,10 @@ __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a)
 
     // ================================ phase 1 + 2: Poisson counts -> s_cnt ================================
     if (do_pois) {
-        const float lam_c = (S * (1.0f / ratio)) * (1.0f / K);      // lam = y * lam_c  (oracle: poisson_lambda_fast)
+        // the rate is the reference's op chain, op for op: ((y * S) / ratio) / K with correctly rounded divisions (noise.py:155-159; oracle:
+        // poisson_lambda).  Rounds 2-3 formed it as y * c with one per-image constant (10 of ~250 VALU operations per pixel saved, the rate an
+        // ulp off the reference's); round 4 pays them: the only arithmetic of the pinned models that was not the reference's is gone.
+        const float pr_ratio = 1.0f / ratio, pr_K = 1.0f / K;
 #pragma unroll 1
         for (int half = 0; half < NOISE_ITERS / PASS_GROUPS; ++half) {
             constexpr int PE = 4 * PASS_GROUPS;                 // pixels a lane carries through this pass
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(NOISE_THREADS) void noise_kernel(const NoiseArgs a)
                 for (int j = 0; j < 4; ++j) {
                     const int e = gi * 4 + j;
                     ok[e] = (uint32_t)j < nvalid;
-                    lam[e] = fmaxf(y[j] * lam_c, 0.f);
+                    lam[e] = fmaxf(div_rn(div_rn(y[j] * S, ratio, pr_ratio), K, pr_K), 0.f);
                     w[e] = pick(wd, j);
                     wv[e] = pick(wd2, j);
                 }

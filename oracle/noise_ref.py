@@ -249,11 +249,10 @@ POIS_KMAX = 96
 
 
 def poisson_lambda_fast(y, p):
-    """Rate as the HIP sampler forms it on the Philox path: y * c with c = fp32(fp32(S*fp32(1/r)) * fp32(1/K)) --
-    one multiply per pixel instead of two IEEE divisions.  (The reference-order replay keeps poisson_lambda.)"""
-    S, r, K = F32(p['saturation']), F32(p['ratio']), F32(p['K'])
-    c = F32(F32(S * F32(F32(1.0) / r)) * F32(F32(1.0) / K))
-    return (np.asarray(y, F32) * c).astype(F32)
+    """Rate on the Philox path.  Rounds 2-3 of the HIP sampler formed it as y * c with one per-image constant (an ulp off the reference's rate);
+    since round 4 the kernel evaluates the reference's own chain ((y*S)/r)/K with correctly rounded divisions, i.e. exactly poisson_lambda
+    (noise.py:155-159).  The name is kept for the callers."""
+    return poisson_lambda(y, p)
 
 
 def _pois_inversion(lam, u):
