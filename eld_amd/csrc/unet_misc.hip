@@ -461,52 +461,114 @@ int launch_absmax(const float* x, size_t n, float* slot, hipStream_t st) {
     return 0;
 }
 
-// all layers of the network in ONE launch: block b belongs to job j with first_block[j] <= b < first_block[j+1]
-__global__ void pack_all_kernel(const PackJobs jobs, const float* __restrict__ params, float* __restrict__ ws, float* __restrict__ amax) {
+// ---- eight consecutive k-channels (c0 .. c0 + 7, c0 % 8 == 0) of one (tap, column) per thread: in every packed layout these are 16 contiguous bytes ----
+__device__ __forceinline__ uint4 bf8(const float (&v)[8]) { return make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])); }
+__device__ __forceinline__ unsigned hi16_pair(float lo, float hi) { return (__float_as_uint(hi) & 0xFFFF0000u) | (__float_as_uint(lo) >> 16); }
+// x3_store for the eight values: the three pieces as three 16-byte stores
+__device__ __forceinline__ void x3_store8(float* dst, int t, int n, int c0, int N, int K, int BN, const float (&v)[8]) {
+    const int NCH = K >> 4, NB = N / BN;
+    const int ky = t / 3, kx = t - 3 * ky;
+    const size_t slab = (size_t)(ky * NCH + (c0 >> 4)) * NB + n / BN;
+    bf16_t* d = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(dst) + slab * x3_slab_stride(BN)) + (size_t)(kx * BN + (n % BN)) * 56 + (c0 & 15);
+    float r[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        r[j] = v[j] - __uint_as_float(__float_as_uint(v[j]) & 0xFFFF0000u);
+        q[j] = r[j] - __uint_as_float(__float_as_uint(r[j]) & 0xFFFF0000u);
+    }
+    *reinterpret_cast<uint4*>(d) = make_uint4(hi16_pair(v[0], v[1]), hi16_pair(v[2], v[3]), hi16_pair(v[4], v[5]), hi16_pair(v[6], v[7]));
+    *reinterpret_cast<uint4*>(d + 16) = make_uint4(hi16_pair(r[0], r[1]), hi16_pair(r[2], r[3]), hi16_pair(r[4], r[5]), hi16_pair(r[6], r[7]));
+    *reinterpret_cast<uint4*>(d + 32) = make_uint4(hi16_pair(q[0], q[1]), hi16_pair(q[2], q[3]), hi16_pair(q[4], q[5]), hi16_pair(q[6], q[7]));
+}
+__device__ __forceinline__ void bfd_store8(float* dst, int t, int n, int c0, int N, int K, int BN, const float (&v)[8]) {
+    const int NCH = K >> 5, NB = N / BN;
+    const int ky = t / 3, kx = t - 3 * ky;
+    const size_t slab = (size_t)(ky * NCH + (c0 >> 5)) * NB + n / BN;
+    const int P = kx * BN + (n % BN), o = (c0 & 31) >> 3;
+    const int slot = 4 * P + (o ^ ((P >> 2) & 3));
+    reinterpret_cast<uint4*>(reinterpret_cast<char*>(dst) + slab * bfd_slab_bytes(BN))[slot] = bf8(v);
+}
+__device__ __forceinline__ void bfg_store8(float* dst, int n, int c0, int N, int K, int BN, const float (&v)[8]) {
+    const int NB = N / BN, np = n % BN;
+    const size_t slab = (size_t)(c0 >> 5) * NB + n / BN;
+    const int slot = 4 * np + (((c0 & 31) >> 3) ^ ((np >> 2) & 3));
+    reinterpret_cast<uint4*>(reinterpret_cast<char*>(dst) + slab * bfg_slab_bytes(BN))[slot] = bf8(v);
+}
+
+// all layers of the network in ONE launch: block b belongs to job j with first_block[j] <= b < first_block[j+1].  A thread packs eight consecutive
+// k-channels of one (tap, column) -- 16 contiguous bytes per piece in every layout -- and the threads of a wave walk the SOURCE tensor in its own order
+// (OIHW / IOHW: the taps fastest), so that the eight strided loads of a wave cover whole cache lines between them:
+//   PACK_CONV_FWD   k = ci (source stride T):        thread = (co, ci / 8, t)
+//   PACK_CONV_BWD   k = co (source stride Cin T):    thread = (co / 8, ci, source tap)
+//   PACK_CONVT_FWD  k = ci (source stride Cout T):   thread = (ci / 8, co, tap)
+//   PACK_CONVT_BWD  k = tap * Cout + co (stride T):  thread = (ci, co / 8, tap)
+__global__ __launch_bounds__(256) void pack_all_kernel(const PackJobs jobs, const float* __restrict__ params, float* __restrict__ ws, float* __restrict__ amax) {
     int j = 0;
     while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.job[j + 1].first_block) ++j;
     const PackJob J = jobs.job[j];
-    const size_t total = (size_t)J.T * J.Cout * (J.kind == PACK_CONV_FWD ? J.Cinp : J.Cin);
+    const int Cout = J.Cout, Cin = J.Cin, Cinp = J.Cinp, T = J.T;
+    const size_t groups = (size_t)T * Cout * (J.kind == PACK_CONV_FWD ? Cinp : Cin) / 8;
     const size_t i = (size_t)(blockIdx.x - J.first_block) * blockDim.x + threadIdx.x;
-    const bool live = i < total;
+    const bool live = i < groups;
     const float* src = params + J.src_off;
     float* dst = ws + J.dst_off;
-    const int Cout = J.Cout, Cin = J.Cin, Cinp = J.Cinp, T = J.T;
-    float v = 0.f;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    int t = 0, n = 0, c0 = 0;          // tap, column and first k-channel of the packed matrix B[t][n][c]
+    size_t plain = 0;                  // index of the vector in the plain (un-slabbed) layout
     if (!live) {
     } else if (J.kind == PACK_CONV_FWD) {
-        const int ci = (int)(i % Cinp); const int co = (int)((i / Cinp) % Cout); const int t = (int)(i / ((size_t)Cinp * Cout));
-        v = ci < Cin ? src[((size_t)co * Cin + ci) * T + t] : 0.f;
+        const int G = Cinp >> 3;
+        t = (int)(i % T); const int g = (int)((i / T) % G); n = (int)(i / ((size_t)T * G)); c0 = 8 * g;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (c0 + e < Cin) v[e] = src[((size_t)n * Cin + c0 + e) * T + t];
+        plain = ((size_t)t * Cout + n) * Cinp + c0;
     } else if (J.kind == PACK_CONV_BWD) {
-        const int co = (int)(i % Cout); const int ci = (int)((i / Cout) % Cin); const int t = (int)(i / ((size_t)Cout * Cin));
-        v = src[((size_t)co * Cin + ci) * T + (T - 1 - t)];
+        const int ts = (int)(i % T); n = (int)((i / T) % Cin); c0 = 8 * (int)(i / ((size_t)T * Cin)); t = T - 1 - ts;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = src[((size_t)(c0 + e) * Cin + n) * T + ts];
+        plain = ((size_t)t * Cin + n) * Cout + c0;
     } else if (J.kind == PACK_CONVT_FWD) {
-        const int ci = (int)(i % Cin); const int co = (int)((i / Cin) % Cout); const int t = (int)(i / ((size_t)Cin * Cout));
-        v = src[((size_t)ci * Cout + co) * T + t];
+        t = (int)(i % T); const int co = (int)((i / T) % Cout); c0 = 8 * (int)(i / ((size_t)T * Cout)); n = t * Cout + co;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = src[((size_t)(c0 + e) * Cout + co) * T + t];
+        plain = (size_t)n * Cin + c0;
     } else {
-        const int co = (int)(i % Cout); const int ci = (int)((i / Cout) % Cin); const int t = (int)(i / ((size_t)Cout * Cin));
-        v = src[((size_t)ci * Cout + co) * T + t];
+        const int G = Cout >> 3;
+        t = (int)(i % T); const int g = (int)((i / T) % G); n = (int)(i / ((size_t)T * G)); c0 = t * Cout + 8 * g;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = src[((size_t)n * Cout + 8 * g + e) * T + t];
+        plain = ((size_t)t * Cin + n) * Cout + 8 * g;
     }
     if (live) {
-        if (J.bf16 && J.bfdbn && J.kind == PACK_CONV_FWD) bfd_store(dst, (int)(i / ((size_t)Cinp * Cout)), (int)((i / Cinp) % Cout), (int)(i % Cinp), Cout, Cinp, J.bfdbn, v);
-        else if (J.bf16 && J.bfdbn && J.kind == PACK_CONV_BWD) bfd_store(dst, (int)(i / ((size_t)Cout * Cin)), (int)((i / Cout) % Cin), (int)(i % Cout), Cin, Cout, J.bfdbn, v);
-        else if (J.bf16 && J.bfgbn && J.kind == PACK_CONVT_FWD) bfg_store(dst, (int)(i / Cin), (int)(i % Cin), T * Cout, Cin, J.bfgbn, v);          // n = tap*Cout + co, k = ci
-        else if (J.bf16 && J.bfgbn && J.kind == PACK_CONVT_BWD) bfg_store(dst, (int)((i / Cout) % Cin), (int)(i / ((size_t)Cout * Cin)) * Cout + (int)(i % Cout), Cin, T * Cout, J.bfgbn, v);      // n = ci, k = tap*Cout + co
-        else if (J.bf16) reinterpret_cast<bf16_t*>(dst)[i] = f2bf(v);
-        else if (J.x3bn && J.kind == PACK_CONV_FWD) x3_store(dst, (int)(i / ((size_t)Cinp * Cout)), (int)((i / Cinp) % Cout), (int)(i % Cinp), Cout, Cinp, J.x3bn, v);
-        else if (J.x3bn && J.kind == PACK_CONV_BWD) x3_store(dst, (int)(i / ((size_t)Cout * Cin)), (int)((i / Cout) % Cin), (int)(i % Cout), Cin, Cout, J.x3bn, v);
-        else dst[i] = v;
+        if (J.bf16 && J.bfdbn && J.kind == PACK_CONV_FWD) bfd_store8(dst, t, n, c0, Cout, Cinp, J.bfdbn, v);
+        else if (J.bf16 && J.bfdbn && J.kind == PACK_CONV_BWD) bfd_store8(dst, t, n, c0, Cin, Cout, J.bfdbn, v);
+        else if (J.bf16 && J.bfgbn && J.kind == PACK_CONVT_FWD) bfg_store8(dst, n, c0, T * Cout, Cin, J.bfgbn, v);          // n = tap*Cout + co, k = ci
+        else if (J.bf16 && J.bfgbn && J.kind == PACK_CONVT_BWD) bfg_store8(dst, n, c0, Cin, T * Cout, J.bfgbn, v);          // n = ci, k = tap*Cout + co
+        else if (J.bf16) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(dst) + plain) = bf8(v);
+        else if (J.x3bn && J.kind == PACK_CONV_FWD) x3_store8(dst, t, n, c0, Cout, Cinp, J.x3bn, v);
+        else if (J.x3bn && J.kind == PACK_CONV_BWD) x3_store8(dst, t, n, c0, Cin, Cout, J.x3bn, v);
+        else {
+            *reinterpret_cast<float4*>(dst + plain) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(dst + plain + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
     }
-    if (amax) amax_accumulate(amax + J.amax_slot, v);          // per-layer weight bound (all lanes take part)
+    if (amax) {      // per-layer weight bound (all lanes take part)
+        float m = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf(v[e]));
+        amax_accumulate(amax + J.amax_slot, m);
+    }
 }
 
 int launch_pack_all(PackJobs& jobs, const float* params, float* ws, hipStream_t st, float* amax) {
     int blocks = 0;
     for (int j = 0; j < jobs.n; ++j) {
         PackJob& J = jobs.job[j];
-        const size_t total = (size_t)J.T * J.Cout * (J.kind == PACK_CONV_FWD ? J.Cinp : J.Cin);
+        const size_t groups = (size_t)J.T * J.Cout * (J.kind == PACK_CONV_FWD ? J.Cinp : J.Cin) / 8;      // Cinp % 16 == 0, every other channel count % 32 == 0
         J.first_block = blocks;
-        blocks += (int)((total + 255) / 256);
+        blocks += (int)((groups + 255) / 256);
     }
     if (!blocks) return 0;
     ELD_LAUNCH(pack_all_kernel, dim3(blocks), dim3(256), 0, st, jobs, params, ws, amax);
