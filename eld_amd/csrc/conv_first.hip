@@ -6,6 +6,7 @@
 //   wgrad   : dW[co][k]     = sum_pixels g[pixel][co] * patch[k][pixel];  db[co] = sum_pixels g[pixel][co]
 // Both keep the input tile as a zero-padded halo [Cin][TH+2][34] in LDS; a patch element is one ds_read_b32 at
 // (lane-constant tap offset + pixel offset), conflict-free along the 32 pixels of a row.
+#include <type_traits>
 #include "unet_misc.h"
 
 #define FTH 8
@@ -538,6 +539,171 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_bf16_kernel(const bf16_t
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// fp32-gradient variant for the three-piece product scheme (conv_fp32_algo 1, the default fp32 path) on the bf16 MFMA: conv_first_wgrad_kernel's fp32
+// MFMAs take 64 cycles per 2 pixels and are its whole time (1.21 ms per 8 frames; a conflict-free tile layout did not move it).  As conv_x3.hip does for
+// the other layers, both operands are cut EXACTLY into three bf16 pieces (v = p1 + p2 + p3, 8 + 8 + 8 significant bits) while they are staged and a
+// 16-pixel k-step accumulates the six products g1x1 + g1x2 + g2x1 + g1x3 + g2x2 + g3x1 (the dropped ones are below 2^-23 of the product):
+//   A[i = co][k = pixel]  the gradient tile, fp32 [256 pixels][32 co] from HBM through registers (loaded one tile ahead), cut into three [pixel][32] bf16
+//                         planes in LDS and read transposed by ds_read_b64_tr_b16 exactly like conv_first_wgrad_bf16_kernel's single plane;
+//   B[k = pixel][j]       the three shifted halo copies of conv_first_wgrad_bf16_kernel, with three pieces instead of two.
+// The bias gradient is summed from the fp32 registers while they are cut (a thread always stages the same four channels).  Partials and their
+// reduction are the other kernels' ([2][co][j % 32] + 32 bias sums per workgroup, fixed order).  LDS: 48 KB + 28.8 KB (dynamic), two workgroups per CU.
+// Measured: 1.21 -> 0.96 ms per 8 frames (3.5 GB: 3.6 TB/s).  The matrix work is now 0.24 ms of that; what is left is the VALU of the cuts and of the
+// nine two-byte halo stores per input element (≈ 850 VALU instructions per wave and tile against 48 MFMAs).
+// ------------------------------------------------------------------------------------------------------------------
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void conv_first_wgrad_x3_kernel(const float* __restrict__ g, const float* __restrict__ x, float* __restrict__ part,
+                                                                     int N, int H, int W) {
+    constexpr int K = 9 * CIN;
+    constexpr int GPL = FTH * FTW * 32;                                    // bf16 elements of one gradient piece plane
+    constexpr int XPL = 3 * CIN * (FTH + 2) * FXW;                         // bf16 elements of the three shifted halo copies of one piece
+    extern __shared__ __attribute__((aligned(16))) bf16_t x3lds[];
+    bf16_t* gl = x3lds;                                                    // [3 pieces][256 pixels][32 co]
+    bf16_t* xs = x3lds + 3 * GPL;                                          // [3 pieces][dx][c][row][FXW]
+    const int tid = threadIdx.x, lane = tid & 63, m = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = (W + FTW - 1) / FTW, tiles_y = (H + FTH - 1) / FTH;
+    const int total = tiles_x * tiles_y * N;
+    int boff[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+        const int j = jt * 32 + m;
+        const int c = j / 9, r9 = j - c * 9, dy = r9 / 3, dx = r9 - dy * 3;
+        boff[jt] = j < K ? ((dx * CIN + c) * (FTH + 2) + dy) * FXW : -1;
+    }
+    const int gi = lane & 15, gg = lane >> 4;
+    const int gq_off = (8 * hi + (gi >> 2)) * 32 + (gg & 1) * 16 + (gi & 3) * 4;          // ds_read_b64_tr_b16 addressing (conv_wgrad.hip)
+    f32x16 acc[2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[jt][i] = 0.f;
+    float4 bs4 = make_float4(0.f, 0.f, 0.f, 0.f);      // bias sums of channels 4 (tid & 7) .. + 3 over this thread's pixels
+    // Two tiles of loads in flight: a tile's gradient / halo loads are issued TWO tiles ahead, right after the buffer they reuse has been cut (one tile of
+    // lead measured 1.02 ms per 8 frames on a 144 ms-per-step board, two tiles 0.96 ms on a 140 ms one: worth about 3 %; 256 VGPRs, no spills).
+    FirstHalo<CIN> hr[2];
+    float4 gr[2][8];                                   // a thread's 8 units of the 256-pixel x 32-channel gradient tile, two tiles
+    auto prefetch = [&](int t, auto B) {
+        constexpr int b = decltype(B)::value;
+        const int tx = t % tiles_x, ty = (t / tiles_x) % tiles_y, img = t / (tiles_x * tiles_y);
+        const int y0 = ty * FTH, x0 = tx * FTW;
+        hr[b].load(x, img, y0, x0, H, W);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int u = threadIdx.x + it * 256;
+            const int lp = u >> 3, part4 = u & 7;
+            const int gy = y0 + lp / FTW, gx = x0 + lp % FTW;
+            gr[b][it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy < H && gx < W) gr[b][it] = *reinterpret_cast<const float4*>(g + ((size_t)(img * H + gy) * W + gx) * 32 + part4 * 4);
+        }
+    };
+    auto top = [](float v) { return __uint_as_float(__float_as_uint(v) & 0xFFFF0000u); };
+    auto hp = [](float lo, float hi_) { return __builtin_amdgcn_perm(__float_as_uint(hi_), __float_as_uint(lo), 0x07060302u); };      // the two top halves as a bf16 pair
+    const int G = (int)gridDim.x;
+    auto tile = [&](int t, auto B) {
+        constexpr int b = decltype(B)::value;
+        __syncthreads();                                        // the previous tile's fragment reads are done
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {                        // gradient tile -> three bf16 planes
+            const int u = tid + it * 256;
+            const float4 v = gr[b][it];
+            bs4.x += v.x; bs4.y += v.y; bs4.z += v.z; bs4.w += v.w;
+            const float4 r = make_float4(v.x - top(v.x), v.y - top(v.y), v.z - top(v.z), v.w - top(v.w));
+            const float4 q = make_float4(r.x - top(r.x), r.y - top(r.y), r.z - top(r.z), r.w - top(r.w));
+            bf16_t* d = gl + u * 4;                             // [pixel u >> 3][channels 4 (u & 7) ..]
+            *reinterpret_cast<uint2*>(d) = make_uint2(hp(v.x, v.y), hp(v.z, v.w));
+            *reinterpret_cast<uint2*>(d + GPL) = make_uint2(hp(r.x, r.y), hp(r.z, r.w));
+            *reinterpret_cast<uint2*>(d + 2 * GPL) = make_uint2(hp(q.x, q.y), hp(q.z, q.w));
+        }
+#pragma unroll
+        for (int it = 0; it < FirstHalo<CIN>::IT; ++it) {      // halo -> three bf16 pieces -> the three shifted copies
+            const int u = tid + it * 256;
+            if (u >= CIN * FHP) continue;
+            const int c = u / FHP, hp_ = u - c * FHP;
+            const int hy = hp_ / (FTW + 2), hx = hp_ - hy * (FTW + 2);
+            const float v = hr[b].v[it];
+            const float r = v - top(v), q = r - top(r);
+            const bf16_t p1 = (bf16_t)(__float_as_uint(v) >> 16), p2 = (bf16_t)(__float_as_uint(r) >> 16), p3 = (bf16_t)(__float_as_uint(q) >> 16);
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int xx = hx - dx;
+                if (xx < 0 || xx >= FTW) continue;
+                const int o = ((dx * CIN + c) * (FTH + 2) + hy) * FXW + xx;
+                xs[o] = p1;
+                xs[o + XPL] = p2;
+                xs[o + 2 * XPL] = p3;
+            }
+        }
+        __syncthreads();
+        if (t + 2 * G < total) prefetch(t + 2 * G, B);
+        constexpr int GI[6] = {0, 1, 2, 0, 1, 0};
+        constexpr int XI[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {                        // 16 consecutive pixels of one row per k-step; the wave owns rows 2 wave, 2 wave + 1
+            const int row = 2 * wave + (ks >> 1), col0 = 16 * (ks & 1);
+            fw_bf16x8 ga[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                const bf16_t* p0 = gl + pc * GPL + (row * FTW + col0) * 32 + gq_off;
+                const fw_s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) fw_s16x4*)p0);
+                const fw_s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) fw_s16x4*)(p0 + 4 * 32));
+                ga[pc] = __builtin_bit_cast(fw_bf16x8, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                uint4 bx[3] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+                if (boff[jt] >= 0) {
+                    const bf16_t* pb = xs + boff[jt] + row * FXW + col0 + 8 * hi;
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) bx[pc] = *reinterpret_cast<const uint4*>(pb + pc * XPL);
+                }
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+                    acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[GI[q]], __builtin_bit_cast(fw_bf16x8, bx[XI[q]]), acc[jt], 0, 0, 0);
+            }
+        }
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    if ((int)blockIdx.x < total) prefetch(blockIdx.x, B0());
+    if ((int)blockIdx.x + G < total) prefetch(blockIdx.x + G, B1());
+    for (int t = blockIdx.x; t < total; t += 2 * G) {
+        tile(t, B0());
+        if (t + G < total) tile(t + G, B1());
+    }
+    // reduce the 4 waves through LDS (fixed order), wave 0 writes the partial -- as conv_first_wgrad_kernel
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(x3lds);                 // [3 waves][2][16][64] floats = 24 KB, then [256 threads][4] bias sums = 4 KB
+    if (wave > 0) {
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) red[(((wave - 1) * 2 + jt) * 16 + i) * 64 + lane] = acc[jt][i];
+    }
+    float4* bred = reinterpret_cast<float4*>(red + 3 * 2 * 16 * 64);
+    bred[tid] = bs4;
+    __syncthreads();
+    if (wave == 0) {
+        float* p = part + (size_t)blockIdx.x * (2 * 32 * 32 + 32);
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float v = acc[jt][i];
+                for (int wv = 0; wv < 3; ++wv) v += red[((wv * 2 + jt) * 16 + i) * 64 + lane];
+                const int row = (i & 3) + 8 * (i >> 2) + 4 * hi;             // co
+                p[(jt * 32 + row) * 32 + m] = v;                              // [jt][co][j%32]
+            }
+        if (lane < 32) {                                                      // channel `lane`: threads lane / 4 + 8 k hold its sums (component lane % 4)
+            const float* bf = reinterpret_cast<const float*>(bred);
+            float b = 0.f;
+            for (int k = 0; k < 32; ++k) b += bf[((lane >> 2) + 8 * k) * 4 + (lane & 3)];
+            p[2 * 32 * 32 + lane] = b;
+        }
+    }
+}
+
 // dW[co][k] (OIHW, k < K) and db[co] from the per-workgroup partials, fixed order: 16 outputs x 16 partial slices per
 // workgroup, 4 loads in flight per lane, slices combined through LDS
 __global__ __launch_bounds__(256) void conv_first_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db, int nblocks, int K) {
@@ -584,8 +750,23 @@ static int launch_first_wgrad_t(const TG* g, const float* x, float* dw, float* d
     return 0;
 }
 
-int launch_conv_first_wgrad(const float* g, const float* x, float* dw, float* db, float* part, int N, int Cin, int H, int W, hipStream_t st) {
-    return launch_first_wgrad_t<float>(g, x, dw, db, part, N, Cin, H, W, st);
+// x3: the call runs under the three-piece product scheme (conv_fp32_algo 1): the packed-raw layer (Cin = 4) goes to the bf16-MFMA kernel
+int launch_conv_first_wgrad(const float* g, const float* x, float* dw, float* db, float* part, int N, int Cin, int H, int W, hipStream_t st, bool x3) {
+    const int tiles = ((W + FTW - 1) / FTW) * ((H + FTH - 1) / FTH) * N;
+    if (tiles <= 0) return 0;
+    if (!x3 || Cin != 4) return launch_first_wgrad_t<float>(g, x, dw, db, part, N, Cin, H, W, st);      // fp32-MFMA kernel
+    constexpr size_t lds_bytes = (size_t)(3 * FTH * FTW * 32 + 3 * 3 * 4 * (FTH + 2) * FXW) * sizeof(bf16_t);
+    auto kern = conv_first_wgrad_x3_kernel<4>;
+    static EldAttrOnce once;
+    { const int rc = once.ensure(kern, lds_bytes); if (rc) return rc; }
+    const int resident = 2 * eld_num_cus();                  // 77 KB of LDS per workgroup: two per CU; the persistent grid must not exceed what is co-resident
+    const int cap = resident < FW_BLOCKS ? resident : FW_BLOCKS;
+    const int grid = tiles < cap ? tiles : cap;
+    ELD_LAUNCH(kern, dim3(grid), dim3(256), lds_bytes, st, g, x, part, N, H, W);
+    ELD_LAUNCH_CHECK();
+    ELD_LAUNCH(conv_first_wgrad_reduce_kernel, dim3((2 * 32 * 32 + 32 + 15) / 16), dim3(256), 0, st, part, dw, db, grid, 9 * Cin);
+    ELD_LAUNCH_CHECK();
+    return 0;
 }
 int launch_conv_first_wgrad_bf16(const bf16_t* g, const float* x, float* dw, float* db, float* part, int N, int Cin, int H, int W, hipStream_t st) {
     const int tiles = ((W + FTW - 1) / FTW) * ((H + FTH - 1) / FTH) * N;

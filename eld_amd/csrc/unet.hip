@@ -507,7 +507,7 @@ int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd
         { float* t = cur; cur = oth; oth = t; }
         if (l == 0) {
             if (P.in_ch <= 4)
-                RC(launch_conv_first_wgrad(cur, fused.x ? fused.x : ws + P.x16, grd + P.L[ia].w_off, grd + P.L[ia].b_off, part, N, P.in_ch, H, W, st));
+                RC(launch_conv_first_wgrad(cur, fused.x ? fused.x : ws + P.x16, grd + P.L[ia].w_off, grd + P.L[ia].b_off, part, N, P.in_ch, H, W, st, g_algo == 1));
             else {
                 WG(gs(cur), S_X, -1);
                 RC(conv_wgrad(cur, C, ws + P.x16, 16, nullptr, 0, P.in_ch, grd + P.L[ia].w_off, grd + P.L[ia].b_off, part, N, H, W, st));

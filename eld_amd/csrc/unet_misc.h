@@ -33,7 +33,7 @@ int launch_adam(float* p, const float* g, float* m, float* v, size_t n, double l
 // first layer (conv_first.hip): NCHW input with Cin <= 4 -> NHWC 32 channels
 int launch_conv_first_fwd(const float* x, const float* w, const float* bias, float* out, int N, int Cin, int H, int W, int lrelu, hipStream_t st);
 size_t conv_first_wgrad_ws_floats();
-int launch_conv_first_wgrad(const float* g, const float* x, float* dw, float* db, float* part, int N, int Cin, int H, int W, hipStream_t st);
+int launch_conv_first_wgrad(const float* g, const float* x, float* dw, float* db, float* part, int N, int Cin, int H, int W, hipStream_t st, bool x3 = false);
 
 // bf16 activations (forward / inference path)
 int launch_maxpool_fwd_bf16(const bf16_t* in, bf16_t* out, int N, int Ho, int Wo, int C, hipStream_t st);
