@@ -18,6 +18,7 @@
 //     The count is deliberately the conservative one: it does not rely on loads and stores retiring in one common order (the epilogue's stores
 //     sit between two tiles' pieces in the queue) -- "at most A_IT operations outstanding" implies "at most A_IT loads outstanding" either way.
 #include <stdlib.h>
+#include <atomic>
 #include "conv.h"
 
 #define TW 32
@@ -307,10 +308,8 @@ int launch_bfs(ConvArgs a, hipStream_t st) {
 // Layers this kernel takes: bf16 3x3 with exactly 32 output channels (GEMM N), K = 32 or 64 input channels (one tensor, or the virtual concat of two
 // 32-channel tensors), a single output tensor, on a tile domain that gives every CU a tile; weights in conv_bfd's slab layout at BN = 32.
 int debug_kernel_mask(int set) {
-    static int mask = [] { const char* e = getenv("ELD_DEBUG_KERNEL_MASK"); return e ? atoi(e) : 0; }();      // (env: same-box A/B runs of bench.py)
-    const int prev = mask;
-    if (set >= 0) mask = set;
-    return prev;
+    static std::atomic<int> mask([] { const char* e = getenv("ELD_DEBUG_KERNEL_MASK"); return e ? atoi(e) : 0; }());      // (env: same-box A/B runs of bench.py)
+    return set >= 0 ? mask.exchange(set) : mask.load();
 }
 extern "C" int eld_debug_kernel_mask(int mask) { return debug_kernel_mask(mask < 0 ? 0 : mask); }
 

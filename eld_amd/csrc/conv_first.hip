@@ -263,8 +263,7 @@ static int launch_first_t(const float* x, const float* w, const float* bias, TO*
     const int tiles = ((W + FTW - 1) / FTW) * ((H + FTH - 1) / FTH) * N;
     if (tiles <= 0) return 0;
     const int grid = tiles < 2048 ? tiles : 2048;
-    static int mma = -1;                          // ELD_FIRST_MMA=0: the K = 36 kernel on the fp32 MFMA for every Cin
-    if (mma < 0) { const char* e = getenv("ELD_FIRST_MMA"); mma = e ? atoi(e) : 1; }
+    static const int mma = [] { const char* e = getenv("ELD_FIRST_MMA"); return e ? atoi(e) : 1; }();      // ELD_FIRST_MMA=0: the K = 36 kernel on the fp32 MFMA for every Cin
     if (Cin == 4 && mma) {                        // packed Bayer raw: the bf16-MFMA kernel (fp32 output: exact three-piece products; bf16 output: two pieces)
         ELD_LAUNCH((conv_first_fwd_mma_kernel<TO, sizeof(TO) == 4 ? 3 : 2>), dim3(grid), dim3(256), 0, st, x, w, bias, out, N, H, W, lrelu);
         ELD_LAUNCH_CHECK();

@@ -26,6 +26,7 @@
 // MFMA-bound and a plain stage -> barrier -> compute -> barrier loop with >= 2 workgroups per CU
 // (LDS <= 80 KB each) keeps the matrix pipe busy while the other workgroup stages.
 #include <stdlib.h>
+#include <atomic>
 #include "conv.h"
 
 #define ELD_FP32_CONV_DEFAULT 1
@@ -416,16 +417,16 @@ static int launch_dt(const ConvArgs& a, int mode, hipStream_t st) {
 }
 
 int conv_fp32_algo(int set) {
-    static int algo = -1;
-    if (algo < 0) {
+    // the process default: initialised once (thread-safe magic static), then an atomic that concurrent callers may read and set
+    static std::atomic<int> algo([] {
         const char* e = getenv("ELD_FP32_CONV");
-        algo = (e && (e[0] == 'm' || e[0] == '0')) ? 0 : ELD_FP32_CONV_DEFAULT;
-        if (e && (e[0] == 'x' || e[0] == '1')) algo = 1;
-        if (e && (e[0] == 'h' || e[0] == '2')) algo = 2;
-    }
-    const int prev = algo;
-    if (set >= 0 && set <= 2) algo = set;
-    return prev;
+        int a = (e && (e[0] == 'm' || e[0] == '0')) ? 0 : ELD_FP32_CONV_DEFAULT;
+        if (e && (e[0] == 'x' || e[0] == '1')) a = 1;
+        if (e && (e[0] == 'h' || e[0] == '2')) a = 2;
+        return a;
+    }());
+    if (set >= 0 && set <= 2) return algo.exchange(set);
+    return algo.load();
 }
 
 // ---- tile shape of the 3x3 kernels whose pixel slots are mapped per lane (conv_x3d_kernel, conv_bfd_kernel): see conv.h ----------------------
@@ -458,26 +459,37 @@ void conv_tile_shape(int N, int H, int W, int TH, bool pooled, int& th, int& tw)
     th = TH; tw = 32;
     // ELD_CONV_TILES (A/B runs of the tile choice; virtual rows stay): f = TH x 32 everywhere, p = widths 8/16/32/64 only, m<k> = widths >= k,
     // q<k> = widths that are multiples of k, t = fewest tiles (no conflict term)
-    static int mode = -1, marg = 0;
-    if (mode < 0) {
+    // (function-local statics with initialisers: C++11 guarantees one thread-safe initialisation -- the entry points may be called from several host threads)
+    struct TileMode { int mode, marg; };
+    static const TileMode tm = [] {
+        TileMode t = {0, 0};
         const char* e = getenv("ELD_CONV_TILES");
-        mode = 0;
-        if (e && e[0] == 'f') mode = 1;
-        if (e && e[0] == 'p') mode = 2;
-        if (e && e[0] == 'm') { mode = 3; marg = atoi(e + 1); }
-        if (e && e[0] == 'q') { mode = 4; marg = atoi(e + 1) > 0 ? atoi(e + 1) : 1; }
-        if (e && e[0] == 't') mode = 5;
-    }
+        if (e && e[0] == 'f') t.mode = 1;
+        if (e && e[0] == 'p') t.mode = 2;
+        if (e && e[0] == 'm') { t.mode = 3; t.marg = atoi(e + 1); }
+        if (e && e[0] == 'q') { t.mode = 4; t.marg = atoi(e + 1) > 0 ? atoi(e + 1) : 1; }
+        if (e && e[0] == 't') t.mode = 5;
+        return t;
+    }();
+    const int mode = tm.mode, marg = tm.marg;
     if (pooled || mode == 1 || N <= 0 || H <= 0 || W <= 0 || (TH != 8 && TH != 16 && TH != 32)) return;
-    static float cf[3][65];                                  // conflict factor per width, per TH in {8, 16, 32}; filled once (shape-independent)
-    static bool cf_ready[3] = {false, false, false};
     const int ti = TH == 8 ? 0 : (TH == 16 ? 1 : 2);
     const int slots = TH * 32, halo = (TH + 2) * 34;
     auto height = [&](int w) { int h = slots / w; while (h > 1 && (h + 2) * (w + 2) > halo) --h; return h > 128 ? 128 : h; };
-    if (!cf_ready[ti]) {
-        for (int w = 8; w <= 64; ++w) cf[ti][w] = tile_conflict_factor(height(w), w, TH);
-        cf_ready[ti] = true;
-    }
+    struct ConflictTable { float v[3][65]; };                // conflict factor per width, per TH in {8, 16, 32}; filled once (shape-independent)
+    static const ConflictTable cft = [] {
+        ConflictTable c = {};
+        for (int k = 0; k < 3; ++k) {
+            const int THk = 8 << k, sl = THk * 32, hl = (THk + 2) * 34;
+            for (int w = 8; w <= 64; ++w) {
+                int h = sl / w;
+                while (h > 1 && (h + 2) * (w + 2) > hl) --h;
+                c.v[k][w] = tile_conflict_factor(h > 128 ? 128 : h, w, THk);
+            }
+        }
+        return c;
+    }();
+    const float (&cf)[3][65] = cft.v;
     double best = (double)tile_count(N, H, W, th, tw);       // the standard shape is conflict-free
     for (int w = 8; w <= 64; ++w) {                          // narrower than 8 pixels: a halo row is no longer a few whole 64-byte DMA units
         if (mode == 2 && (w & (w - 1))) continue;
@@ -499,7 +511,7 @@ int launch_conv(const ConvArgs& a_in, int mode, hipStream_t st) {
     ConvArgs a = a_in;
     a.dbg = 0;
 #if ELD_DEV_TOOLS
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("ELD_CONV_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
+    { static const int dbg = [] { const char* e = getenv("ELD_CONV_DBG"); return e ? atoi(e) : 0; }(); a.dbg = dbg; }
 #endif
     const int Cin = a.C0 + a.C1;
     const int ck = a.dtype == DT_BF16 ? 32 : 16;

@@ -895,8 +895,7 @@ __global__ __launch_bounds__(512, 2) void wgrad8d_kernel(const WgradArgs a) {
 // with its 256-pixel register-staged tiles).  The smaller blocks stay on wgrad8_kernel: they are the 32 / 64-channel layers, at the HBM roofline
 // already (conv1_2: 3.5 GB per launch in 0.65 ms = 5.4 TB/s); their DMA variants (16 x 16 tiles) measured 3 ... 17 % slower.
 static int wgrad8_dma() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("ELD_WGRAD_DMA"); on = e ? (atoi(e) != 0) : 1; }
+    static const int on = [] { const char* e = getenv("ELD_WGRAD_DMA"); return e ? (int)(atoi(e) != 0) : 1; }();
     return on && !(debug_kernel_mask(-1) & 16);      // test hook (eld_debug_kernel_mask bit 4): back on the register-staged kernel
 }
 bool wgrad8_shape(int CA, int CBp, int& COB, int& JBK, int& TH, int& TWo, bool bf16) {
@@ -1018,8 +1017,7 @@ int launch_wgrad(const WgradArgs& a, int mode, hipStream_t st) {
             const int rc = launch_wgrad8(a, st);
             if (rc != ELD_ENOTSUP) return rc;
         }
-        static int mma = -1;                  // ELD_WGRAD_BF16_MMA=0 falls back to fp32-MFMA accumulation of the widened operands
-        if (mma < 0) { const char* e = getenv("ELD_WGRAD_BF16_MMA"); mma = e ? atoi(e) : 1; }
+        static const int mma = [] { const char* e = getenv("ELD_WGRAD_BF16_MMA"); return e ? atoi(e) : 1; }();      // ELD_WGRAD_BF16_MMA=0 falls back to fp32-MFMA accumulation of the widened operands
         if (mma) {
             if (mode == CONV_3X3) return c64 ? launch_w<bf16_t, CONV_3X3, 2, 4, ALG_BFM>(a, st) : launch_w<bf16_t, CONV_3X3, 1, 4, ALG_BFM>(a, st);
             if (mode == CONV_GATHER2X2) return c64 ? launch_w<bf16_t, CONV_GATHER2X2, 2, 2, ALG_BFM>(a, st) : launch_w<bf16_t, CONV_GATHER2X2, 1, 2, ALG_BFM>(a, st);

@@ -953,8 +953,7 @@ int launch_x3d(ConvArgs a, hipStream_t st) {
     // split K where the smallest tiles still leave most of the chip idle (single patches: conv5_x of a 512 x 512 input is 32 workgroups) and the
     // caller provided room for the partial sums
     a.ksplit = 1;
-    static int no_splitk = -1;                                   // dev switch (ELD_NO_SPLITK=1): small problems without the K split
-    if (no_splitk < 0) { const char* e = getenv("ELD_NO_SPLITK"); no_splitk = e ? atoi(e) : 0; }
+    static const int no_splitk = [] { const char* e = getenv("ELD_NO_SPLITK"); return e ? atoi(e) : 0; }();      // dev switch (ELD_NO_SPLITK=1): small problems without the K split
     if (WAVES == 4 && a.kpart != nullptr && !no_splitk) {
         const int nch = (a.C0 + a.C1) / 16;
         const size_t plane = (size_t)a.N * a.H * a.W * a.Nout;
@@ -1021,8 +1020,7 @@ int x3_slab_bn(int Nout, int N, int H, int W, int* waves) {
     // conv_x3_kernel<32, 4> (3087 vs 2917 us per launch, same box): one 8-wave workgroup per CU loses more to its barriers than the two 4-wave
     // workgroups of the register-staged kernel lose to the weight cut.  Off by default.
     if (Nout == 32) {
-        static int on = -1;
-        if (on < 0) { const char* e = getenv("ELD_X3D_32"); on = e ? atoi(e) : 0; }
+        static const int on = [] { const char* e = getenv("ELD_X3D_32"); return e ? atoi(e) : 0; }();
         return (on && conv_tile_count(N, H, W, 32, false) >= 2 * eld_num_cus()) ? 32 : 0;
     }
     if (Nout % 64) return 0;

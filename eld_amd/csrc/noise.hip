@@ -603,7 +603,7 @@ extern "C" int eld_noise_forward_strided(const void* in, int in_dtype, size_t in
     a.key.k0 = (uint32_t)seed; a.key.k1 = (uint32_t)(seed >> 32);
     a.dbg = 0;
 #if ELD_DEV_TOOLS
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("ELD_NOISE_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = (uint32_t)dbg; }
+    { static const int dbg = [] { const char* e = getenv("ELD_NOISE_DBG"); return e ? atoi(e) : 0; }(); a.dbg = (uint32_t)dbg; }
 #endif
 
     const size_t in_align = (in_dtype == ELD_IN_U16) ? 8 : 16;

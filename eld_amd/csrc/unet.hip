@@ -700,11 +700,14 @@ extern "C" int eld_unet_backward_ex(const float* dout, const float* params, floa
     // dout == NULL is only meaningful right after eld_unet_forward_loss_ex on this workspace with the same problem: anything else would hand back
     // stale head gradients without a sign of trouble
     FusedFwd fused;
-    if (!dout) {
+    {
         HeadState hs = {N, H, W, in_ch, out_ch, precision, nullptr};
-        if (!head_state_is(ws, hs)) return ELD_EINVAL;
-        fused.packed = true;
-        fused.x = in_ch <= 4 ? hs.x : nullptr;      // (more input planes: the forward converted x to NHWC16 in the workspace)
+        const bool after_fused = head_state_is(ws, hs);
+        if (!dout && !after_fused) return ELD_EINVAL;
+        // An explicit dout after the fused-loss forward is a valid call order too (the head is then recomputed from dout): that forward left the
+        // input with the caller instead of copying it into the workspace, so the first layer's weight gradient must read it there as well.
+        if (after_fused) fused.x = in_ch <= 4 ? hs.x : nullptr;      // (more input planes: the forward converted x to NHWC16 in the workspace)
+        fused.packed = !dout;                                         // with an explicit dout the backward packs its own weights (params may have changed)
     }
     for (int k = 0; k < n_buckets; ++k)
         if (!bucket_event[k] || bucket_start[k] < 0 || (k > 0 && bucket_start[k] <= bucket_start[k - 1]) || (size_t)bucket_start[k] >= P.nparams) return ELD_EINVAL;

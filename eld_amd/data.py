@@ -166,8 +166,9 @@ class ELDTrainDataset(tdata.Dataset):
         if src is not tgt and not (getattr(src, 'db_path', None) is not None and getattr(src, 'db_path', None) == getattr(tgt, 'db_path', object())
                                    and getattr(src, 'length', None) == getattr(tgt, 'length', object())):
             return False
-        try:                                                 # SynDataset reads dataset[i % (size or len(dataset))]: the index must never wrap below len(target)
-            return (d.size is None or d.size >= len(tgt)) and len(src) >= len(tgt)
+        try:                                                 # SynDataset reads dataset[i % (size or len(dataset))]: the index must never wrap below len(target),
+            n_in = len(self.input_datasets)                  # and this dataset's own `size` must not run the pair index i // N past the target database
+            return (d.size is None or d.size >= len(tgt)) and len(src) >= len(tgt) and (self.size is None or self.size <= len(tgt) * n_in)
         except TypeError:
             return False
 
@@ -175,6 +176,11 @@ class ELDTrainDataset(tdata.Dataset):
         N = len(self.input_datasets)
         inp = self.input_datasets[i % N][i // N]
         same = self._shared[i % N] and isinstance(inp, Deferred) and inp.isp is None and inp.index == i // N
+        if self._shared[i % N] and isinstance(inp, Deferred) and inp.isp is None and not same:
+            # the clean patch was declared to BE the target for this input dataset (no 'clean' key travels): a sample whose SynDataset index differs
+            # from its pair index would be degraded from the wrong patch without a sign of trouble
+            raise IndexError('ELDTrainDataset: sample %d pairs target %d with SynDataset patch %d although both read the same database '
+                             '(index wrap-around): give the SynDataset its own dataset object' % (i, i // N, inp.index))
         target = inp.clean if same else self.target_dataset[i // N]
         bits = 0
         if self.augment:                                     # sid_dataset.py:344-352: flip H, flip W, transpose

@@ -33,12 +33,13 @@ class _Workspace:
         self.gen = {}
         self.algo = {}       # fp32 product scheme the forward that filled the buffer ran with
         self.fused_head = {} # True: the buffer was filled by eld_unet_forward_loss_ex (the only forward a dout = None backward may follow)
+        self.x_ref = {}      # the fused-loss forward's (converted) input: the library reads it again in the backward (include/eld_amd.h), so it must outlive this call
 
     def get(self, key, nbytes, device):
         b = self.bufs.get(key)
         if b is None or b.numel() < nbytes or b.device != device:
             if len(self.bufs) > 4:          # shapes changed (e.g. chop tiles): drop old scratch
-                self.bufs.clear(); self.gen.clear(); self.algo.clear(); self.fused_head.clear()
+                self.bufs.clear(); self.gen.clear(); self.algo.clear(); self.fused_head.clear(); self.x_ref.clear()
             b = torch.empty(nbytes, dtype=torch.uint8, device=device)
             self.bufs[key] = b
             self.gen[key] = 0
@@ -140,6 +141,7 @@ class UNetSeeInDark(nn.Module):
         algo = self.fp32_products if self.fp32_products is not None else L.lib().eld_conv_fp32_algo(-1)
         self._ws.algo[key] = algo
         self._ws.fused_head[key] = False
+        self._ws.x_ref.pop(key, None)
         L.check(L.lib().eld_unet_forward_ex(L.dptr(x), L.dptr(self.flat_params), L.dptr(out), L.dptr(ws), ws.numel(),
                                             N, H, W, self.in_channels, self.out_channels, 1 if bf16 else 0, algo, L.cur_stream()), 'eld_unet_forward_ex')
         return out, key, self._ws.gen[key]
@@ -166,6 +168,7 @@ class UNetSeeInDark(nn.Module):
         algo = self.fp32_products if self.fp32_products is not None else L.lib().eld_conv_fp32_algo(-1)
         self._ws.algo[key] = algo
         self._ws.fused_head[key] = True
+        self._ws.x_ref[key] = x          # x.contiguous().float() may be a temporary: keep it until the next forward of this shape replaces it
         L.check(L.lib().eld_unet_forward_loss_ex(L.dptr(x), L.dptr(self.flat_params), L.dptr(target), L.dptr(out), L.dptr(loss_buf), L.dptr(ws), ws.numel(),
                                                  N, H, W, self.in_channels, self.out_channels, 1 if bf16 else 0, algo, 1 if mse else 0, float(grad_scale),
                                                  L.cur_stream()), 'eld_unet_forward_loss_ex')

@@ -188,8 +188,10 @@ int eld_unet_backward_buckets(const float* dout, const float* params, float* gra
  * head's dW / db and runs the rest of the backward.  grad_scale multiplies dLoss/dout (1 for a plain mean loss).
  * The pair shares more than the head: the forward packs the weights for both directions in one launch (the backward differentiates at the
  * parameters the forward ran with), and the backward's first-layer weight gradient reads `x` where the forward read it -- no copy of the input is
- * kept in the workspace.  `x` (and `params`) must therefore stay valid and unchanged until the matching eld_unet_backward_ex(dout = NULL) has
- * been enqueued on the same stream. */
+ * kept in the workspace.  `x` (and `params`) must therefore stay valid and unchanged until the backward that follows this forward on the
+ * workspace has been enqueued on the same stream -- the matching eld_unet_backward_ex(dout = NULL), or a backward with an explicit dout
+ * (allowed: the head is then recomputed from dout, the weights are packed again, and the first layer's weight gradient still reads `x`
+ * from the caller). */
 int eld_unet_forward_loss_ex(const float* x, const float* params, const float* target, float* out, float* loss, void* ws, size_t ws_bytes,
                              int N, int H, int W, int in_ch, int out_ch, int precision, int fp32_algo, int loss_kind, float grad_scale, void* stream);
 /* The same two calls with everything per call: precision 0 = fp32 / 1 = bf16 activations; fp32_algo names the fp32 product

@@ -212,3 +212,19 @@ def test_unmodified_train_syn_reaches_the_hip_model_with_all_plugins(tmp_path):
     else:
         assert 'on-device synthesis from SID_Sony_Raw.db' in out, out[-3000:]
         assert 'there is no CPU fallback' in out, out[-3000:]
+
+
+def test_size_wraparound_keeps_the_clean_patch_with_the_sample():
+    """ELDTrainDataset(size > len(target) * N) runs the pair index past the database, where SynDataset's own index wraps
+    (sid_dataset.py:259-264) while the target's does not (ArrayDB wraps like the in-memory LMDB stand-in): the clean patch is then NOT the
+    target, so the sample must carry its own 'clean' key (the decision is per input dataset: every sample of the run carries it)."""
+    from eld_amd.data import ELDTrainDataset, SynDataset
+    nm = quiet_model('Pg')
+    clean = ArrayDB(n=4)
+    ds = ELDTrainDataset(clean, [SynDataset(clean, noise_maker=nm)], size=6, augment=False)
+    assert ds._shared == [False]
+    for i in range(6):
+        d = ds[i]
+        assert 'clean' in d and np.array_equal(d['clean'].view(np.uint16), clean[i % 4])
+    ds2 = ELDTrainDataset(clean, [SynDataset(clean, noise_maker=nm)], size=4, augment=False)
+    assert ds2._shared == [True] and 'clean' not in ds2[3]

@@ -648,6 +648,32 @@ def test_fused_head_equals_the_three_kernel_path(lib, prec, mse):
     assert torch.equal(g1, g0)
 
 
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+def test_explicit_dout_backward_after_the_fused_forward(lib, prec):
+    """eld_unet_forward_loss_ex leaves the input with the caller (no copy in the workspace); a backward with an EXPLICIT dout that follows
+    it on the same workspace is a valid call order (include/eld_amd.h) and must read the first layer's operand from the caller's x too -- same
+    gradients, bit for bit, as the plain forward + backward pair."""
+    from eld_amd.unet import UNetSeeInDark
+    torch.manual_seed(4)
+    net = UNetSeeInDark(4, 4).cuda()
+    bf16 = prec == 'bf16'
+    g = torch.Generator(device='cuda').manual_seed(9)
+    shape = (2, 4, 96, 208)
+    x = torch.rand(*shape, device='cuda', generator=g)
+    t = torch.rand(*shape, device='cuda', generator=g)
+    dout = torch.randn(*shape, device='cuda', generator=g) / x.numel()
+    _, key, _ = net._engine_forward(x, save=True, bf16=bf16)
+    g0 = net._engine_backward(dout, key, shape).clone()
+    # poison the workspace copy a plain forward leaves behind: the fused forward must not depend on it
+    junk = torch.rand(*shape, device='cuda', generator=g)
+    net._engine_forward(junk, save=True, bf16=bf16)
+    lb = torch.zeros(1, device='cuda')
+    _, key, _ = net._engine_forward_loss(x, t, lb, bf16=bf16)
+    g1 = net._engine_backward(dout, key, shape).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(g1, g0), int((g1 != g0).sum())
+
+
 def test_forward_loss_argument_checks(lib):
     """eld_unet_forward_loss_ex rejects what it cannot run (include/eld_amd.h): a missing target / loss pointer, an unknown loss kind, a workspace
     that is too small -- error codes, no launch."""

@@ -4,7 +4,11 @@ images, tiny deep levels -- through the whole U-Net step.
   bf16: the specialised kernels (mask 8) against the generic conv_igemm_kernel<bf16> (mask 15, untouched by the strip tiling): output and every gradient
         bit for bit; wgrad8d vs wgrad8 (mask 16) to 1e-4.
   fp32: the default three-piece scheme against the float64 oracle (oracle/unet_ref.py on the GPU's fp64 vector units): output to 1e-5, every gradient to
-        5e-3 relative L2 (sign flips of near-zero LeakyReLU inputs under float32 rounding dominate at the tiny deep levels of small inputs)."""
+        5e-3 relative L2 (sign flips of near-zero LeakyReLU inputs under float32 rounding dominate at the tiny deep levels of small inputs); round 5: on
+        levels with >= 10^4 pixels also max|err| <= 2e-4 max|ref| or <= 8x the float32 oracle's own distance from float64 (tests/test_parity_full_gpu.py's
+        relative criterion; hard limit 2e-3: a wrong seam row of one tile row would be off by percents).
+  both: the FUSED training pair (eld_unet_forward_loss_ex + eld_unet_backward_ex(dout = NULL): PACK_BOTH, first-layer weight gradient from the caller's
+        x, fused head) against the plain forward / eld_l1_loss / backward pair of the same precision -- output and every gradient bit for bit."""
 import os, sys, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,6 +22,33 @@ def step(net, x, t):
     out = net(x)
     torch.nn.functional.l1_loss(out, t).backward()
     return out.detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+
+def fused_vs_plain(net, x, t, bf16):
+    """(mismatch messages) of the fused training pair against the plain pair on the same input; both through the C ABI, no autograd."""
+    from eld_amd import _lib as L
+    shape = tuple(x.shape)
+    out0, key, _ = net._engine_forward(x, save=True, bf16=bf16)
+    out0 = out0.clone()
+    dout = torch.empty_like(out0)
+    loss0 = torch.zeros(1, device=x.device)
+    ws = torch.empty(lib.eld_l1_workspace_bytes(), dtype=torch.uint8, device=x.device)
+    L.check(lib.eld_l1_loss(L.dptr(out0), L.dptr(t), L.dptr(dout), L.dptr(loss0), L.dptr(ws), out0.numel(), 1.0, L.cur_stream()), 'eld_l1_loss')
+    g0 = net._engine_backward(dout, key, shape).clone()
+    loss1 = torch.zeros(1, device=x.device)
+    out1, key, _ = net._engine_forward_loss(x, t, loss1, bf16=bf16)
+    g1 = net._engine_backward(None, key, shape).clone()
+    # an explicit dout after the fused forward is a valid call order too (ADVICE r4): the first layer's weight gradient must still find x
+    out2, key, _ = net._engine_forward_loss(x, t, loss1, bf16=bf16)
+    g2 = net._engine_backward(dout, key, shape).clone()
+    tag = 'bf16' if bf16 else 'fp32'
+    msg = []
+    if not torch.equal(out1, out0): msg.append(tag + ' fused out')
+    if not torch.equal(g1, g0): msg.append(tag + ' fused grads (%d elements differ)' % int((g1 != g0).sum()))
+    if not torch.equal(g2, g0): msg.append(tag + ' fused forward + explicit dout (%d elements differ)' % int((g2 != g0).sum()))
+    if abs(float(loss1) - float(loss0)) > 2e-6 * abs(float(loss0)): msg.append(tag + ' fused loss')
+    return msg
+
+LEVEL = {'conv1': 0, 'conv2': 1, 'conv3': 2, 'conv4': 3, 'conv5': 4, 'upv6': 3, 'conv6': 3, 'upv7': 2, 'conv7': 2, 'upv8': 1, 'conv8': 1, 'upv9': 0, 'conv9': 0, 'conv10': 0}
 
 def main(n_cases=24, seed=0, big=1):
     rnd = random.Random(seed)
@@ -44,6 +75,7 @@ def main(n_cases=24, seed=0, big=1):
             if not torch.equal(res[8][1][n_], res[15][1][n_]): msg.append('bf16 grad ' + n_)
         prev = lib.eld_debug_kernel_mask(0)
         r0 = step(net, x, t)
+        msg += fused_vs_plain(net, x, t, True)
         lib.eld_debug_kernel_mask(prev)
         for n_ in r0[1]:
             a, b = r0[1][n_].double(), res[16][1][n_].double()
@@ -51,8 +83,10 @@ def main(n_cases=24, seed=0, big=1):
         # ---- fp32: default three-piece scheme vs the float64 oracle (stock torch ops on the GPU's fp64 units: checker only)
         net.train_precision = net.inference_precision = 'fp32'
         r1 = step(net, x, t)
+        msg += fused_vs_plain(net, x, t, False)
         sd64 = {k: v.detach().double() for k, v in net.state_dict().items()}
         o64, _, g64 = U.loss_and_grads(sd64, x.double(), t.double())
+        _, _, g32 = U.loss_and_grads({k: v.detach().clone() for k, v in net.state_dict().items()}, x, t)      # the float32 oracle's own distance from float64
         if float((r1[0].double() - o64).abs().max()) > 1e-5 * (1 + float(o64.abs().max())): msg.append('fp32 out')
         for n_ in r1[1]:
             a, b = r1[1][n_].double(), g64[n_]
@@ -60,6 +94,13 @@ def main(n_cases=24, seed=0, big=1):
             # of five -- at the tiny deep levels of small inputs that alone is 1e-3 of max|ref| in any float32 implementation (measured: conv5_2 at
             # 2 x 112 x 368, identical in the round-3 library) -- while a wrong seam row or tile is off by tens of percent
             if float((a - b).norm()) > 5e-3 * float(b.norm()) + 1e-30: msg.append('fp32 grad %s %.2e' % (n_, float((a - b).norm()) / float(b.norm())))
+            lev = LEVEL[n_.split('_')[0].split('.')[0]]
+            if N * (H >> lev) * (W >> lev) >= 10000:            # a level large enough that single LeakyReLU sign flips do not dominate
+                err, rmax = float((a - b).abs().max()), float(b.abs().max())
+                own = float((g32[n_].double() - b).abs().max())
+                if err > 2e-4 * rmax and err > 8.0 * own:
+                    if err > 2e-3 * rmax: msg.append('fp32 grad %s max-abs %.2e of max|ref|' % (n_, err / rmax))
+                    else: print('   note: %s max-abs %.2e of max|ref| (float32 oracle: %.2e)' % (n_, err / rmax, own / rmax), flush=True)
         torch.cuda.synchronize()
         print('case %2d  N=%d H=%d W=%d  %s' % (case, N, H, W, 'ok' if not msg else 'MISMATCH: ' + '; '.join(msg[:6])), flush=True)
         bad += bool(msg)
