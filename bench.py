@@ -48,12 +48,25 @@ def make_opt(local_rank, precision='fp32'):
 
 
 def load_traffic():
-    """HBM bytes from the committed rocprofv3 PMC passes (profiles/traffic.json, tools/traffic_from_pmc.py); None if absent."""
+    """HBM bytes from the committed rocprofv3 PMC passes (profiles/traffic.json, tools/traffic_from_pmc.py); None if absent.
+    The figures belong to ONE kernel set: the file records the source hash of the library that ran the PMC passes (library_src_hash[_bf16]) and a
+    precision's bytes are dropped (traffic = null on the line) when the loaded library was built from other sources -- a stale constant cannot
+    ride a new kernel set onto the driver line."""
     try:
         with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
-            return json.load(f)
+            t = json.load(f)
     except Exception:
         return None
+    from eld_amd import _lib as L
+    have = L.build_src_hash()
+    t['_stale'] = {}
+    for key, hk in (('unet_conv_bytes_per_pass', 'library_src_hash'), ('unet_conv_bytes_per_pass_bf16', 'library_src_hash_bf16')):
+        if t.get(hk) != have:
+            t['_stale'][key] = 'profiles/traffic.json was measured on library src=%s, this run loaded src=%s: not reported' % (t.get(hk), have)
+            t.pop(key, None)
+            if key == 'unet_conv_bytes_per_pass':
+                t.pop('sampler_bytes_per_pixel', None)
+    return t
 
 
 def timed_events(fn, reps):
@@ -104,8 +117,9 @@ def unet_roofline(model, B, Hh, Ww, precision, dev, traffic):
         kern, note = 'conv_igemm_kernel fwd/bwd-data + wgrad_kernel', 'dense fp32 MFMA peak'
     return {'bound': 'mfma', 'kernel': 'U-Net convolution launches of one step (%s), timed as eld_unet_forward + eld_unet_backward' % kern,
             'achieved': round(ach, 2), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4), 'peak_note': note,
-            'traffic': tr, 'traffic_source': ('profiles/traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, scaled to the '
-                                              'frames of this run; not re-measured in this run)' if tr is not None else None),
+            'traffic': tr, 'traffic_source': ('profiles/traffic.json (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on a library with '
+                                              'the same source hash, scaled to the frames of this run; not re-measured in this run)' if tr is not None else
+                                              ((traffic or {}).get('_stale', {}).get(key))),
             'fwd_ms': round(t_f, 3), 'bwd_ms': round(t_b, 3),
             'fwd_tflops': round(FLOP_FWD_PER_PIX * B * 4.0 * Hh * Ww / (t_f * 1e-3) / 1e12, 2)}, peak, x3
 
@@ -175,11 +189,12 @@ def cpu_baseline(h, w, seed=2018):
             'os_cpu_count': os.cpu_count()}
 
 
-def eval_sweep_leg(dev, precision, frames=3):
+def eval_sweep_leg(dev, precision, frames=3, batch=8):
     """BASELINE.json configs[4] on the driver line: one setting of the reference's evaluation sweep (test_ELD.py:18-52 -> ELDModel.eval,
-    ELD_model.py:203-307) at sensor resolution, on the device: SonyA7S2 packed frame, ISO 1600, ratio 100 -- noise synthesis with the camera's
-    tables -> U-Net inference -> IlluminanceCorrect -> tensor2im + PSNR + SSIM (csrc/eval.hip), HIP events per stage.  tools/eval_sweep.py runs
-    all 4 cameras x 3 ISOs x 2 ratios (profiles/r04_eval_sweep_*.json)."""
+    ELD_model.py:203-307) at sensor resolution, on the device: SonyA7S2 packed frames, ISO 1600, ratio 100 -- noise synthesis with the camera's
+    tables -> U-Net inference -> IlluminanceCorrect -> tensor2im + PSNR + SSIM (csrc/eval.hip), HIP events per stage, `batch` frames per launch
+    (round 5: one frame per launch left the deep U-Net levels with too few tiles; tests/test_eval_sweep_gpu.py pins the batched chain to single
+    frames bit for bit).  tools/eval_sweep.py runs all 4 cameras x 3 ISOs x 2 ratios (profiles/r05_eval_sweep_*.json)."""
     import importlib.util
     import eld_amd
     from eld_amd import _lib as L
@@ -191,6 +206,7 @@ def eval_sweep_leg(dev, precision, frames=3):
     spec.loader.exec_module(es)
     cam, iso, ratio = 'SonyA7S2', 1600, 100
     H, W = es.CAMERAS[cam]
+    B = es.frames_per_launch(eld_amd.load_library(), H, W, batch, budget_bytes=64e9)
     torch.manual_seed(2018)
     net = UNetSeeInDark(4, 4).to(dev)
     net.inference_precision = precision
@@ -200,11 +216,11 @@ def eval_sweep_leg(dev, precision, frames=3):
     tables = load_camera_params(cam)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(frames + 1)]
     q = None
-    for f in range(frames + 1):                               # frame 0 warms up (workspace allocation)
-        clean = (torch.floor(65535.0 * torch.rand(1, 4, H, W, device=dev, generator=g) ** 2.2) / 65535.0).contiguous()
-        p = es.params_for(tables, iso, ratio, rng)
+    for f in range(frames + 1):                               # launch 0 warms up (workspace allocation)
+        clean = (torch.floor(65535.0 * torch.rand(B, 4, H, W, device=dev, generator=g) ** 2.2) / 65535.0).contiguous()
+        ps = [es.params_for(tables, iso, ratio, rng) for _ in range(B)]
         ev[f][0].record()
-        noisy = sample_noise(clean, [p], flags, 2018, [f])
+        noisy = sample_noise(clean, ps, flags, 2018, [16 * f + b for b in range(B)])
         ev[f][1].record()
         with torch.no_grad():
             out = net(noisy)
@@ -214,17 +230,20 @@ def eval_sweep_leg(dev, precision, frames=3):
         q = quality_assess_frames(out, clean)
         ev[f][4].record()
     torch.cuda.synchronize()
-    st = [min(ev[f][i].elapsed_time(ev[f][i + 1]) for f in range(1, frames + 1)) for i in range(4)]
+    st = [min(ev[f][i].elapsed_time(ev[f][i + 1]) for f in range(1, frames + 1)) for i in range(4)]      # ms per launch of B frames
     tot = min(ev[f][0].elapsed_time(ev[f][4]) for f in range(1, frames + 1))
-    npx = 4.0 * H * W
+    npx = 4.0 * H * W * B
     # the two evaluation kernels are single passes over the frames: IlluminanceCorrect reads predict + source for the two dot products, then
     # reads predict and writes the output (16 B per element); the quality kernel reads both images once (8 B per element)
     gb_corr, gb_q = 16.0 * npx / (st[2] * 1e-3) / 1e9, 8.0 * npx / (st[3] * 1e-3) / 1e9
-    psnr, ssim = q[0].tolist()
-    return {'value': round(npx / (tot * 1e-3) / 1e6, 1), 'unit': 'raw MPix/s', 'ms_per_frame': round(tot, 3), 'frames': frames, 'dtype': 'f32' if precision == 'fp32' else 'bf16',
-            'config': {'workload': 'BASELINE.json configs[4], one setting: %s packed %dx%d, ISO %d, ratio x%d, synthetic frame; synth (PGRU) -> U-Net inference -> '
-                                   'IlluminanceCorrect -> tensor2im + PSNR + SSIM, all on the device' % (cam, H, W, iso, ratio)},
-            'stage_ms': {'sampler': round(st[0], 4), 'unet_inference': round(st[1], 3), 'illuminance_correct': round(st[2], 4), 'quality_assess': round(st[3], 4)},
+    psnr, ssim = q.mean(dim=0).tolist()
+    net.release_workspaces()
+    return {'value': round(npx / (tot * 1e-3) / 1e6, 1), 'unit': 'raw MPix/s', 'ms_per_frame': round(tot / B, 3), 'frames_per_launch': B, 'launches': frames,
+            'dtype': 'f32' if precision == 'fp32' else 'bf16',
+            'config': {'workload': 'BASELINE.json configs[4], one setting: %s packed %dx%d, ISO %d, ratio x%d, %d synthetic frames per launch; synth (PGRU) -> U-Net '
+                                   'inference -> IlluminanceCorrect -> tensor2im + PSNR + SSIM, all on the device' % (cam, H, W, iso, ratio, B)},
+            'stage_ms_per_frame': {'sampler': round(st[0] / B, 4), 'unet_inference': round(st[1] / B, 3), 'illuminance_correct': round(st[2] / B, 4),
+                                   'quality_assess': round(st[3] / B, 4)},
             'unet_inference_tflops': round(FLOP_FWD_PER_PIX * npx / (st[1] * 1e-3) / 1e12, 1),
             'eval_kernels_hbm': {'illuminance_correct': {'algorithmic_bytes': 16 * int(npx), 'achieved_GBps': round(gb_corr, 1), 'frac': round(gb_corr / PEAK_HBM_GBS, 4)},
                                  'quality_assess': {'algorithmic_bytes': 8 * int(npx), 'achieved_GBps': round(gb_q, 1), 'frac': round(gb_q / PEAK_HBM_GBS, 4)}},

@@ -122,6 +122,12 @@ def lib():
     return load_library()
 
 
+def build_src_hash():
+    """The source hash compiled into the loaded library (eld_build_info: "... src=<16 hex digits>"; "unknown" for builds that did not pass one)."""
+    info = lib().eld_build_info().decode()
+    return info.rsplit('src=', 1)[1].strip() if 'src=' in info else 'unknown'
+
+
 class EldError(RuntimeError):
     pass
 

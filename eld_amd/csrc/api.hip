@@ -3,8 +3,14 @@
 
 extern "C" int eld_abi_version(void) { return ELD_ABI_VERSION; }
 
+// ELD_SRC_HASH: first 16 hex digits of the SHA-256 over csrc/*.hip, csrc/*.h and include/eld_amd.h, passed by the build (__graft_entry__.build) --
+// what bench.py compares with the hash recorded beside the committed PMC traffic figures (profiles/traffic.json), so that figures measured on
+// another kernel set are never reported for this one
+#ifndef ELD_SRC_HASH
+#define ELD_SRC_HASH "unknown"
+#endif
 extern "C" const char* eld_build_info(void) {
-    return "libeld_amd gfx950 (CDNA4) HIP " __VERSION__;
+    return "libeld_amd gfx950 (CDNA4) HIP " __VERSION__ " src=" ELD_SRC_HASH;
 }
 
 extern "C" const char* eld_error_string(int code) {

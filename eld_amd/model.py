@@ -121,17 +121,12 @@ class ELDModel:
         self.CRF = getattr(opt, 'crf_tables', None)
         if self.CRF is None and ISPDataset.last() is not None:
             self.CRF = ISPDataset.last().CRF
-        if self.CRF is None and getattr(opt, 'crf', False):
-            try:                                             # what the reference model does itself (ELD_model.py:374-375)
-                from util import process as _ref_process
-                self.CRF = _ref_process.load_CRF()
-            except Exception:
-                self.CRF = None
+        # (The reference model loads the tables itself, ELD_model.py:374-375; this plugin does not import the host tree: the tables arrive as data.)
         if self.CRF is None and getattr(opt, 'crf', False) and self.stage_in == 'srgb' and self.isTrain:
             # only the training step renders the input on the device (set_input of a deferred ISPDataset sample); eval / test entry points
             # (test_ELD.py) get inputs rendered by their own datasets
-            raise RuntimeError('--crf: no CRF tables reached the model (opt.crf_tables / ISPDataset(CRF=...) / util.process.load_CRF()); refusing to render '
-                               'the input with gamma 2.2 against a CRF-rendered target')
+            raise RuntimeError('--crf: no CRF tables reached the model: pass them as opt.crf_tables = (E, fs) or through ISPDataset(CRF=...) as '
+                               'train_syn.py:42-58 does; refusing to render the input with gamma 2.2 against a CRF-rendered target')
         prec = getattr(opt, 'precision', os.environ.get('ELD_AMD_PRECISION', 'fp32'))      # 'bf16' = BASELINE config 3
         if prec == 'bf16' and cin > 4:
             raise NotImplementedError('precision=bf16 supports up to 4 input planes (got %d: burst inputs run in fp32)' % cin)

@@ -190,6 +190,11 @@ class UNetSeeInDark(nn.Module):
                                              starts, events, nb, L.cur_stream()), 'eld_unet_backward_ex')
         return grads
 
+    def release_workspaces(self):
+        """Drop the module's scratch (saved activations included): a sweep over sensor shapes holds tens of GB per shape otherwise."""
+        ws = self._ws
+        ws.bufs.clear(); ws.gen.clear(); ws.algo.clear(); ws.fused_head.clear(); ws.x_ref.clear()
+
     def forward(self, x):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self._plist):
             return _UNetFunction.apply(self, x, *self._plist)

@@ -192,3 +192,27 @@ def test_hand_issued_loads_are_not_touched_before_their_wait(src_name, kernel, w
                     changed = True
     assert not violations, 'compiler instructions touch un-waited asm load destinations: %s' % violations[:5]
     assert checked >= 1
+
+
+def test_traffic_constant_is_tied_to_the_library_sources(eld_lib, tmp_path, monkeypatch):
+    """bench.py reports the committed PMC byte counts (profiles/traffic.json) only for a library built from the sources those
+    passes ran on: eld_build_info() carries the source hash (__graft_entry__.source_hash), traffic.json records it, a mismatch drops the figure."""
+    import importlib.util
+    import json
+    import __graft_entry__ as ge
+    from eld_amd import _lib as L
+    have = L.build_src_hash()
+    assert have == ge.source_hash() and len(have) == 16, (have, ge.source_hash())      # the in-tree library is a build of the in-tree sources
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    (tmp_path / 'profiles').mkdir()
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    base = {'unet_conv_bytes_per_pass': 1.0, 'unet_conv_bytes_per_pass_bf16': 2.0, 'sampler_bytes_per_pixel': 8.5, 'frames_per_pass': 8}
+    json.dump(dict(base, library_src_hash=have, library_src_hash_bf16='0' * 16), open(tmp_path / 'profiles' / 'traffic.json', 'w'))
+    t = bench.load_traffic()
+    assert t['unet_conv_bytes_per_pass'] == 1.0 and 'sampler_bytes_per_pixel' in t
+    assert 'unet_conv_bytes_per_pass_bf16' not in t and 'not reported' in t['_stale']['unet_conv_bytes_per_pass_bf16']
+    json.dump(base, open(tmp_path / 'profiles' / 'traffic.json', 'w'))                  # a file from before the hash existed: nothing is reported
+    t = bench.load_traffic()
+    assert 'unet_conv_bytes_per_pass' not in t and 'sampler_bytes_per_pixel' not in t and len(t['_stale']) == 2

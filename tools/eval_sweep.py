@@ -8,7 +8,12 @@ inference -> IlluminanceCorrect -> tensor2im + PSNR/SSIM (csrc/eval.hip), and re
 random-init weights the PSNR/SSIM columns only exercise the metric path; load a checkpoint with --weights for real numbers.
 Replicas only: under torchrun the settings are sharded over ranks, no data-path collective.
 
-  python tools/eval_sweep.py [--precision fp32|bf16] [--frames 2] [--weights ckpt.pt]
+Round 5: the frames of a setting go through the chain `--batch` at a time (default 8, capped so that the U-Net workspace of one launch stays
+below 96 GB: 8 frames for the Sony / Canon sensors, 3 for the D850) -- one sampler launch with per-image parameters, one U-Net inference, one
+IlluminanceCorrect and one quality launch per batch; a single full frame per launch left the deep levels of the U-Net with too few tiles to
+fill the chip (169 vs 199 TF/s fp32).  tests/test_eval_sweep_gpu.py pins the batched chain to the single-frame launches bit for bit.
+
+  python tools/eval_sweep.py [--precision fp32|bf16] [--frames 2] [--batch 8] [--weights ckpt.pt]
 """
 import argparse
 import json
@@ -42,10 +47,17 @@ def params_for(cam_tables, iso, ratio, rng):
                        tl_scale=reg('G_scale'), row_scale=reg('R_scale'), q_step=1.0)
 
 
+def frames_per_launch(lib, H, W, want, budget_bytes=96e9):
+    """Frames per launch of the chain at H x W: `want`, capped so that the U-Net workspace of the launch stays below the budget."""
+    one = lib.eld_unet_workspace_bytes(1, H, W, 4, 4)
+    return max(1, min(int(want), int(budget_bytes // max(one, 1))))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'])
-    ap.add_argument('--frames', type=int, default=2, help='frames per setting')
+    ap.add_argument('--frames', type=int, default=2, help='timed launches per setting (each of --batch frames)')
+    ap.add_argument('--batch', type=int, default=8, help='frames per launch (capped by the workspace: see frames_per_launch)')
     ap.add_argument('--weights', default=None, help="checkpoint with a 'netG' state_dict (ELD_model.py:518)")
     ap.add_argument('--noise', default='PGRU')
     args = ap.parse_args()
@@ -77,12 +89,14 @@ def main():
         g = torch.Generator(device=dev).manual_seed(77 + k)
         psnr = ssim = 0.0
         t_total = 0.0
-        for f in range(args.frames + 1):                          # frame 0 warms up (workspace allocation)
-            clean = (torch.floor(65535.0 * torch.rand(1, 4, H, W, device=dev, generator=g) ** 2.2) / 65535.0).contiguous()
-            p = params_for(tables, iso, ratio, rng)
+        B = frames_per_launch(L.lib(), H, W, args.batch)
+        for f in range(args.frames + 1):                          # launch 0 warms up (workspace allocation)
+            clean = (torch.floor(65535.0 * torch.rand(B, 4, H, W, device=dev, generator=g) ** 2.2) / 65535.0).contiguous()
+            ps = [params_for(tables, iso, ratio, rng) for _ in range(B)]
+            ids = [(len(settings) * f + k) * 16 + b for b in range(B)]
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            noisy = sample_noise(clean, [p], flags, 2018, [len(settings) * f + k])
+            noisy = sample_noise(clean, ps, flags, 2018, ids)
             with torch.no_grad():
                 out = net(noisy)
             out = illuminance_correct(out, clean)
@@ -91,11 +105,15 @@ def main():
             dt = time.perf_counter() - t0
             if f:
                 t_total += dt
-                a, b = q[0].tolist()
-                psnr += a; ssim += b
+                qa = q.mean(dim=0).tolist()
+                psnr += qa[0]; ssim += qa[1]
+            del noisy, out, clean
         n = args.frames
-        rows.append({'camera': cam, 'iso': iso, 'ratio': ratio, 'packed_hw': [H, W], 'ms_per_frame': round(t_total / n * 1e3, 3),
-                     'raw_mpix_s': round(4.0 * H * W / (t_total / n) / 1e6, 1), 'psnr': round(psnr / n, 3), 'ssim': round(ssim / n, 5)})
+        rows.append({'camera': cam, 'iso': iso, 'ratio': ratio, 'packed_hw': [H, W], 'frames_per_launch': B, 'ms_per_frame': round(t_total / (n * B) * 1e3, 3),
+                     'raw_mpix_s': round(4.0 * H * W * B / (t_total / n) / 1e6, 1), 'psnr': round(psnr / n, 3), 'ssim': round(ssim / n, 5)})
+        if k + 1 == len(mine) or CAMERAS[mine[k + 1][0]] != (H, W):      # next setting runs another sensor shape: give this one's scratch back
+            net.release_workspaces()
+            torch.cuda.empty_cache()
     if world > 1:
         gathered = [None] * world
         torch.distributed.all_gather_object(gathered, rows)

@@ -4,6 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/${1:-final}; mkdir -p $O
+python -c "import eld_amd; print(eld_amd.load_library().eld_build_info().decode())" > $O/build_info.txt 2>/dev/null      # src=<hash>: recorded beside the PMC figures (tools/traffic_from_pmc.py)
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_fp32.json 2> $O/bench_fp32.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o fp32 -- python bench.py --no-cpu-baseline --no-alt > $O/bench_fp32_prof.json 2> $O/prof_fp32.err
 timeout 600 python bench.py --precision bf16 --no-cpu-baseline > $O/bench_bf16.json 2> $O/bench_bf16.err

@@ -3,6 +3,8 @@
 profiles/traffic.json, which bench.py reports as roofline.traffic.
   bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024   -- FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE counts half of a
   wide (16 B/lane) coalesced read stream (MI355X_MICROARCH.md, HBM section), every read in these kernels is 16 B/lane.
+The hash of the library that ran the passes (eld_build_info "src=", written as build_info.txt by tools/gpu_profile_set.sh into the directory above the
+CSVs) is recorded as library_src_hash / library_src_hash_bf16: bench.py reports these bytes only for a library built from the same sources.
 Usage: traffic_from_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [frames per pass = bench.py --batch, default 8] [bf16]
 With a fifth argument `bf16` the passes are those of `bench.py --precision bf16`: the kernels and the per-pass total are MERGED into an existing
 <out.json> under `kernels_bf16` / `unet_conv_bytes_per_pass_bf16` (bench.py reports it as alt_bf16.roofline.traffic)."""
@@ -27,6 +29,18 @@ def load(path, counter):
             calls[k] += 1
             grid[k] += float(r['Grid_Size'])
     return tot, calls, grid
+
+
+def src_hash_of(csv_path):
+    """src=<hash> of the build_info.txt one or two directories above the counter CSV; None when the run did not record one."""
+    import os
+    d = os.path.dirname(os.path.abspath(csv_path))
+    for up in (d, os.path.dirname(d), os.path.dirname(os.path.dirname(d))):
+        p = os.path.join(up, 'build_info.txt')
+        if os.path.exists(p):
+            t = open(p).read()
+            return t.rsplit('src=', 1)[1].split()[0].strip() if 'src=' in t else None
+    return None
 
 
 def main():
@@ -56,6 +70,7 @@ def main():
         except Exception:
             base = {}
         base['kernels_bf16'] = out['kernels']
+        base['library_src_hash_bf16'] = src_hash_of(sys.argv[1])
         base['source_bf16'] = out['source'].replace('--no-cpu-baseline', '--precision bf16 --no-cpu-baseline')
         if passes and conv:
             base['unet_passes_bf16'] = passes
@@ -63,6 +78,7 @@ def main():
         json.dump(base, open(sys.argv[3], 'w'), indent=1)
         print(json.dumps({k: v for k, v in base.items() if not k.startswith('kernels')}, indent=1))
         return
+    out['library_src_hash'] = src_hash_of(sys.argv[1])
     json.dump(out, open(sys.argv[3], 'w'), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != 'kernels'}, indent=1))
 
