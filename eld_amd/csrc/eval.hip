@@ -8,6 +8,8 @@
 // Sums are accumulated in double and reduced in a fixed order (run-to-run bit-stable, no atomics).
 #include "common.h"
 
+int debug_kernel_mask(int set);      // conv_bfs.hip (eld_debug_kernel_mask): set < 0 only queries
+
 namespace {
 
 constexpr int QA_TW = 32, QA_TH = 8, WIN = 7, HALO = WIN - 1;
@@ -16,6 +18,9 @@ constexpr int RED_BLOCKS = 512;
 // tensor2im (ELD_model.py:23-38): np.clip(x * 255, 0, 255).  mul = 255 for [0,1] inputs; mul = 1 (an exact no-op multiply) for values
 // that are already images on the [0, range] scale (util/index.py's own callers)
 __device__ __forceinline__ float to_im(float v, float mul, float range) { return fminf(fmaxf(v * mul, 0.f), range); }
+
+// the same clip as one v_med3_f32 (finite values: median(v, 0, range) == min(max(v, 0), range))
+__device__ __forceinline__ float to_im3(float v, float mul, float range) { return __builtin_amdgcn_fmed3f(v * mul, 0.f, range); }
 
 __device__ __forceinline__ double block_sum(double v, double* sh) {       // 256 threads, fixed tree
     const int t = threadIdx.x;
@@ -117,19 +122,176 @@ __global__ __launch_bounds__(256) void qa_final_kernel(const double* __restrict_
     }
 }
 
-// illuminance correction, pass 1: per-block partial <p,s> and <p,p> over s != 1 (p clamped to [0,1]); grid (RED_BLOCKS, N)
+// ---- round 5: PSNR + SSIM in ONE pass, no LDS, no workgroup barriers -------------------------------------------------------------------
+// The tile kernel above re-reads a 14 x 38 halo per 8 x 32 window positions (2.1x), runs three barriers plus a nine-barrier double-precision tree
+// per 256 results and a second pass (sqerr_kernel) over both images: 0.25 ms for one 4 x 1424 x 2128 frame pair = 0.05 of HBM.
+// Here one WAVE owns a strip of 64 * NC columns x QA_RH rows of one plane and slides down it: a lane owns NC adjacent window columns, forms the
+// horizontal 7-sums of the four moments SSIM needs (sum a, sum b, sum (a^2 + b^2), sum ab -- var_x + var_y only ever appear added) for the input
+// row that enters the window, keeps the last seven rows' sums in registers (ring indexed at compile time: the row loop is unrolled by 14 =
+// lcm(7 ring slots, 2 load buffers)) and updates the vertical sum by adding the entering row and subtracting the leaving one.  With NC = 2 the two
+// windows of a lane share their six common columns (5 + 2 adds per moment for two windows instead of 12) and every pixel is converted by four
+// lanes instead of seven.  Every accumulation is double and every order is fixed (per lane: rows top to bottom; per wave: a butterfly; per image:
+// qa_final2_kernel's strided sum + tree): run-to-run bit-stable.  Products of two float32 values are exact in double, so the fused multiply-adds
+// below round exactly like a multiply followed by an add; and for identical images the result is exactly PSNR = inf / SSIM = 1: q = a^2 + b^2 is
+// formed per pixel and summed in the same order as p = ab, so every partial sum of q is exactly twice that of p (and A1 == B1, A2 == B2 below).  Rows are loaded two ahead of
+// their use (two register buffers); the shifted loads of a lane hit the lines its neighbours fetch (L1).  The squared error of PSNR rides along:
+// a lane adds (b - a)^2 of its OWN columns for the rows its item owns (strips / chunks are cut over ALL columns / rows, so every pixel has an owner).
+constexpr int QA_RH = 106, QA_ROWS = QA_RH + HALO;                  // 112 input rows per item = 8 x 14
+static_assert(QA_ROWS % 14 == 0, "row loop unrolled by 14");
+
+__device__ __forceinline__ double wave_sum_fixed(double v) {        // butterfly over the 64 lanes: the same order on every run
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// EDGE = false: every column this wave reads exists (uniform row base + per-lane column + immediate k: no address arithmetic per load);
+// EDGE = true (the last strip of a row of strips): column indices clamped to W - 1
+template <int NC, bool EDGE>
+__device__ __forceinline__ void qa_item(const float* __restrict__ px, const float* __restrict__ py, double* __restrict__ ss_out, double* __restrict__ sq_out,
+                                        int H, int W, int y0, int c, int lane, float mul, float scale) {
+    constexpr int NV = WIN + NC - 1;                                // input columns a lane reads per row
+    const int Ho = H - HALO, Wo = W - HALO;
+    // window outputs that do not exist (column >= Wo, row >= Ho) are computed from clamped addresses and discarded: an existing output only ever
+    // reads in-range pixels, so no zero padding is needed -- only in-bounds addresses
+    int idx[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) idx[k] = min(c + k, W - 1);
+    float pa[2][NV], pb[2][NV];
+    auto issue = [&](int i, float (&A)[NV], float (&B)[NV]) {       // loads of input row y0 + i (clamped)
+        const size_t ro = (size_t)min(y0 + i, H - 1) * W;
+        const float* rx = px + ro;
+        const float* ry = py + ro;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) { A[k] = rx[EDGE ? idx[k] : c + k]; B[k] = ry[EDGE ? idx[k] : c + k]; }
+    };
+    issue(0, pa[0], pb[0]);
+    issue(1, pa[1], pb[1]);
+    double ring[WIN][NC][4], vs[NC][4];
+#pragma unroll
+    for (int w = 0; w < NC; ++w)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) vs[w][q] = 0.0;
+    double S_acc = 0.0, sq = 0.0;
+    const double NP = (double)(WIN * WIN), cov_norm = NP / (NP - 1.0);
+    const double K1 = (0.01 * (double)scale) * (0.01 * (double)scale) * (NP * NP), K2 = (0.03 * (double)scale) * (0.03 * (double)scale) * (NP * NP);
+#pragma unroll 1
+    for (int u = 0; u < QA_ROWS / 14; ++u) {
+#pragma unroll
+        for (int j = 0; j < 14; ++j) {
+            const int i = 14 * u + j;                               // input row of the item; ring slot j % 7, load buffer j % 2 (compile time)
+            double a[NV], b[NV], q[NV], p[NV];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) { a[k] = (double)to_im3(pa[j & 1][k], mul, scale); b[k] = (double)to_im3(pb[j & 1][k], mul, scale); }
+            if (i + 2 < QA_ROWS) issue(i + 2, pa[j & 1], pb[j & 1]);      // the buffer is free: its values were converted above
+#pragma unroll
+            for (int k = 0; k < NV; ++k) { q[k] = __builtin_fma(b[k], b[k], a[k] * a[k]); p[k] = a[k] * b[k]; }
+            if (i < QA_RH && y0 + i < H) {                          // this item's own rows, this lane's own columns
+#pragma unroll
+                for (int w = 0; w < NC; ++w)
+                    if (c + w < W) { const double d = b[w] - a[w]; sq = __builtin_fma(d, d, sq); }
+            }
+            // the NC windows share columns NC-1 .. 6: one core sum per moment, then the private columns on either side (the same tree for all four)
+            double h[NC][4];
+            {
+                double c0 = a[NC - 1], c1 = b[NC - 1], c2 = q[NC - 1], c3 = p[NC - 1];
+#pragma unroll
+                for (int k = NC; k < WIN; ++k) { c0 = c0 + a[k]; c1 = c1 + b[k]; c2 = c2 + q[k]; c3 = c3 + p[k]; }
+                if constexpr (NC == 1) { h[0][0] = c0; h[0][1] = c1; h[0][2] = c2; h[0][3] = c3; }
+                else {
+                    h[0][0] = a[0] + c0; h[0][1] = b[0] + c1; h[0][2] = q[0] + c2; h[0][3] = p[0] + c3;
+                    h[1][0] = c0 + a[WIN]; h[1][1] = c1 + b[WIN]; h[1][2] = c2 + q[WIN]; h[1][3] = c3 + p[WIN];
+                }
+            }
+            const int leave = (j + 1) % WIN;                        // ring slot of row i - 6 ((i - 6) % 7 == (i + 1) % 7)
+#pragma unroll
+            for (int w = 0; w < NC; ++w) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) vs[w][m] = vs[w][m] + h[w][m];
+                if (i >= HALO) {                                    // rows i-6 .. i are summed: the window of output row y0 + i - 6
+                    if (c + w < Wo && y0 + i - HALO < Ho) {
+                        // S = (2 ux uy + C1)(2 vxy + C2) / ((ux^2 + uy^2 + C1)(vx + vy + C2)) with u = s / 49, v = cov_norm (s_2 / 49 - u u): both
+                        // factors of numerator and denominator scaled by 49^2, so the window sums are used as they are
+                        const double s0 = vs[w][0], s1 = vs[w][1];
+                        const double t = s0 * s1, uu = s0 * s0 + s1 * s1;
+                        const double A1 = __builtin_fma(2.0, t, K1), B1 = uu + K1;
+                        const double A2 = __builtin_fma(2.0 * cov_norm, __builtin_fma(NP, vs[w][3], -t), K2);
+                        const double B2 = __builtin_fma(cov_norm, __builtin_fma(NP, vs[w][2], -uu), K2);
+                        S_acc = S_acc + (A1 * A2) / (B1 * B2);
+                    }
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) vs[w][m] = vs[w][m] - ring[leave][w][m];
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) ring[j % WIN][w][m] = h[w][m];
+            }
+        }
+    }
+    const double Sw = wave_sum_fixed(S_acc), Qw = wave_sum_fixed(sq);
+    if (lane == 0) { *ss_out = Sw; *sq_out = Qw; }
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void qa_fused_kernel(const float* __restrict__ est, const float* __restrict__ ref, double* __restrict__ ss_part,
+                                                       double* __restrict__ sq_part, int H, int W, int strips, int chunks, float mul, float scale) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= strips * chunks) return;                            // (no barrier anywhere in this kernel)
+    const int plane = blockIdx.y;
+    const int chunk = item / strips, strip = item - chunk * strips;
+    const int y0 = chunk * QA_RH, c = (strip * 64 + lane) * NC;
+    const float* px = est + (size_t)plane * H * W;
+    const float* py = ref + (size_t)plane * H * W;
+    const size_t o = (size_t)plane * strips * chunks + item;
+    if ((strip * 64 + 63) * NC + WIN + NC - 1 <= W) qa_item<NC, false>(px, py, ss_part + o, sq_part + o, H, W, y0, c, lane, mul, scale);      // wave-uniform
+    else qa_item<NC, true>(px, py, ss_part + o, sq_part + o, H, W, y0, c, lane, mul, scale);
+}
+
+// one workgroup per image: out[2n] = PSNR, out[2n+1] = SSIM from the per-item partials of qa_fused_kernel ([plane][item])
+__global__ __launch_bounds__(256) void qa_final2_kernel(const double* __restrict__ ss, const double* __restrict__ sq, double* __restrict__ out, int C,
+                                                        int items, size_t chw, size_t windows, float scale) {
+    __shared__ double red[256];
+    const int n = blockIdx.x;
+    double a = 0.0;
+    for (int i = threadIdx.x; i < C * items; i += 256) a += sq[(size_t)n * C * items + i];
+    const double err = block_sum(a, red) / (double)chw;
+    double ssim = 0.0;
+    for (int c = 0; c < C; ++c) {                      // mean over channels of the per-channel means (multichannel=True)
+        double b = 0.0;
+        for (int i = threadIdx.x; i < items; i += 256) b += ss[((size_t)n * C + c) * items + i];
+        ssim += block_sum(b, red) / (double)windows;
+    }
+    if (threadIdx.x == 0) {
+        out[2 * n] = 10.0 * log10((double)scale * (double)scale / err);
+        out[2 * n + 1] = ssim / C;
+    }
+}
+
+// illuminance correction, pass 1: per-block partial <p,s> and <p,p> over s != 1 (p clamped to [0,1]); grid (RED_BLOCKS, N).
+// VEC: 16-byte loads (chw % 4 == 0 and 16-byte aligned planes: every frame of the path); the scalar form stays for odd sizes.
+__device__ __forceinline__ void illum_acc(float pv_, float sv, double& num, double& den) {
+    if (sv != 1.0f) {
+        const double pv = fminf(fmaxf(pv_, 0.f), 1.f);
+        num += pv * (double)sv; den += pv * pv;
+    }
+}
+template <bool VEC>
 __global__ __launch_bounds__(256) void illum_dot_kernel(const float* __restrict__ pred, const float* __restrict__ src, double* __restrict__ part, size_t chw,
                                                         size_t src_stride) {
     __shared__ double red[256];
     const float* p = pred + (size_t)blockIdx.y * chw;
     const float* s = src + (size_t)blockIdx.y * src_stride;
     double num = 0.0, den = 0.0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < chw; i += (size_t)RED_BLOCKS * 256) {
-        const float sv = s[i];
-        if (sv != 1.0f) {
-            const double pv = fminf(fmaxf(p[i], 0.f), 1.f);
-            num += pv * (double)sv; den += pv * pv;
+    if (VEC) {
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+        const float4* s4 = reinterpret_cast<const float4*>(s);
+        const size_t n4 = chw >> 2;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)RED_BLOCKS * 256) {
+            const float4 a = p4[i], b = s4[i];
+            illum_acc(a.x, b.x, num, den); illum_acc(a.y, b.y, num, den); illum_acc(a.z, b.z, num, den); illum_acc(a.w, b.w, num, den);
         }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < chw; i += (size_t)RED_BLOCKS * 256) illum_acc(p[i], s[i], num, den);
     }
     const double tn = block_sum(num, red), td = block_sum(den, red);
     if (threadIdx.x == 0) { part[((size_t)blockIdx.y * RED_BLOCKS + blockIdx.x) * 2] = tn; part[((size_t)blockIdx.y * RED_BLOCKS + blockIdx.x) * 2 + 1] = td; }
@@ -144,11 +306,22 @@ __global__ __launch_bounds__(256) void illum_alpha_kernel(const double* __restri
     if (threadIdx.x == 0) alpha[n] = (float)num / (float)den;             // num / den as fp32 tensors (ELD_model.py:164-166)
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(256) void illum_scale_kernel(const float* __restrict__ pred, const float* __restrict__ alpha, float* __restrict__ out, size_t chw) {
     const float a = alpha[blockIdx.y];
     const size_t base = (size_t)blockIdx.y * chw;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < chw; i += (size_t)gridDim.x * 256)
-        out[base + i] = a * fminf(fmaxf(pred[base + i], 0.f), 1.f);
+    if (VEC) {
+        const float4* p4 = reinterpret_cast<const float4*>(pred + base);
+        float4* o4 = reinterpret_cast<float4*>(out + base);
+        const size_t n4 = chw >> 2;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+            const float4 v = p4[i];
+            o4[i] = make_float4(a * fminf(fmaxf(v.x, 0.f), 1.f), a * fminf(fmaxf(v.y, 0.f), 1.f), a * fminf(fmaxf(v.z, 0.f), 1.f), a * fminf(fmaxf(v.w, 0.f), 1.f));
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < chw; i += (size_t)gridDim.x * 256)
+            out[base + i] = a * fminf(fmaxf(pred[base + i], 0.f), 1.f);
+    }
 }
 
 // ---- raw -> sRGB ISP: util/process.py:52-68 `process`, one pass: 16 B read + 12 B written per RGBG position.
@@ -216,12 +389,18 @@ __global__ __launch_bounds__(256) void isp_kernel(const float* __restrict__ baye
 }
 
 inline size_t qa_tiles(int H, int W) { return (size_t)((W - HALO + QA_TW - 1) / QA_TW) * ((H - HALO + QA_TH - 1) / QA_TH); }
-
+inline size_t qa_items(int H, int W) { return (size_t)((W + 63) / 64) * ((H + QA_RH - 1) / QA_RH); }      // upper bound (64-column strips); strips over ALL columns / rows: every pixel has an owner
+// test / A-B hooks (eld_debug_kernel_mask, env ELD_DEBUG_KERNEL_MASK): bit 6 (64) = the round-2 tile kernels, bit 5 (32) = one window column per
+// lane (64-column strips) instead of two -- tests/test_model_gpu.py runs the oracle comparison under all three
+int qa_use_tiles() { return (debug_kernel_mask(-1) & 64) != 0; }
+int qa_cols() { return (debug_kernel_mask(-1) & 32) ? 1 : 2; }
 }  // namespace
 
 extern "C" size_t eld_quality_assess_workspace_bytes(int N, int C, int H, int W) {
     if (N < 1 || C < 1 || H < WIN || W < WIN) return 0;
-    return ((size_t)N * RED_BLOCKS + (size_t)N * C * qa_tiles(H, W)) * sizeof(double);
+    const size_t tiles = ((size_t)N * RED_BLOCKS + (size_t)N * C * qa_tiles(H, W)) * sizeof(double);      // tile kernels (ELD_QA_TILES=1)
+    const size_t fused = (size_t)2 * N * C * qa_items(H, W) * sizeof(double);                                // qa_fused_kernel: S and squared-error partials
+    return tiles > fused ? tiles : fused;
 }
 
 static int quality_assess_impl(const float* est, const float* ref, double* out, void* ws, size_t ws_bytes, int N, int C, int H, int W,
@@ -230,6 +409,20 @@ static int quality_assess_impl(const float* est, const float* ref, double* out, 
     if (!est || !ref || !out || !ws || N < 0 || C < 1 || H < WIN || W < WIN || !(data_range > 0.f)) return ELD_EINVAL;
     if (ws_bytes < eld_quality_assess_workspace_bytes(N, C, H, W)) return ELD_EWS;
     hipStream_t st = as_stream(stream);
+    const size_t chw_ = (size_t)C * H * W;
+    if (!qa_use_tiles() && (long long)N * C <= 65535) {
+        const int nc = qa_cols();
+        const int strips = (W + 64 * nc - 1) / (64 * nc), chunks = (H + QA_RH - 1) / QA_RH;
+        const size_t items = (size_t)strips * chunks;
+        double* ssp = (double*)ws;
+        double* sqp = ssp + (size_t)N * C * items;
+        if (nc == 2) { ELD_LAUNCH(qa_fused_kernel<2>, dim3((unsigned)((items + 3) / 4), N * C), dim3(256), 0, st, est, ref, ssp, sqp, H, W, strips, chunks, mul, data_range); }
+        else { ELD_LAUNCH(qa_fused_kernel<1>, dim3((unsigned)((items + 3) / 4), N * C), dim3(256), 0, st, est, ref, ssp, sqp, H, W, strips, chunks, mul, data_range); }
+        ELD_LAUNCH_CHECK();
+        ELD_LAUNCH(qa_final2_kernel, dim3(N), dim3(256), 0, st, ssp, sqp, out, C, (int)items, chw_, (size_t)(H - HALO) * (W - HALO), data_range);
+        ELD_LAUNCH_CHECK();
+        return 0;
+    }
     double* sq = (double*)ws;
     double* ss = sq + (size_t)N * RED_BLOCKS;
     const int tiles_x = (W - HALO + QA_TW - 1) / QA_TW, tiles_y = (H - HALO + QA_TH - 1) / QA_TH;
@@ -265,11 +458,15 @@ extern "C" int eld_illuminance_correct(const float* predict, const float* source
     hipStream_t st = as_stream(stream);
     double* part = (double*)ws;
     float* alpha = (float*)(part + (size_t)N * RED_BLOCKS * 2);
-    ELD_LAUNCH(illum_dot_kernel, dim3(RED_BLOCKS, N), dim3(256), 0, st, predict, source, part, chw, source_N == 1 ? (size_t)0 : chw);
+    const bool vec = chw % 4 == 0 && (((uintptr_t)predict | (uintptr_t)source | (uintptr_t)out) & 15) == 0;      // (then every image plane is 16-byte aligned too)
+    const size_t sstride = source_N == 1 ? (size_t)0 : chw;
+    if (vec) { ELD_LAUNCH(illum_dot_kernel<true>, dim3(RED_BLOCKS, N), dim3(256), 0, st, predict, source, part, chw, sstride); }
+    else { ELD_LAUNCH(illum_dot_kernel<false>, dim3(RED_BLOCKS, N), dim3(256), 0, st, predict, source, part, chw, sstride); }
     ELD_LAUNCH_CHECK();
     ELD_LAUNCH(illum_alpha_kernel, dim3(N), dim3(256), 0, st, part, alpha);
     ELD_LAUNCH_CHECK();
-    ELD_LAUNCH(illum_scale_kernel, dim3(1024, N), dim3(256), 0, st, predict, alpha, out, chw);
+    if (vec) { ELD_LAUNCH(illum_scale_kernel<true>, dim3(1024, N), dim3(256), 0, st, predict, alpha, out, chw); }
+    else { ELD_LAUNCH(illum_scale_kernel<false>, dim3(1024, N), dim3(256), 0, st, predict, alpha, out, chw); }
     ELD_LAUNCH_CHECK();
     return 0;
 }

@@ -338,20 +338,29 @@ def test_two_rank_training_equals_global_batch(eld_lib, tmp_path):
     assert np.abs(res[0][2] - ref).max() < 3e-5      # Adam moves every weight ~lr per step; sign-unstable tiny gradients may differ
 
 
-@pytest.mark.parametrize('shape', [(2, 4, 64, 80), (1, 4, 37, 41), (3, 3, 7, 129), (1, 4, 512, 512)])
-def test_quality_assess_kernel_vs_oracle(eld_lib, shape):
-    """csrc/eval.hip eld_quality_assess == tensor2im + PSNR + SSIM of oracle/metrics_ref.py (float64), per image."""
+@pytest.mark.parametrize('variant', [0, 32, 64], ids=['strip2', 'strip1', 'tiles'])
+@pytest.mark.parametrize('shape', [(2, 4, 64, 80), (1, 4, 37, 41), (3, 3, 7, 129), (1, 4, 512, 512), (1, 4, 230, 300), (2, 3, 113, 257), (1, 2, 1424, 2128)])
+def test_quality_assess_kernel_vs_oracle(eld_lib, shape, variant):
+    """csrc/eval.hip eld_quality_assess == tensor2im + PSNR + SSIM of oracle/metrics_ref.py (float64), per image.  Round 5: the one-pass strip kernel
+    (qa_fused_kernel, two window columns per lane), its one-column variant and the round-2 tile kernels (eld_debug_kernel_mask bits 5 / 6), on shapes
+    that cross its 106-row chunks and 128- / 64-column strips, leave a strip almost empty (W = 129, 257) or have fewer rows than one window needs + 1."""
     from eld_amd.metrics import quality_assess_frames
     from oracle import metrics_ref as M
     g = torch.Generator().manual_seed(shape[2] * shape[3])
     ref = torch.rand(*shape, generator=g) * 1.1 - 0.05                 # some values outside [0,1]: the clip matters
     est = ref + 0.05 * torch.randn(*shape, generator=g)
-    q = quality_assess_frames(est.cuda(), ref.cuda()).cpu().numpy()
+    prev = eld_lib.eld_debug_kernel_mask(variant)
+    try:
+        q = quality_assess_frames(est.cuda(), ref.cuda()).cpu().numpy()
+        q2 = quality_assess_frames(est.cuda(), ref.cuda()).cpu().numpy()
+        same = quality_assess_frames(ref.cuda(), ref.cuda()).cpu().numpy()
+    finally:
+        eld_lib.eld_debug_kernel_mask(prev)
+    assert np.array_equal(q, q2)                                       # fixed reduction order: run-to-run the same bits
     for n in range(shape[0]):
         a, b = M.tensor2im(est[n].numpy()), M.tensor2im(ref[n].numpy())
         assert abs(q[n, 0] - M.psnr(b, a)) < 1e-9
         assert abs(q[n, 1] - M.ssim(b, a)) < 1e-9
-    same = quality_assess_frames(ref.cuda(), ref.cuda()).cpu().numpy()
     assert np.all(np.isinf(same[:, 0])) and np.all(np.abs(same[:, 1] - 1.0) < 1e-12)
 
 
