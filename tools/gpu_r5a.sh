@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/${1:-r5a}; mkdir -p $O
-( time timeout 1500 python -m pytest tests -m gpu -q -x --deselect tests/test_fuzz_gpu.py ) > $O/pytest.log 2>&1; tail -15 $O/pytest.log
+( time timeout 1500 python -m pytest tests -m gpu -q --deselect tests/test_fuzz_gpu.py ) > $O/pytest.log 2>&1; tail -15 $O/pytest.log
 ( time timeout 900 python -m pytest tests/test_fuzz_gpu.py -m gpu -q ) > $O/pytest_fuzz.log 2>&1; tail -8 $O/pytest_fuzz.log
 timeout 300 python tools/qa_microbench.py > $O/qa_microbench.json 2> $O/qa_microbench.err; cat $O/qa_microbench.json | tr -d '\n' | cut -c1-1500; echo
 timeout 900 python bench.py --gpus 1 --steps 10 --warmup 3 > $O/bench_fp32.json 2> $O/bench_fp32.err; cut -c1-400 $O/bench_fp32.json
