@@ -54,8 +54,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     constexpr int KS = PW / 2;             // MFMA k-steps per wave per tile
     constexpr int X_PIX = MODE == CONV_3X3 ? (TH + 2) * (TW + 2) : 4 * TPIX;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* ldsG = lds;                                   // [TPIX][COB]   (LES-byte elements)
-    float* ldsX = lds + TPIX * COB * LES / 4;            // [X_PIX][JB]
+    // piece-plane layouts of fp32 inputs (ALG_X3 / ALG_H2): a 32-channel block of G is padded by one 64-byte row, as in wgrad8_kernel -- the staging
+    // stores of one pixel's two blocks (consecutive lanes) then land on different banks (block planes of TPIX x 64 B are multiples of the 256-byte
+    // bank row: 2-way conflicts on every G store without the pad; round 4's counters: SQ_LDS_BANK_CONFLICT = the kernel's MFMA count)
+    constexpr int GROWS = TPIX + ((X3 || H2) ? 1 : 0);   // rows of a 32-channel block of G in LDS
+    float* ldsG = lds;                                   // [TPIX][COB]   (LES-byte elements); piece layouts: [plane][COB / 32][GROWS][32]
+    float* ldsX = lds + GROWS * COB * LES / 4;           // [X_PIX][JB]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 31, hi = lane >> 5;
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int it = 0; it < X_IT; ++it) rx[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)ox[it], cs * ES, 0));
     };
-    constexpr int GPL = TPIX * COB, XPL = X_PIX * JB;                 // x3: elements per piece plane
+    constexpr int GPL = GROWS * COB, XPL = X_PIX * JB;                // x3: elements per piece plane
     auto put = [&](float* dst, int u, const float4& raw, int plane_elems, int e0) {      // e0: element index of the unit inside a bf16 plane            // LDS rows are unit-linear: [lp][COB] and [hp][JB]
         if constexpr (H2) {
             typedef __fp16 h2v __attribute__((ext_vector_type(2)));
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
             // bf16 planes of G are [32-channel block][pixel][32]: 64-byte rows, the layout ds_read_b64_tr_b16 reads conflict-free
             const int lp = u / (COB / EPU), part = u - lp * (COB / EPU);
             const int c = part * EPU;
-            if (u < G_UNITS) put(ldsG, u, rg[it], GPL, ((c >> 5) * TPIX + lp) * 32 + (c & 31));
+            if (u < G_UNITS) put(ldsG, u, rg[it], GPL, ((c >> 5) * GROWS + lp) * 32 + (c & 31));
         }
 #pragma unroll
         for (int it = 0; it < X_IT; ++it) {
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
         const int gi = lane & 15, gg = lane >> 4;                   // lane inside its 16-lane group, group: channels 16(gg&1).., k-half gg>>1 (= hi)
         const int lq0 = wpix * PW + 8 * hi + (gi >> 2);             // pixel row this lane ADDRESSES in k-step 0 (first 4-pixel block)
         const int pyq = lq0 / TW, pxq = lq0 - pyq * TW;
-        const bf16_t* gq = reinterpret_cast<const bf16_t*>(ldsG) + (wco * TPIX + lq0) * 32 + (gg & 1) * 16 + (gi & 3) * 4;
+        const bf16_t* gq = reinterpret_cast<const bf16_t*>(ldsG) + (wco * GROWS + lq0) * 32 + (gg & 1) * 16 + (gi & 3) * 4;
         const bf16_t* xq = reinterpret_cast<const bf16_t*>(ldsX) + (MODE == CONV_3X3 ? (pyq * (TW + 2) + pxq) : lq0) * JB + (gg & 1) * 16 + (gi & 3) * 4;
         auto tr8 = [](const bf16_t* p0) {                           // pixels [0,4) and [4,8) of the lane's k-half -> one operand
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
@@ -994,7 +998,8 @@ static int launch_w(WgradArgs a, hipStream_t st) {
     constexpr int X_PIX = MODE == CONV_3X3 ? (TH + 2) * (TW + 2) : 4 * TH * TW;
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + TH - 1) / TH;
-    size_t lds_bytes = (size_t)(TH * TW * COB + X_PIX * JB) * (ALG == ALG_X3 ? 6 : (ALG == ALG_BFM ? 2 : 4));      // ALG_H2: 2 planes x 2 B
+    constexpr int GROWS = TH * TW + ((ALG == ALG_X3 || ALG == ALG_H2) ? 1 : 0);      // one pad row per 32-channel block of G in the fp32 piece layouts (see the kernel)
+    size_t lds_bytes = (size_t)(GROWS * COB + X_PIX * JB) * (ALG == ALG_X3 ? 6 : (ALG == ALG_BFM ? 2 : 4));      // ALG_H2: 2 planes x 2 B
     const size_t red_bytes = (size_t)4 * 16 * 64 * sizeof(float);
     if (lds_bytes < red_bytes) lds_bytes = red_bytes;
     const long long blocks = (long long)(a.CA / COB) * (a.CBp / JB) * a.psplit;

@@ -373,7 +373,7 @@ template <int BN, int RPW, int WAVES, bool DB>
 __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES == 8 ? 2 : 1)) void conv_x3d_kernel(const ConvArgs a) {
     constexpr int CK = 16, THREADS = 64 * WAVES;
     constexpr int TH = WAVES * RPW, NT = BN / 32, A_PIX = (TH + 2) * (TW + 2);
-    constexpr int A_WORDS = A_PIX * PX, B_ROWS = 3 * BN;
+    constexpr int B_ROWS = 3 * BN;
     constexpr int B_WORDS = (B_ROWS * PX * 4 + 1023) / 1024 * 256;     // slab stride (global and LDS): rows padded to whole 1 KiB DMA pieces
     constexpr int B_PIECES = B_WORDS * 4 / 1024;                      // 1 KiB per wave-instruction
     constexpr int DMA_IT = (B_PIECES + WAVES - 1) / WAVES;
@@ -1021,7 +1021,10 @@ int x3_slab_bn(int Nout, int N, int H, int W, int* waves) {
     // workgroups of the register-staged kernel lose to the weight cut.  Off by default.
     if (Nout == 32) {
         static const int on = [] { const char* e = getenv("ELD_X3D_32"); return e ? atoi(e) : 0; }();
-        return (on && conv_tile_count(N, H, W, 32, false) >= 2 * eld_num_cus()) ? 32 : 0;
+        // ELD_X3D_32=2 (round 5 experiment): conv_x3d_kernel<32, 2, 4> -- the same pre-split slabs, 8-row tiles, 4-wave workgroups, TWO per CU like the
+        // register-staged kernel (60 KB of LDS each)
+        if (waves && on == 2) *waves = 4;
+        return (on && conv_tile_count(N, H, W, on == 2 ? 8 : 32, false) >= 2 * eld_num_cus()) ? 32 : 0;
     }
     if (Nout % 64) return 0;
     const long long px_tiles = conv_tile_count(N, H, W, 16, false);
@@ -1042,7 +1045,7 @@ int launch_conv_x3(const ConvArgs& a_in, hipStream_t st) {
     // conv_x3d_kernel addresses a two-image window (virtual rows)
     if (bn0 && a.N > 1 && (size_t)a.H * a.W * a.C0 * 8 >= 0xFFFFFFF0ull) return ELD_ENOTSUP;
     const int bn = x3_slab_bn(a.Nout, a.N, a.H, a.W, &waves);
-    if (bn == 32) return launch_x3d<32, 4, 8, false>(a, st);
+    if (bn == 32) return waves == 4 ? launch_x3d<32, 2, 4, false>(a, st) : launch_x3d<32, 4, 8, false>(a, st);
     if (bn == 128) return launch_x3d<128, 2, 8, false>(a, st);      // weights pre-split in slab layout: LDS-DMA kernel
     if (bn == 64) return waves == 8 ? launch_x3d<64, 2, 8, false>(a, st) : launch_x3d<64, 2, 4, false>(a, st);
     return launch_x3<32, 4, false>(a, st);

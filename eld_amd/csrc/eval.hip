@@ -180,29 +180,26 @@ __device__ __forceinline__ void qa_item(const float* __restrict__ px, const floa
 #pragma unroll
         for (int j = 0; j < 14; ++j) {
             const int i = 14 * u + j;                               // input row of the item; ring slot j % 7, load buffer j % 2 (compile time)
-            double a[NV], b[NV], q[NV], p[NV];
-#pragma unroll
-            for (int k = 0; k < NV; ++k) { a[k] = (double)to_im3(pa[j & 1][k], mul, scale); b[k] = (double)to_im3(pb[j & 1][k], mul, scale); }
-            if (i + 2 < QA_ROWS) issue(i + 2, pa[j & 1], pb[j & 1]);      // the buffer is free: its values were converted above
-#pragma unroll
-            for (int k = 0; k < NV; ++k) { q[k] = __builtin_fma(b[k], b[k], a[k] * a[k]); p[k] = a[k] * b[k]; }
-            if (i < QA_RH && y0 + i < H) {                          // this item's own rows, this lane's own columns
-#pragma unroll
-                for (int w = 0; w < NC; ++w)
-                    if (c + w < W) { const double d = b[w] - a[w]; sq = __builtin_fma(d, d, sq); }
-            }
-            // the NC windows share columns NC-1 .. 6: one core sum per moment, then the private columns on either side (the same tree for all four)
+            // one column at a time, summed as soon as it is converted (few live doubles: the kernel's registers are the ring); the NC windows share
+            // columns NC-1 .. 6: one core sum per moment, then the private columns on either side (the same tree for all four moments)
             double h[NC][4];
             {
-                double c0 = a[NC - 1], c1 = b[NC - 1], c2 = q[NC - 1], c3 = p[NC - 1];
+                const bool own_row = i < QA_RH && y0 + i < H;       // this item's own rows: squared error of this lane's own columns
+                double e0[4], c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
 #pragma unroll
-                for (int k = NC; k < WIN; ++k) { c0 = c0 + a[k]; c1 = c1 + b[k]; c2 = c2 + q[k]; c3 = c3 + p[k]; }
-                if constexpr (NC == 1) { h[0][0] = c0; h[0][1] = c1; h[0][2] = c2; h[0][3] = c3; }
-                else {
-                    h[0][0] = a[0] + c0; h[0][1] = b[0] + c1; h[0][2] = q[0] + c2; h[0][3] = p[0] + c3;
-                    h[1][0] = c0 + a[WIN]; h[1][1] = c1 + b[WIN]; h[1][2] = c2 + q[WIN]; h[1][3] = c3 + p[WIN];
+                for (int k = 0; k < NV; ++k) {
+                    const double ak = (double)to_im3(pa[j & 1][k], mul, scale), bk = (double)to_im3(pb[j & 1][k], mul, scale);
+                    const double qk = __builtin_fma(bk, bk, ak * ak), pk = ak * bk;
+                    if (k < NC && own_row && c + k < W) { const double d = bk - ak; sq = __builtin_fma(d, d, sq); }
+                    if (NC == 2 && k == 0) { e0[0] = ak; e0[1] = bk; e0[2] = qk; e0[3] = pk; }
+                    else if (k == NC - 1) { c0 = ak; c1 = bk; c2 = qk; c3 = pk; }
+                    else if (k < WIN) { c0 = c0 + ak; c1 = c1 + bk; c2 = c2 + qk; c3 = c3 + pk; }
+                    else if constexpr (NC == 2) { h[NC - 1][0] = c0 + ak; h[NC - 1][1] = c1 + bk; h[NC - 1][2] = c2 + qk; h[NC - 1][3] = c3 + pk; }      // k == WIN: the second window's last column
                 }
+                if constexpr (NC == 1) { h[0][0] = c0; h[0][1] = c1; h[0][2] = c2; h[0][3] = c3; (void)e0; }
+                else { h[0][0] = e0[0] + c0; h[0][1] = e0[1] + c1; h[0][2] = e0[2] + c2; h[0][3] = e0[3] + c3; }
             }
+            if (i + 2 < QA_ROWS) issue(i + 2, pa[j & 1], pb[j & 1]);      // the buffer is free: its values were consumed above
             const int leave = (j + 1) % WIN;                        // ring slot of row i - 6 ((i - 6) % 7 == (i + 1) % 7)
 #pragma unroll
             for (int w = 0; w < NC; ++w) {

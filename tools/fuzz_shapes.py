@@ -5,8 +5,8 @@ images, tiny deep levels -- through the whole U-Net step.
         bit for bit; wgrad8d vs wgrad8 (mask 16) to 1e-4.
   fp32: the default three-piece scheme against the float64 oracle (oracle/unet_ref.py on the GPU's fp64 vector units): output to 1e-5, every gradient to
         5e-3 relative L2 (sign flips of near-zero LeakyReLU inputs under float32 rounding dominate at the tiny deep levels of small inputs); round 5: on
-        levels with >= 10^4 pixels also max|err| <= 2e-4 max|ref| or <= 8x the float32 oracle's own distance from float64 (tests/test_parity_full_gpu.py's
-        relative criterion; hard limit 2e-3: a wrong seam row of one tile row would be off by percents).
+        levels with >= 10^4 pixels also max|err| <= 2e-3 max|ref| (a wrong seam row of one tile row is off by percents; tests/test_parity_full_gpu.py's
+        2e-4 is printed as a note when exceeded: single LeakyReLU sign flips under float32 rounding can reach it on the smaller of these levels).
   both: the FUSED training pair (eld_unet_forward_loss_ex + eld_unet_backward_ex(dout = NULL): PACK_BOTH, first-layer weight gradient from the caller's
         x, fused head) against the plain forward / eld_l1_loss / backward pair of the same precision -- output and every gradient bit for bit."""
 import os, sys, random
@@ -86,7 +86,6 @@ def main(n_cases=24, seed=0, big=1):
         msg += fused_vs_plain(net, x, t, False)
         sd64 = {k: v.detach().double() for k, v in net.state_dict().items()}
         o64, _, g64 = U.loss_and_grads(sd64, x.double(), t.double())
-        _, _, g32 = U.loss_and_grads({k: v.detach().clone() for k, v in net.state_dict().items()}, x, t)      # the float32 oracle's own distance from float64
         if float((r1[0].double() - o64).abs().max()) > 1e-5 * (1 + float(o64.abs().max())): msg.append('fp32 out')
         for n_ in r1[1]:
             a, b = r1[1][n_].double(), g64[n_]
@@ -97,10 +96,8 @@ def main(n_cases=24, seed=0, big=1):
             lev = LEVEL[n_.split('_')[0].split('.')[0]]
             if N * (H >> lev) * (W >> lev) >= 10000:            # a level large enough that single LeakyReLU sign flips do not dominate
                 err, rmax = float((a - b).abs().max()), float(b.abs().max())
-                own = float((g32[n_].double() - b).abs().max())
-                if err > 2e-4 * rmax and err > 8.0 * own:
-                    if err > 2e-3 * rmax: msg.append('fp32 grad %s max-abs %.2e of max|ref|' % (n_, err / rmax))
-                    else: print('   note: %s max-abs %.2e of max|ref| (float32 oracle: %.2e)' % (n_, err / rmax, own / rmax), flush=True)
+                if err > 2e-3 * rmax: msg.append('fp32 grad %s max-abs %.2e of max|ref|' % (n_, err / rmax))
+                elif err > 2e-4 * rmax: print('   note: %s max-abs %.2e of max|ref|' % (n_, err / rmax), flush=True)
         torch.cuda.synchronize()
         print('case %2d  N=%d H=%d W=%d  %s' % (case, N, H, W, 'ok' if not msg else 'MISMATCH: ' + '; '.join(msg[:6])), flush=True)
         bad += bool(msg)
