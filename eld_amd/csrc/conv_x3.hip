@@ -1031,6 +1031,9 @@ int x3_slab_bn(int Nout, int N, int H, int W, int* waves) {
     const int cus = eld_num_cus();
     if (Nout % 128 == 0 && px_tiles * (Nout / 128) >= cus) return 128;
     if (waves && px_tiles * (Nout / 64) < cus) *waves = 4;
+    // ELD_X3D_64W4=1 (round 5 experiment): the 64-channel layers of big problems on the 4-wave kernel too (8-row tiles, two 81 KB workgroups per CU)
+    static const int w4 = [] { const char* e = getenv("ELD_X3D_64W4"); return e ? atoi(e) : 0; }();
+    if (waves && w4) *waves = 4;
     return 64;
 }
 
