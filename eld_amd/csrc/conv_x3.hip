@@ -506,10 +506,14 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
 
         for (int chunk = c_begin; chunk < c_end; ++chunk) {
             const bool last_chunk = chunk + 1 >= c_end;
+            // halo loads were issued in the chunk's first stage, BEHIND that stage's slab DMA: vmcnt retires in order, so the second stage may wait
+            // for the slab alone and leave the A_IT halo loads in flight for another stage (round 5; they used to be drained here with vmcnt(0))
+            const bool a_behind = a.keep_a && (!last_chunk || t_next < total_tiles);
 #pragma unroll 1
             for (int ky = 0; ky < 3; ++ky) {
                 __builtin_amdgcn_s_setprio(3);   // the short staging section goes ahead of co-resident waves' MFMA streams
-                dma_wait();                      // this wave's pieces of the stage's slab (issued one stage ago) have landed
+                if (ky == 1 && a_behind) eld_wait_vmcnt<A_IT>();      // this wave's pieces of the stage's slab (issued one stage ago) have landed ...
+                else dma_wait();
                 __syncthreads();                 // ... and so have everybody else's; the previous stage's fragment reads are done
                 if (ky == 0) {
                     store_A();
@@ -964,6 +968,8 @@ int launch_x3d(ConvArgs a, hipStream_t st) {
         if (ks >= 2) { a.ksplit = ks; tiles *= ks; }
     }
     if (tiles > 0x7fffffffLL) return ELD_ENOTSUP;
+    static const int keep_a = [] { const char* e = getenv("ELD_X3D_KEEPA"); return e ? atoi(e) : 0; }();
+    a.keep_a = keep_a;
     auto kern = conv_x3d_kernel<BN, RPW, WAVES, DB>;
     static EldAttrOnce once;
     { const int rc = once.ensure(kern, lds_bytes); if (rc) return rc; }
