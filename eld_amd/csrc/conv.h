@@ -319,9 +319,3 @@ int wgrad8_ntiles(int CA, int CBp, int N, int H, int W, bool bf16);
 // out[(i*CBr + j)*T + tap] = sum_s part[s][tap][i][j]   (OIHW / (Cin,Cout,2,2) layouts);  bgrad[i] = sum_s bpart[s][i]
 int launch_wgrad_reduce(const float* part, const float* bpart, float* wgrad, float* bgrad, int psplit, int T, int CA,
                         int CBp, int CBr, hipStream_t st, int bias_n = 0);      // bias_n > 0: bpart is [psplit][bias_n] (default [psplit][CA])
-// The same reductions for several layers in ONE launch (round 5, small steps: a 4 x 512 x 512 patch ran 21 of its 118 launches for these): every job
-// is summed exactly as launch_wgrad_reduce sums it (same waves per block, same order: bit-identical results); the partials of all jobs must stay valid
-// until the launch, i.e. every layer needs its own partial region.
-struct WgradReduceJob { const float* part; const float* bpart; float* wgrad; float* bgrad; int psplit, T, CA, CBp, CBr, bias_n; };
-constexpr int WGRAD_REDUCE_MAX_JOBS = 24;
-int launch_wgrad_reduce_batch(const WgradReduceJob* jobs, int n, hipStream_t st);

@@ -1119,112 +1119,6 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
     }
 }
 
-// ---- batched form: one launch for the reductions of several layers ---------------------------------------------------------------------
-// Block -> job by a table in the kernel arguments; a job keeps the wave count (NW) and the loop structure launch_wgrad_reduce would give it, so
-// every sum is formed in the same order (waves beyond the job's NW idle: the block size is the largest NW of the batch).
-struct ReduceJobK { const float* part; const float* bpart; float* wgrad; float* bgrad; int psplit, T, CA, CBp, CBr, NB, NW, pair_blocks, block0; };
-struct ReduceJobsK { int n; ReduceJobK job[WGRAD_REDUCE_MAX_JOBS]; };
-
-__global__ __launch_bounds__(1024) void wgrad_reduce_batch_kernel(const ReduceJobsK J) {
-    extern __shared__ float sh[];                 // [NW][T][64]
-    int ji = 0;
-    while (ji + 1 < J.n && (int)blockIdx.x >= J.job[ji + 1].block0) ++ji;      // block-uniform
-    const float* __restrict__ part = J.job[ji].part;
-    const float* __restrict__ bpart = J.job[ji].bpart;
-    float* __restrict__ wgrad = J.job[ji].wgrad;
-    float* __restrict__ bgrad = J.job[ji].bgrad;
-    const int psplit = J.job[ji].psplit, T = J.job[ji].T, CA = J.job[ji].CA, CBp = J.job[ji].CBp, CBr = J.job[ji].CBr, NB = J.job[ji].NB;
-    const int NW = J.job[ji].NW, pair_blocks = J.job[ji].pair_blocks, bx = (int)blockIdx.x - J.job[ji].block0;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const size_t pairs = (size_t)CA * CBp, plane = pairs * T;
-    const bool active = w < NW;                   // (block-uniform per wave; every wave reaches the barrier below)
-    if (bx >= pair_blocks) {                      // bias block: 64 of the NB bias channels (bpart is [psplit][NB])
-        const int c = (bx - pair_blocks) * 64 + lane;
-        float b = 0.f;
-        if (active && c < NB) {
-            int k = w;
-            for (; k + 3 * NW < psplit; k += 4 * NW)
-                b += (bpart[(size_t)k * NB + c] + bpart[(size_t)(k + NW) * NB + c]) + (bpart[(size_t)(k + 2 * NW) * NB + c] + bpart[(size_t)(k + 3 * NW) * NB + c]);
-            for (; k < psplit; k += NW) b += bpart[(size_t)k * NB + c];
-        }
-        if (active) sh[w * 64 + lane] = b;
-        __syncthreads();
-        if (w == 0 && c < NB) {
-            for (int ww = 1; ww < NW; ++ww) b += sh[ww * 64 + lane];
-            bgrad[c] = b;
-        }
-        return;
-    }
-    const size_t pr = (size_t)bx * 64 + lane;
-    float s[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) s[t] = 0.f;
-    if (active && pr < pairs) {
-        int k = w;
-        for (; k + NW < psplit; k += 2 * NW) {
-            const float* p0 = part + (size_t)k * plane + pr;
-            const float* p1 = part + (size_t)(k + NW) * plane + pr;
-            float a[9], b[9];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) if (t < T) { a[t] = p0[(size_t)t * pairs]; b[t] = p1[(size_t)t * pairs]; }
-#pragma unroll
-            for (int t = 0; t < 9; ++t) if (t < T) s[t] += a[t] + b[t];
-        }
-        for (; k < psplit; k += NW) {
-            const float* p0 = part + (size_t)k * plane + pr;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) if (t < T) s[t] += p0[(size_t)t * pairs];
-        }
-    }
-    if (NW > 1) {
-        if (active) {
-#pragma unroll
-            for (int t = 0; t < 9; ++t) if (t < T) sh[(w * T + t) * 64 + lane] = s[t];
-        }
-        __syncthreads();
-        if (w == 0)
-            for (int ww = 1; ww < NW; ++ww)
-#pragma unroll
-                for (int t = 0; t < 9; ++t) if (t < T) s[t] += sh[(ww * T + t) * 64 + lane];
-    }
-    if (w == 0 && pr < pairs) {
-        const int j = (int)(pr % CBp), i = (int)(pr / CBp);
-        if (j < CBr) {
-            float* o = wgrad + ((size_t)i * CBr + j) * T;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) if (t < T) o[t] = s[t];
-        }
-    }
-}
-
-int launch_wgrad_reduce_batch(const WgradReduceJob* jobs, int n, hipStream_t st) {
-    if (n <= 0) return 0;
-    if (n > WGRAD_REDUCE_MAX_JOBS) return ELD_EINVAL;
-    ReduceJobsK J;
-    J.n = n;
-    int blocks = 0, nw_max = 1;
-    size_t lds = 0;
-    for (int i = 0; i < n; ++i) {
-        const WgradReduceJob& q = jobs[i];
-        if (q.T != 9 && q.T != 4) return ELD_EINVAL;
-        int NW = 1;
-        while (NW < 16 && NW < q.psplit) NW <<= 1;                       // launch_wgrad_reduce's choice
-        const size_t pairs = (size_t)q.CA * q.CBp;
-        ReduceJobK& k = J.job[i];
-        k.part = q.part; k.bpart = q.bpart; k.wgrad = q.wgrad; k.bgrad = q.bgrad;
-        k.psplit = q.psplit; k.T = q.T; k.CA = q.CA; k.CBp = q.CBp; k.CBr = q.CBr;
-        k.NB = q.bias_n > 0 ? q.bias_n : q.CA;
-        k.NW = NW; k.pair_blocks = (int)((pairs + 63) / 64); k.block0 = blocks;
-        blocks += k.pair_blocks + (q.bgrad ? (k.NB + 63) / 64 : 0);
-        nw_max = NW > nw_max ? NW : nw_max;
-        const size_t l = (size_t)NW * q.T * 64 * sizeof(float);
-        lds = l > lds ? l : lds;
-    }
-    ELD_LAUNCH(wgrad_reduce_batch_kernel, dim3(blocks), dim3(64 * nw_max), lds, st, J);
-    ELD_LAUNCH_CHECK();
-    return 0;
-}
-
 int launch_wgrad_reduce(const float* part, const float* bpart, float* wgrad, float* bgrad, int psplit, int T, int CA,
                         int CBp, int CBr, hipStream_t st, int bias_n) {
     const int NB = bias_n > 0 ? bias_n : CA;      // channels of the bias partials (transposed convs: the column sums of the gathered operand, CBp of them)

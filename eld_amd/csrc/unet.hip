@@ -101,18 +101,6 @@ thread_local Amax g_am;
 struct KPart { float* p = nullptr; size_t floats = 0; };
 thread_local KPart g_kp;
 struct KPartScope { KPart prev; KPartScope(float* p, size_t n) : prev(g_kp) { g_kp.p = p; g_kp.floats = n; } ~KPartScope() { g_kp = prev; } };
-// Small steps (round 5): the weight-gradient reductions of a backward are collected and run as ONE launch at its end (launch_wgrad_reduce_batch) when
-// the plan gave every layer its own partial region (Plan::defer) and no gradient-bucket events were asked for; set for the duration of a backward.
-struct ReduceBatch { WgradReduceJob job[WGRAD_REDUCE_MAX_JOBS]; int n = 0; };
-thread_local ReduceBatch* g_rb = nullptr;
-struct ReduceScope { ReduceBatch* prev; explicit ReduceScope(ReduceBatch* b) : prev(g_rb) { g_rb = b; } ~ReduceScope() { g_rb = prev; } };
-int reduce_or_defer(const float* part, const float* bpart, float* wgrad, float* bgrad, int psplit, int T, int CA, int CBp, int CBr, hipStream_t st, int bias_n = 0) {
-    if (g_rb != nullptr && g_rb->n < WGRAD_REDUCE_MAX_JOBS) {
-        g_rb->job[g_rb->n++] = {part, bpart, wgrad, bgrad, psplit, T, CA, CBp, CBr, bias_n};
-        return 0;
-    }
-    return launch_wgrad_reduce(part, bpart, wgrad, bgrad, psplit, T, CA, CBp, CBr, st, bias_n);
-}
 thread_local int g_algo = -1;      // fp32 product scheme of the entry point being executed on this thread (-1: process default)
 struct AlgoScope { int prev; explicit AlgoScope(int a) : prev(g_algo) { g_algo = resolve_algo(a); } ~AlgoScope() { g_algo = prev; } };
 inline void take_amax(ConvArgs& a) { a.algo = g_algo; a.amax_in0 = g_am.in0; a.amax_in1 = g_am.in1; a.amax_w = g_am.w; a.amax_out0 = g_am.out0; a.amax_out1 = g_am.out1; g_am = Amax(); }
@@ -150,7 +138,7 @@ int conv_wgrad(const float* g, int Cout, const float* x0, int C0, const float* x
     a.wgrad8 = q.w8;
     int rc = launch_wgrad(a, CONV_3X3, st);
     if (rc) return rc;
-    return reduce_or_defer(part, a.bpart, dw, db, q.psplit, q.T, q.CA, q.CBp, Cin_real, st);
+    return launch_wgrad_reduce(part, a.bpart, dw, db, q.psplit, q.T, q.CA, q.CBp, Cin_real, st);
 }
 
 // in [N,H,W,Cin] -> out [N,2H,2W,Cout]; wf packed [4*Cout][Cin]
@@ -185,10 +173,8 @@ int convt_wgrad(const float* in, const float* dout, float* dw, float* db, float*
     int rc = launch_wgrad(a, CONV_GATHER2X2, st);
     if (rc) return rc;
     // (the bias partials ride in the same reduction launch: one launch less per transposed conv)
-    if (fused_bias || !db) return reduce_or_defer(part, fused_bias ? a.xbpart : nullptr, dw, fused_bias ? db : nullptr, q.psplit, q.T, q.CA, q.CBp, Cout, st, q.CBp);
-    // (the separate column-sum pass reuses `part` as scratch: this reduction cannot wait for the end of the backward)
-    rc = launch_wgrad_reduce(part, nullptr, dw, nullptr, q.psplit, q.T, q.CA, q.CBp, Cout, st, q.CBp);
-    if (rc) return rc;
+    rc = launch_wgrad_reduce(part, fused_bias ? a.xbpart : nullptr, dw, fused_bias ? db : nullptr, q.psplit, q.T, q.CA, q.CBp, Cout, st, q.CBp);
+    if (rc || !db || fused_bias) return rc;
     return launch_colsum(dout, db, part, (size_t)N * 4 * H * W, Cout, st);
 }
 
@@ -205,8 +191,6 @@ struct Plan {
     size_t x16, ea[NLEV], eb[NLEV], pool[NLEV - 1], up[NLEV - 1], da[NLEV - 1], db[NLEV - 1];
     size_t gA, gB, skip[NLEV - 1], part, part_floats, amax;
     size_t head_part; // partials of the fused training head (eld_unet_forward_loss_ex -> the backward)
-    bool defer;       // small problems: every layer has its own weight-gradient partial region (part_l), so the reductions can run as one launch at the end of the backward
-    size_t part_l[NLAYERS];
     size_t total;     // floats
 };
 
@@ -247,7 +231,6 @@ int make_plan(Plan& P, int N, int H, int W, int in_ch, int out_ch) {
     size_t pmax = head_bwd_ws_floats();
     pmax = pmax > conv_first_wgrad_ws_floats() ? pmax : conv_first_wgrad_ws_floats();
     pmax = pmax > colsum_ws_floats(256) ? pmax : colsum_ws_floats(256);
-    size_t layer_part[NLAYERS];
     for (int i = 0; i < NLAYERS; ++i) {
         const LayerDef& d = P.L[i];
         int lev;
@@ -260,7 +243,6 @@ int make_plan(Plan& P, int N, int H, int W, int in_ch, int out_ch) {
             const size_t f3 = wgrad_geom(CONV_3X3, d.cout, i == L_E0A ? 16 : d.cin, N, P.Hl[lev], P.Wl[lev], 3).floats;
             f = f3 > f ? f3 : f;
         } else if (d.kind == 1) f = wgrad_geom(CONV_GATHER2X2, d.cin, d.cout, N, P.Hl[lev + 1], P.Wl[lev + 1], 0).floats;
-        layer_part[i] = f;
         pmax = f > pmax ? f : pmax;
     }
     // split-K partial sums of small problems share this region: up to 16 parts of the largest 3x3 output that can take the split
@@ -281,10 +263,6 @@ int make_plan(Plan& P, int N, int H, int W, int in_ch, int out_ch) {
     }
     P.part = take(pmax);
     P.part_floats = pmax;
-    // a step of a few patches is launch-bound (one 4 x 512 x 512 patch: 118 launches of ~25 us): give every layer its own partial region (a few MB
-    // together at these sizes) so that the backward can reduce all weight gradients in one launch; full frames keep the shared region
-    P.defer = (size_t)N * H * W <= (size_t)4 * 512 * 512;
-    for (int i = 0; i < NLAYERS; ++i) P.part_l[i] = (P.defer && layer_part[i] > 0 && i != L_E0A && i != L_HEAD) ? take(layer_part[i]) : P.part;
     P.amax = take(S_COUNT);
     P.total = off;
     return 0;
@@ -477,10 +455,6 @@ int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd
     if (h2 && hipMemsetAsync(am + S_GA, 0, (S_COUNT - S_GA) * sizeof(float), st) != hipSuccess) return (int)hipGetLastError();
     if (!fused.packed) RC(pack_weights(P, prm, ws, PACK_BWD, st, false, h2 ? am : nullptr));
     float* gA = ws + P.gA; float* gB = ws + P.gB; float* part = ws + P.part;
-    ReduceBatch rb;
-    const bool defer = P.defer && marks.n == 0;              // (bucket events want every layer's gradients final as soon as possible)
-    ReduceScope rscope(defer ? &rb : nullptr);
-    auto lp = [&](int layer) { return defer ? ws + P.part_l[layer] : part; };      // partial region of a layer's weight gradient
     auto gs = [&](const float* buf) { return buf == gA ? (int)S_GA : (int)S_GB; };                 // slot of a ping-pong gradient buffer
     auto fresh = [&](int slot) -> int {                                                               // zero a slot before its tensor is rewritten
         if (!h2) return 0;
@@ -500,14 +474,14 @@ int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd
         const int H = P.Hl[l], W = P.Wl[l], C = chan(l);
         // conv_2 of the level: input da[l]
         WG(gs(cur), S_DA + l, -1);
-        RC(conv_wgrad(cur, C, ws + P.da[l], C, nullptr, 0, C, grd + P.L[iu + 2].w_off, grd + P.L[iu + 2].b_off, lp(iu + 2), N, H, W, st));
+        RC(conv_wgrad(cur, C, ws + P.da[l], C, nullptr, 0, C, grd + P.L[iu + 2].w_off, grd + P.L[iu + 2].b_off, part, N, H, W, st));
         RC(marks.done(P, iu + 2, st));
         RC(fresh(gs(oth))); BD(gs(cur), S_W + iu + 2, gs(oth), -1);
         RC(conv_bwd_data(cur, ws + P.wp_bwd[iu + 2], oth, nullptr, C, ws + P.da[l], nullptr, N, H, W, C, C, st));
         { float* t = cur; cur = oth; oth = t; }
         // conv_1: input cat[up[l], eb[l]] -> d_up (raw) in oth, skip grad (raw) in skip[l]
         WG(gs(cur), S_UP + l, S_EB + l);
-        RC(conv_wgrad(cur, C, ws + P.up[l], C, ws + P.eb[l], C, 2 * C, grd + P.L[iu + 1].w_off, grd + P.L[iu + 1].b_off, lp(iu + 1), N, H, W, st));
+        RC(conv_wgrad(cur, C, ws + P.up[l], C, ws + P.eb[l], C, 2 * C, grd + P.L[iu + 1].w_off, grd + P.L[iu + 1].b_off, part, N, H, W, st));
         RC(marks.done(P, iu + 1, st));
         RC(fresh(gs(oth))); BD(gs(cur), S_W + iu + 1, gs(oth), S_SKIP + l);
         RC(conv_bwd_data(cur, ws + P.wp_bwd[iu + 1], oth, ws + P.skip[l], C, nullptr, nullptr, N, H, W, 2 * C, C, st));
@@ -515,7 +489,7 @@ int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd
         // transposed conv: input src (level l+1, 2C channels), output grad = cur (d_up)
         const float* src = l == 3 ? ws + P.eb[4] : ws + P.db[l + 1];
         WG(l == 3 ? S_EB + 4 : S_DB + l + 1, gs(cur), -1);
-        RC(convt_wgrad(src, cur, grd + P.L[iu].w_off, grd + P.L[iu].b_off, lp(iu), N, P.Hl[l + 1], P.Wl[l + 1], 2 * C, C, st));
+        RC(convt_wgrad(src, cur, grd + P.L[iu].w_off, grd + P.L[iu].b_off, part, N, P.Hl[l + 1], P.Wl[l + 1], 2 * C, C, st));
         RC(marks.done(P, iu, st));
         RC(fresh(gs(oth))); BD(gs(cur), S_W + iu, gs(oth), -1);
         RC(convt_bwd_data(cur, ws + P.wp_bwd[iu], src, oth, N, P.Hl[l + 1], P.Wl[l + 1], 2 * C, C, st));
@@ -526,7 +500,7 @@ int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd
         const int H = P.Hl[l], W = P.Wl[l], C = chan(l);
         const int ia = 2 * l, ib = 2 * l + 1;
         WG(gs(cur), S_EA + l, -1);
-        RC(conv_wgrad(cur, C, ws + P.ea[l], C, nullptr, 0, C, grd + P.L[ib].w_off, grd + P.L[ib].b_off, lp(ib), N, H, W, st));
+        RC(conv_wgrad(cur, C, ws + P.ea[l], C, nullptr, 0, C, grd + P.L[ib].w_off, grd + P.L[ib].b_off, part, N, H, W, st));
         RC(marks.done(P, ib, st));
         RC(fresh(gs(oth))); BD(gs(cur), S_W + ib, gs(oth), -1);
         RC(conv_bwd_data(cur, ws + P.wp_bwd[ib], oth, nullptr, C, ws + P.ea[l], nullptr, N, H, W, C, C, st));
@@ -543,7 +517,7 @@ int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd
         }
         const int Cp = chan(l - 1);
         WG(gs(cur), S_EB + l - 1, -1);                 // pooled activations are bounded by their source's bound
-        RC(conv_wgrad(cur, C, ws + P.pool[l - 1], Cp, nullptr, 0, Cp, grd + P.L[ia].w_off, grd + P.L[ia].b_off, lp(ia), N, H, W, st));
+        RC(conv_wgrad(cur, C, ws + P.pool[l - 1], Cp, nullptr, 0, Cp, grd + P.L[ia].w_off, grd + P.L[ia].b_off, part, N, H, W, st));
         RC(marks.done(P, ia, st));
         RC(fresh(gs(oth))); BD(gs(cur), S_W + ia, gs(oth), -1);
         RC(conv_bwd_data(cur, ws + P.wp_bwd[ia], oth, nullptr, Cp, nullptr, nullptr, N, H, W, Cp, C, st));      // d_pool (raw)
@@ -552,7 +526,6 @@ int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd
         if (h2) { RC(fresh(gs(oth))); RC(launch_absmax(oth, (size_t)N * 4 * H * W * Cp, am + gs(oth), st)); }
         { float* t = cur; cur = oth; oth = t; }
     }
-    if (defer) RC(launch_wgrad_reduce_batch(rb.job, rb.n, st));      // every layer's partials -> gradients, one launch
     return 0;
 }
 
@@ -574,7 +547,7 @@ int conv_wgrad_bf16(const bf16_t* g, int Cout, const bf16_t* x0, int C0, const b
     a.part = part; a.bpart = db ? part + (size_t)q.psplit * q.T * q.CA * q.CBp : nullptr; a.CBp = q.CBp; a.psplit = q.psplit;
     a.wgrad8 = q.w8;
     RC(launch_wgrad(a, CONV_3X3, st));
-    return reduce_or_defer(part, a.bpart, dw, db, q.psplit, q.T, q.CA, q.CBp, C0 + C1, st);
+    return launch_wgrad_reduce(part, a.bpart, dw, db, q.psplit, q.T, q.CA, q.CBp, C0 + C1, st);
 }
 
 int unet_backward_bf16(const Plan& P, const float* dout, const float* prm, float* grd, float* ws, hipStream_t st, BucketMarks& marks, const FusedFwd& fused) {
@@ -583,10 +556,6 @@ int unet_backward_bf16(const Plan& P, const float* dout, const float* prm, float
     if (!fused.packed) RC(pack_weights(P, prm, ws, PACK_BWD, st, true));
     auto B = [&](size_t off) { return reinterpret_cast<bf16_t*>(ws + off); };
     bf16_t* cur = B(P.gA); bf16_t* oth = B(P.gB); float* part = ws + P.part;
-    ReduceBatch rb;
-    const bool defer = P.defer && marks.n == 0;
-    ReduceScope rscope(defer ? &rb : nullptr);
-    auto lp = [&](int layer) { return defer ? ws + P.part_l[layer] : part; };
     const LayerDef& Hd = P.L[L_HEAD];
     if (dout) RC(launch_head_bwd_bf16(dout, B(P.db[0]), prm + Hd.w_off, cur, grd + Hd.w_off, grd + Hd.b_off, part, N, P.H, P.W, P.out_ch, st));
     else RC(launch_head_train_reduce(ws + P.head_part, grd + Hd.w_off, grd + Hd.b_off, N, P.H, P.W, P.out_ch, 1, st));
@@ -595,11 +564,11 @@ int unet_backward_bf16(const Plan& P, const float* dout, const float* prm, float
     for (int l = 0; l <= 3; ++l) {
         const int iu = L_UP3 + 3 * (3 - l);
         const int H = P.Hl[l], W = P.Wl[l], C = chan(l);
-        RC(conv_wgrad_bf16(cur, C, B(P.da[l]), C, nullptr, 0, grd + P.L[iu + 2].w_off, grd + P.L[iu + 2].b_off, lp(iu + 2), N, H, W, st));
+        RC(conv_wgrad_bf16(cur, C, B(P.da[l]), C, nullptr, 0, grd + P.L[iu + 2].w_off, grd + P.L[iu + 2].b_off, part, N, H, W, st));
         RC(marks.done(P, iu + 2, st));
         RC(conv_bwd_data_bf16(cur, B(P.wp_bwd[iu + 2]), oth, nullptr, C, B(P.da[l]), nullptr, N, H, W, C, C, st));
         swap();
-        RC(conv_wgrad_bf16(cur, C, B(P.up[l]), C, B(P.eb[l]), C, grd + P.L[iu + 1].w_off, grd + P.L[iu + 1].b_off, lp(iu + 1), N, H, W, st));
+        RC(conv_wgrad_bf16(cur, C, B(P.up[l]), C, B(P.eb[l]), C, grd + P.L[iu + 1].w_off, grd + P.L[iu + 1].b_off, part, N, H, W, st));
         RC(marks.done(P, iu + 1, st));
         RC(conv_bwd_data_bf16(cur, B(P.wp_bwd[iu + 1]), oth, B(P.skip[l]), C, nullptr, nullptr, N, H, W, 2 * C, C, st));
         swap();
@@ -608,12 +577,11 @@ int unet_backward_bf16(const Plan& P, const float* dout, const float* prm, float
             const int Hi = P.Hl[l + 1], Wi = P.Wl[l + 1];
             const WgradGeom q = wgrad_geom(CONV_GATHER2X2, 2 * C, C, N, Hi, Wi, 0);
             WgradArgs a = {};
-            float* lpart = lp(iu);
             a.g = src; a.CA = 2 * C; a.x0 = cur; a.C0 = C; a.N = N; a.H = Hi; a.W = Wi; a.dtype = DT_BF16;
-            a.part = lpart; a.bpart = nullptr; a.CBp = q.CBp; a.psplit = q.psplit;
-            a.xbpart = lpart + (size_t)q.psplit * q.T * q.CA * q.CBp;          // bias gradient = column sums of d_up, from the staging registers
+            a.part = part; a.bpart = nullptr; a.CBp = q.CBp; a.psplit = q.psplit;
+            a.xbpart = part + (size_t)q.psplit * q.T * q.CA * q.CBp;          // bias gradient = column sums of d_up, from the staging registers
             RC(launch_wgrad(a, CONV_GATHER2X2, st));
-            RC(reduce_or_defer(lpart, a.xbpart, grd + P.L[iu].w_off, grd + P.L[iu].b_off, q.psplit, q.T, q.CA, q.CBp, C, st, q.CBp));
+            RC(launch_wgrad_reduce(part, a.xbpart, grd + P.L[iu].w_off, grd + P.L[iu].b_off, q.psplit, q.T, q.CA, q.CBp, C, st, q.CBp));
             RC(marks.done(P, iu, st));
             ConvArgs c = {};
             c.in0 = cur; c.C0 = C; c.wp = B(P.wp_bwd[iu]); c.N = N; c.H = Hi; c.W = Wi; c.Nout = 2 * C;
@@ -625,7 +593,7 @@ int unet_backward_bf16(const Plan& P, const float* dout, const float* prm, float
     for (int l = 4; l >= 0; --l) {
         const int H = P.Hl[l], W = P.Wl[l], C = chan(l);
         const int ia = 2 * l, ib = 2 * l + 1;
-        RC(conv_wgrad_bf16(cur, C, B(P.ea[l]), C, nullptr, 0, grd + P.L[ib].w_off, grd + P.L[ib].b_off, lp(ib), N, H, W, st));
+        RC(conv_wgrad_bf16(cur, C, B(P.ea[l]), C, nullptr, 0, grd + P.L[ib].w_off, grd + P.L[ib].b_off, part, N, H, W, st));
         RC(marks.done(P, ib, st));
         RC(conv_bwd_data_bf16(cur, B(P.wp_bwd[ib]), oth, nullptr, C, B(P.ea[l]), nullptr, N, H, W, C, C, st));
         swap();
@@ -635,14 +603,13 @@ int unet_backward_bf16(const Plan& P, const float* dout, const float* prm, float
             break;
         }
         const int Cp = chan(l - 1);
-        RC(conv_wgrad_bf16(cur, C, B(P.pool[l - 1]), Cp, nullptr, 0, grd + P.L[ia].w_off, grd + P.L[ia].b_off, lp(ia), N, H, W, st));
+        RC(conv_wgrad_bf16(cur, C, B(P.pool[l - 1]), Cp, nullptr, 0, grd + P.L[ia].w_off, grd + P.L[ia].b_off, part, N, H, W, st));
         RC(marks.done(P, ia, st));
         RC(conv_bwd_data_bf16(cur, B(P.wp_bwd[ia]), oth, nullptr, Cp, nullptr, nullptr, N, H, W, Cp, C, st));
         swap();
         RC(launch_maxpool_bwd_bf16(B(P.eb[l - 1]), cur, B(P.skip[l - 1]), oth, N, H, W, Cp, st));
         swap();
     }
-    if (defer) RC(launch_wgrad_reduce_batch(rb.job, rb.n, st));
     return 0;
 }
 

@@ -674,29 +674,6 @@ def test_explicit_dout_backward_after_the_fused_forward(lib, prec):
     assert torch.equal(g1, g0), int((g1 != g0).sum())
 
 
-@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
-@pytest.mark.parametrize('shape', [(1, 4, 512, 512), (3, 4, 96, 208)])
-def test_batched_weight_gradient_reduction_equals_the_per_layer_launches(lib, prec, shape):
-    """Round 5, small steps: a backward over at most 4 x 512 x 512 pixels without gradient-bucket events keeps every layer's weight-gradient partials
-    in its own region and reduces all of them in ONE launch at its end (launch_wgrad_reduce_batch: 21 launches fewer per step); with bucket events
-    the layers are reduced one by one as before.  Same sums in the same order: the two gradient buffers must be the same bits."""
-    from eld_amd.unet import UNetSeeInDark
-    from eld_amd import dist as D
-    torch.manual_seed(6)
-    net = UNetSeeInDark(4, 4).cuda()
-    bf16 = prec == 'bf16'
-    g = torch.Generator(device='cuda').manual_seed(2)
-    x = torch.rand(*shape, device='cuda', generator=g)
-    dout = torch.randn(*shape, device='cuda', generator=g) / x.numel()
-    _, key, _ = net._engine_forward(x, save=True, bf16=bf16)
-    g_batched = net._engine_backward(dout, key, shape).clone()
-    bk = D.GradBuckets(g_batched.numel(), g_batched.device)
-    g_layers = torch.zeros_like(g_batched)
-    net._engine_backward(dout, key, shape, grads=g_layers, buckets=bk)
-    torch.cuda.synchronize()
-    assert torch.equal(g_batched, g_layers), int((g_batched != g_layers).sum())
-
-
 def test_forward_loss_argument_checks(lib):
     """eld_unet_forward_loss_ex rejects what it cannot run (include/eld_amd.h): a missing target / loss pointer, an unknown loss kind, a workspace
     that is too small -- error codes, no launch."""
