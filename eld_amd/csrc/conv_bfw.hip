@@ -342,7 +342,6 @@ int launch_bfw(ConvArgs a, hipStream_t st) {
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + TH - 1) / TH;
     constexpr size_t A_BYTES = (size_t)(((TH + 2) * (TW + 2) * 2 + 63) / 64) * 1024;
-    const int NCH = (a.C0 + a.C1) >> 5;
     const size_t lds_bytes = BFW_NAB * A_BYTES + 2 * (size_t)BFW_WCHUNK + 256;      // + bias (the second weight chunk's space stays unused at K = 32)
     const long long tiles = (long long)a.tiles_x * a.tiles_y * a.N;
     if (tiles <= 0) return 0;

@@ -95,7 +95,7 @@ __device__ __forceinline__ void pool_epilogue(const ConvArgs& a, const f32x16 (&
     }
 }
 
-template <int BN, int RPW, bool DB>
+template <int BN, int RPW, bool DB, bool BFIRST = false>
 __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
     constexpr int CK = 16;
     constexpr int TH = 4 * RPW, NT = BN / 32, A_PIX = (TH + 2) * (TW + 2);
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
 
         for (int c0 = 0; c0 < Cin; c0 += CK) {
             const bool last_chunk = c0 + CK >= Cin;
-#pragma unroll 1
+#pragma unroll BFIRST ? 3 : 1            // (BFIRST: three explicit stages, so that every wait sees a static queue -- see the issue order below)
             for (int ky = 0; ky < 3; ++ky) {
                 __builtin_amdgcn_s_setprio(3);   // the short staging section goes ahead of the co-resident workgroup's MFMA stream
                 __syncthreads();                 // every wave is done with the previous stage's operands
@@ -209,13 +209,20 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
                 store_B();
                 __syncthreads();
                 {
+                    // Order matters: vmcnt retires in order, so the loads the NEXT stage needs (its weight slab) go first and the halo tile -- needed
+                    // three stages from now -- behind them: the compiler's wait for the slab registers then leaves the halo loads in flight (round 5;
+                    // with the halo first, the next stage's wait for the slab drained the halo as well: one stage of latency instead of two)
+                    auto issue_B = [&]() {
+                        if (ky < 2) load_B(nb, c0, ky + 1);
+                        else if (!last_chunk) load_B(nb, c0 + CK, 0);
+                        else if (t_next < total_tiles) load_B(t_next % NB, 0, 0);
+                    };
+                    if constexpr (BFIRST) issue_B();          // (a compile-time choice: the compiler's wait counts follow the issue order)
                     if (ky == 0) {               // the halo tile of the next chunk / next tile has three stages to arrive
                         if (!last_chunk) load_A(c0 + CK);
                         else if (t_next < total_tiles) { setup_load(t_next); load_A(0); }
                     }
-                    if (ky < 2) load_B(nb, c0, ky + 1);
-                    else if (!last_chunk) load_B(nb, c0 + CK, 0);
-                    else if (t_next < total_tiles) load_B(t_next % NB, 0, 0);
+                    if constexpr (!BFIRST) issue_B();
                 }
                 uint4 fx[DB ? 2 : 1][3][RPW], fw[DB ? 2 : 1][3][NT];
                 __builtin_amdgcn_s_setprio(0);
@@ -922,7 +929,7 @@ int launch_x3_splitk_finish(const ConvArgs& a, hipStream_t st) {
     return 0;
 }
 
-template <int BN, int RPW, bool DB>
+template <int BN, int RPW, bool DB, bool BFIRST = false>
 int launch_x3(ConvArgs a, hipStream_t st) {
     constexpr int TH = 4 * RPW;
     a.tiles_x = (a.W + TW - 1) / TW;
@@ -931,7 +938,7 @@ int launch_x3(ConvArgs a, hipStream_t st) {
     const long long tiles = (long long)a.tiles_x * a.tiles_y * a.N * (a.Nout / BN);
     if (tiles <= 0) return 0;
     if (tiles > 0x7fffffffLL) return ELD_ENOTSUP;
-    auto kern = conv_x3_kernel<BN, RPW, DB>;
+    auto kern = conv_x3_kernel<BN, RPW, DB, BFIRST>;
     static EldAttrOnce once;
     { const int rc = once.ensure(kern, lds_bytes); if (rc) return rc; }
     int per_cu = (int)((160 * 1024) / lds_bytes);
@@ -1057,6 +1064,8 @@ int launch_conv_x3(const ConvArgs& a_in, hipStream_t st) {
     if (bn == 32) return waves == 4 ? launch_x3d<32, 2, 4, false>(a, st) : launch_x3d<32, 4, 8, false>(a, st);
     if (bn == 128) return launch_x3d<128, 2, 8, false>(a, st);      // weights pre-split in slab layout: LDS-DMA kernel
     if (bn == 64) return waves == 8 ? launch_x3d<64, 2, 8, false>(a, st) : launch_x3d<64, 2, 4, false>(a, st);
+    static const int bfirst = [] { const char* e = getenv("ELD_X3_BFIRST"); return e ? atoi(e) : 0; }();      // round 5 experiment: slab loads ahead of the halo loads
+    if (bfirst) return launch_x3<32, 4, false, true>(a, st);
     return launch_x3<32, 4, false>(a, st);
 }
 
