@@ -513,14 +513,11 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
 
         for (int chunk = c_begin; chunk < c_end; ++chunk) {
             const bool last_chunk = chunk + 1 >= c_end;
-            // halo loads were issued in the chunk's first stage, BEHIND that stage's slab DMA: vmcnt retires in order, so the second stage may wait
-            // for the slab alone and leave the A_IT halo loads in flight for another stage (round 5; they used to be drained here with vmcnt(0))
-            const bool a_behind = a.keep_a && (!last_chunk || t_next < total_tiles);
 #pragma unroll 1
             for (int ky = 0; ky < 3; ++ky) {
                 __builtin_amdgcn_s_setprio(3);   // the short staging section goes ahead of co-resident waves' MFMA streams
-                if (ky == 1 && a_behind) eld_wait_vmcnt<A_IT>();      // this wave's pieces of the stage's slab (issued one stage ago) have landed ...
-                else dma_wait();
+                dma_wait();                      // this wave's pieces of the stage's slab (issued one stage ago) have landed (round 5: a counted wait that
+                                                 // leaves the halo loads of the chunk's first stage in flight here measured 0.0 %: profiles/r05_ab_notes.md)
                 __syncthreads();                 // ... and so have everybody else's; the previous stage's fragment reads are done
                 if (ky == 0) {
                     store_A();
@@ -975,8 +972,6 @@ int launch_x3d(ConvArgs a, hipStream_t st) {
         if (ks >= 2) { a.ksplit = ks; tiles *= ks; }
     }
     if (tiles > 0x7fffffffLL) return ELD_ENOTSUP;
-    static const int keep_a = [] { const char* e = getenv("ELD_X3D_KEEPA"); return e ? atoi(e) : 0; }();
-    a.keep_a = keep_a;
     auto kern = conv_x3d_kernel<BN, RPW, WAVES, DB>;
     static EldAttrOnce once;
     { const int rc = once.ensure(kern, lds_bytes); if (rc) return rc; }
@@ -1034,19 +1029,15 @@ int x3_slab_bn(int Nout, int N, int H, int W, int* waves) {
     // workgroups of the register-staged kernel lose to the weight cut.  Off by default.
     if (Nout == 32) {
         static const int on = [] { const char* e = getenv("ELD_X3D_32"); return e ? atoi(e) : 0; }();
-        // ELD_X3D_32=2 (round 5 experiment): conv_x3d_kernel<32, 2, 4> -- the same pre-split slabs, 8-row tiles, 4-wave workgroups, TWO per CU like the
-        // register-staged kernel (60 KB of LDS each)
-        if (waves && on == 2) *waves = 4;
-        return (on && conv_tile_count(N, H, W, on == 2 ? 8 : 32, false) >= 2 * eld_num_cus()) ? 32 : 0;
+        // (round 5: conv_x3d_kernel<32, 2, 4> -- the same slabs, 8-row tiles, two 4-wave workgroups per CU -- measured +10.7 %: not kept either)
+        return (on && conv_tile_count(N, H, W, 32, false) >= 2 * eld_num_cus()) ? 32 : 0;
     }
     if (Nout % 64) return 0;
     const long long px_tiles = conv_tile_count(N, H, W, 16, false);
     const int cus = eld_num_cus();
     if (Nout % 128 == 0 && px_tiles * (Nout / 128) >= cus) return 128;
     if (waves && px_tiles * (Nout / 64) < cus) *waves = 4;
-    // ELD_X3D_64W4=1 (round 5 experiment): the 64-channel layers of big problems on the 4-wave kernel too (8-row tiles, two 81 KB workgroups per CU)
-    static const int w4 = [] { const char* e = getenv("ELD_X3D_64W4"); return e ? atoi(e) : 0; }();
-    if (waves && w4) *waves = 4;
+    // (round 5: the 4-wave kernel for the 64-channel layers of big problems too -- 8-row tiles, two 81 KB workgroups per CU -- measured -0.2 %: not kept)
     return 64;
 }
 
@@ -1061,10 +1052,12 @@ int launch_conv_x3(const ConvArgs& a_in, hipStream_t st) {
     // conv_x3d_kernel addresses a two-image window (virtual rows)
     if (bn0 && a.N > 1 && (size_t)a.H * a.W * a.C0 * 8 >= 0xFFFFFFF0ull) return ELD_ENOTSUP;
     const int bn = x3_slab_bn(a.Nout, a.N, a.H, a.W, &waves);
-    if (bn == 32) return waves == 4 ? launch_x3d<32, 2, 4, false>(a, st) : launch_x3d<32, 4, 8, false>(a, st);
+    if (bn == 32) return launch_x3d<32, 4, 8, false>(a, st);
     if (bn == 128) return launch_x3d<128, 2, 8, false>(a, st);      // weights pre-split in slab layout: LDS-DMA kernel
     if (bn == 64) return waves == 8 ? launch_x3d<64, 2, 8, false>(a, st) : launch_x3d<64, 2, 4, false>(a, st);
-    static const int bfirst = [] { const char* e = getenv("ELD_X3_BFIRST"); return e ? atoi(e) : 0; }();      // round 5 experiment: slab loads ahead of the halo loads
+    // round 5: the next stage's slab loads are issued AHEAD of the halo loads (template BFIRST; -2.7 % per launch, same box); ELD_X3_BFIRST=0 restores the
+    // round-4 order for A/B runs
+    static const int bfirst = [] { const char* e = getenv("ELD_X3_BFIRST"); return e ? atoi(e) : 1; }();
     if (bfirst) return launch_x3<32, 4, false, true>(a, st);
     return launch_x3<32, 4, false>(a, st);
 }
