@@ -256,3 +256,33 @@ def test_eval_oracle_vs_reference_fixture(golden_dir):
         for tag in ('chop_a', 'chop_b'):                       # shave < 10 (+16) and shave >= 10 branches
             out = U.forward_chop(sd, torch.from_numpy(d[tag + '_x']))
             assert float(np.abs(out.numpy() - d[tag + '_out']).max()) < 1e-6, tag
+
+
+def test_ssim_psnr_oracle_vs_brute_force_statement():
+    """PSNR / SSIM stay "parity unpinned" (scikit-image is absent: util/index.py:76-81 calls it), so the oracle's uniform_filter formulation is checked
+    against an independent brute-force statement of the same published definition (Wang et al. 2004 with skimage.metrics.structural_similarity's
+    documented defaults: 7x7 uniform window, K1 = 0.01, K2 = 0.03, sample covariance NP / (NP - 1), windows fully inside the image, channel mean):
+    every window summed explicitly in float64.  Plus the closed-form cases: identical images, a constant offset."""
+    from oracle import metrics_ref as M
+    rng = np.random.default_rng(7)
+    for shape in [(3, 9, 11), (1, 7, 7), (4, 20, 13)]:
+        x = np.clip(rng.uniform(-10, 265, size=shape), 0, 255).astype(np.float32)
+        y = np.clip(x + rng.normal(0, 12, size=shape), 0, 255).astype(np.float32)
+        C1, C2 = (0.01 * 255.0) ** 2, (0.03 * 255.0) ** 2
+        per_channel = []
+        for c in range(shape[0]):
+            vals = []
+            for i in range(shape[1] - 6):
+                for j in range(shape[2] - 6):
+                    a = x[c, i:i + 7, j:j + 7].astype(np.float64).ravel()
+                    b = y[c, i:i + 7, j:j + 7].astype(np.float64).ravel()
+                    ua, ub = a.mean(), b.mean()
+                    va, vb = a.var(ddof=1), b.var(ddof=1)
+                    vab = np.sum((a - ua) * (b - ub)) / 48.0
+                    vals.append(((2 * ua * ub + C1) * (2 * vab + C2)) / ((ua * ua + ub * ub + C1) * (va + vb + C2)))
+            per_channel.append(np.mean(vals))
+        assert abs(M.ssim(x, y) - float(np.mean(per_channel))) < 1e-10
+        assert abs(M.psnr(x, y) - 10 * np.log10(255.0 ** 2 / np.mean((x.astype(np.float64) - y.astype(np.float64)) ** 2))) < 1e-12
+        assert abs(M.ssim(x, x) - 1.0) < 1e-12
+    flat = np.full((2, 16, 16), 100.0, np.float32)
+    assert abs(M.psnr(flat, flat + 5.0) - 20 * np.log10(255.0 / 5.0)) < 1e-12
