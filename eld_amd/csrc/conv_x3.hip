@@ -683,11 +683,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
 // Tile = 2*WAVES rows x 32 pixels x BN channels, K stage = 32 k-values (two 16-k sub-chunks; a stage never straddles a tap):
 //   <64, 4>:  8 x 32 x 64,  LDS = [sub][256 pixels][28 words] + [sub][64][28 words] = 71.7 KB, two workgroups per CU;
 //   <128, 8>: 16 x 32 x 128, 143 KB, one 8-wave workgroup per CU -- each cut operand feeds twice the MFMAs.
-// PF = 2 (round 5): the staging registers are doubled and a stage's loads are issued TWO stages ahead of their use (the 32-k stages of this GEMM are
-// 0.7 ... 1.5 us of matrix work: one stage of lead did not cover a miss to HBM).  The K loop is unrolled by two so that the register set of a stage is a
-// compile-time choice, and the loads are issued unconditionally (out-of-range offsets past the last tile: zeros, no traffic) so that the compiler's
-// vmcnt counts are the same on every path: the wait in front of a stage's cut leaves exactly the younger stage's loads in flight.  Needs Ktot % 64 == 0.
-template <int MODE, int BN, int WAVES, int PF = 1>
+template <int MODE, int BN, int WAVES>
 __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv_x3_gemm_kernel(const ConvArgs a) {
     constexpr int THREADS = 64 * WAVES, RPW = 2, TH = WAVES * RPW, NT = BN / 32, NS = 2;
     constexpr int TPIX = TH * TW;
@@ -706,11 +702,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv_x3_gemm_k
     constexpr int A_UNITS = NS * TPIX * 4, B_UNITS = NS * BN * 4;
     constexpr int A_IT = A_UNITS / THREADS, B_IT = B_UNITS / THREADS;
     static_assert(A_UNITS % THREADS == 0 && B_UNITS % THREADS == 0, "whole staging passes");
-    float4 ra[PF][A_IT], rb[PF][B_IT];
+    float4 ra[A_IT], rb[B_IT];
     constexpr unsigned OOB = 0xFFFFFFF0u;
     unsigned a_voff[A_IT], b_voff[B_IT];
     int l_img = 0;
-    bool l_live = true;                                                // PF = 2: false once the loads run past the last tile (offsets out of range)
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (int)((size_t)(MODE == CONV_1X1 ? 1 : 4) * a.Nout * C0 * 4), 0x00020000);
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
@@ -740,7 +735,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv_x3_gemm_k
             a_voff[it] = ok ? pix * (unsigned)(C0 * 4) + (unsigned)(sub * 64 + part * 16) : OOB;
         }
     };
-    auto load_stage = [&](int nb, int k0, float4 (&RA)[A_IT], float4 (&RB)[B_IT]) {
+    auto load_stage = [&](int nb, int k0) {
         const int tap = MODE == CONV_GATHER2X2 ? k0 / C0 : 0;
         const int cs = k0 - tap * C0;
         const size_t img_bytes = (size_t)Hs * Ws * C0 * 4;
@@ -748,30 +743,29 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv_x3_gemm_k
         const int asoff = (((tap >> 1) * Ws + (tap & 1)) * C0 + cs) * 4;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it)
-            RA[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)a_voff[it], asoff, 0));
+            ra[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)a_voff[it], asoff, 0));
         const int wsoff = ((tap * a.Nout + nb * BN) * C0 + cs) * 4;
 #pragma unroll
         for (int it = 0; it < B_IT; ++it)
-            RB[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, l_live ? (int)b_voff[it] : (int)OOB, wsoff, 0));
+            rb[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)b_voff[it], wsoff, 0));
     };
-    auto store_stage = [&](const float4 (&RA)[A_IT], const float4 (&RB)[B_IT]) {
+    auto store_stage = [&]() {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int u = tid + it * THREADS;
-            split_store(ldsA + stage_row(u >> 2, NS * TPIX) * PX + (u & 3) * 2, RA[it]);          // row = sub * TPIX + pixel
+            split_store(ldsA + stage_row(u >> 2, NS * TPIX) * PX + (u & 3) * 2, ra[it]);          // row = sub * TPIX + pixel
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             const int u = tid + it * THREADS;
-            split_store(ldsB + stage_row(u >> 2, NS * BN) * PX + (u & 3) * 2, RB[it]);
+            split_store(ldsB + stage_row(u >> 2, NS * BN) * PX + (u & 3) * 2, rb[it]);
         }
     };
 
     int t = blockIdx.x;
     if (t >= total_tiles) return;
     setup_load(t);
-    load_stage(t % NB, 0, ra[0], rb[0]);
-    if constexpr (PF == 2) load_stage(t % NB, 16 * NS, ra[1], rb[1]);
+    load_stage(t % NB, 0);
     for (;;) {
         int nb, img, y0, x0;
         decode(t, nb, img, y0, x0);
@@ -783,8 +777,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv_x3_gemm_k
             for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[r][tt][i] = 0.f;
-        // the matrix work of one 32-k stage out of LDS
-        auto mfma_stage = [&]() {
+        for (int k0 = 0; k0 < Ktot; k0 += 16 * NS) {
+            __syncthreads();
+            store_stage();
+            __syncthreads();
+            if (k0 + 16 * NS < Ktot) load_stage(nb, k0 + 16 * NS);
+            else if (t_next < total_tiles) { setup_load(t_next); load_stage(t_next % NB, 0); }
             constexpr int WI[6] = {0, 1, 2, 0, 1, 0};
             constexpr int XI[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
@@ -816,43 +814,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv_x3_gemm_k
                                                                                           acc[r][t0 + tt], 0, 0, 0);
                     if constexpr (NT > NTH) __builtin_amdgcn_sched_barrier(0);
                 }
-            }
-        };
-        if constexpr (PF == 1) {
-            for (int k0 = 0; k0 < Ktot; k0 += 16 * NS) {
-                __syncthreads();
-                store_stage(ra[0], rb[0]);
-                __syncthreads();
-                if (k0 + 16 * NS < Ktot) load_stage(nb, k0 + 16 * NS, ra[0], rb[0]);
-                else if (t_next < total_tiles) { setup_load(t_next); load_stage(t_next % NB, 0, ra[0], rb[0]); }
-                mfma_stage();
-            }
-        } else {
-            // loads of the stage two ahead, into the register set the stage just cut from: the same tile, or -- at a tile's last two stages -- stage
-            // kk - Ktot of the next tile (the switch to its offsets happens once, at its stage 0); past the last tile: out-of-range offsets
-            auto issue_ahead = [&](int kk, float4 (&RA)[A_IT], float4 (&RB)[B_IT]) {
-                if (kk < Ktot) { load_stage(nb, kk, RA, RB); return; }
-                if (kk == Ktot) {
-                    if (t_next < total_tiles) setup_load(t_next);
-                    else {
-                        l_live = false;
-#pragma unroll
-                        for (int it = 0; it < A_IT; ++it) a_voff[it] = OOB;
-                    }
-                }
-                load_stage(t_next < total_tiles ? t_next % NB : 0, kk - Ktot, RA, RB);
-            };
-            for (int k0 = 0; k0 < Ktot; k0 += 2 * 16 * NS) {
-                __syncthreads();
-                store_stage(ra[0], rb[0]);
-                __syncthreads();
-                issue_ahead(k0 + 2 * 16 * NS, ra[0], rb[0]);
-                mfma_stage();
-                __syncthreads();
-                store_stage(ra[PF - 1], rb[PF - 1]);
-                __syncthreads();
-                issue_ahead(k0 + 3 * 16 * NS, ra[PF - 1], rb[PF - 1]);
-                mfma_stage();
             }
         }
         {   // epilogue: the MFMA leaves lane (m, hi) with channels 8q+4hi..+3 of pixel x0+m in each 32-block; stores in the full-line layout (conv.h f32_line_store)
@@ -1028,7 +989,7 @@ int launch_x3d(ConvArgs a, hipStream_t st) {
     return 0;
 }
 
-template <int MODE, int BN, int WAVES, int PF = 1>
+template <int MODE, int BN, int WAVES>
 int launch_x3_gemm(ConvArgs a, hipStream_t st) {
     constexpr int TH = 2 * WAVES;
     a.tiles_x = (a.W + TW - 1) / TW;
@@ -1037,7 +998,7 @@ int launch_x3_gemm(ConvArgs a, hipStream_t st) {
     const long long tiles = (long long)a.tiles_x * a.tiles_y * a.N * (a.Nout / BN);
     if (tiles <= 0) return 0;
     if (tiles > 0x7fffffffLL) return ELD_ENOTSUP;
-    auto kern = conv_x3_gemm_kernel<MODE, BN, WAVES, PF>;
+    auto kern = conv_x3_gemm_kernel<MODE, BN, WAVES>;
     static EldAttrOnce once;
     { const int rc = once.ensure(kern, lds_bytes); if (rc) return rc; }
     int per_cu = (int)((160 * 1024) / lds_bytes);
@@ -1108,18 +1069,7 @@ int launch_conv_x3_gemm(const ConvArgs& a, int mode, hipStream_t st) {
     if (a.Nout % 64 || a.C0 % 32 || a.C1 != 0 || src_img >= 0xFFFFFFF0ull) return ELD_ENOTSUP;
     // (an 8-wave 16 x 32 x 128 tile, <.., 128, 8>, was measured at the same speed as the 4-wave 8 x 32 x 64 one: these launches are not bound by
     // the operand cuts; the small tile wastes less on the 89 x 133 / 178 x 266 levels)
-    // ELD_X3G (round 5 experiments): 1 = the 16 x 32 x 128 tile (8 waves), 2 = that tile with loads two stages ahead, 3 = the 8 x 32 x 64 tile with loads two stages ahead
-    static const int variant = [] { const char* e = getenv("ELD_X3G"); return e ? atoi(e) : 0; }();
-    const int Ktot = mode == CONV_1X1 ? a.C0 : 4 * a.C0;
-    const bool pf2 = (variant == 2 || variant == 3) && Ktot % 64 == 0;
-    const bool big = (variant == 1 || variant == 2) && a.Nout % 128 == 0;
-    if (mode == CONV_1X1 && a.epi == EPI_CONVT_FWD) {
-        if (big) return pf2 ? launch_x3_gemm<CONV_1X1, 128, 8, 2>(a, st) : launch_x3_gemm<CONV_1X1, 128, 8>(a, st);
-        return pf2 ? launch_x3_gemm<CONV_1X1, 64, 4, 2>(a, st) : launch_x3_gemm<CONV_1X1, 64, 4>(a, st);
-    }
-    if (mode == CONV_GATHER2X2 && a.epi == EPI_GRAD && a.split == a.Nout) {
-        if (big) return pf2 ? launch_x3_gemm<CONV_GATHER2X2, 128, 8, 2>(a, st) : launch_x3_gemm<CONV_GATHER2X2, 128, 8>(a, st);
-        return pf2 ? launch_x3_gemm<CONV_GATHER2X2, 64, 4, 2>(a, st) : launch_x3_gemm<CONV_GATHER2X2, 64, 4>(a, st);
-    }
+    if (mode == CONV_1X1 && a.epi == EPI_CONVT_FWD) return launch_x3_gemm<CONV_1X1, 64, 4>(a, st);
+    if (mode == CONV_GATHER2X2 && a.epi == EPI_GRAD && a.split == a.Nout) return launch_x3_gemm<CONV_GATHER2X2, 64, 4>(a, st);
     return ELD_ENOTSUP;
 }
