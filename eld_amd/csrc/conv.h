@@ -45,7 +45,6 @@ struct ConvArgs {
     int tile_h, tile_w; // conv_x3d / conv_bfd: the launch's tile shape (rows x columns of pixels; tile_h * tile_w <= the kernel's pixel count)
     int dtype;          // DT_F32 / DT_BF16
     int algo;           // fp32 product scheme of THIS call: 0 fp32 MFMA, 1 three bf16 pieces, 2 two fp16 pieces; < 0 = process default (conv_fp32_algo)
-    int pp_mode;        // conv_x3_kernel ping-pong experiment: 2 = no s_setprio flips around the staging section
     int dbg;            // ablation switches for tools/ (env ELD_CONV_DBG): 1 skip epilogue, 4 skip staging loads, 8/16 skip slab/halo stores (conv_x3), 64 one workgroup per CU
     unsigned long long* prof;   // dev tool (eld_debug_conv_prof): per-stage s_memtime stamps of the first workgroups; null in production
     // two-piece fp16 product scheme (conv_fp32_algo 2): device floats holding an upper bound of max|.| of each operand tensor

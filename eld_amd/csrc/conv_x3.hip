@@ -102,16 +102,14 @@ __device__ __forceinline__ void pool_epilogue(const ConvArgs& a, const f32x16 (&
 // 4-wave workgroups per CU drift: when their matrix segments overlap, the waves of a SIMD halve each other's MFMA rate, segment lengths scatter
 // and every barrier waits for the slowest wave: 52 % matrix-pipe busy.)  The halves execute the same number of barriers: half 1's extra one at the start
 // is half 0's extra one at the end, and a half with one tile fewer runs that tile's stages as bare barrier pairs.
-// (The body is a device function instantiated once per half: with the half a compile-time constant the LDS addresses stay immediates -- as a run-time
-// base they cost 23 registers, and the spilled halo offsets came back from scratch one wait at a time in front of every halo load.)
-template <int BN, int RPW, bool DB, bool BFIRST, bool PP, int HALF>
-__device__ __forceinline__ void conv_x3_body(const ConvArgs& a) {
+template <int BN, int RPW, bool DB, bool BFIRST = false, bool PP = false>
+__global__ __launch_bounds__(PP ? 512 : 256, 2) void conv_x3_kernel(const ConvArgs a) {
     constexpr int CK = 16;
     constexpr int TH = 4 * RPW, NT = BN / 32, A_PIX = (TH + 2) * (TW + 2);
     constexpr int A_WORDS = A_PIX * PX, B_ROWS = 3 * BN;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int half = HALF;
-    float* ldsA = lds + HALF * (A_WORDS + B_ROWS * PX);
+    const int half = PP ? (int)(threadIdx.x >> 8) : 0;                 // wave-uniform
+    float* ldsA = lds + half * (A_WORDS + B_ROWS * PX);
     float* ldsB = ldsA + A_WORDS;
 
     const int tid = PP ? (int)(threadIdx.x & 255) : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -218,7 +216,7 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a) {
             const bool last_chunk = c0 + CK >= Cin;
 #pragma unroll BFIRST ? 3 : 1            // (BFIRST: three explicit stages, so that every wait sees a static queue -- see the issue order below)
             for (int ky = 0; ky < 3; ++ky) {
-                if (a.pp_mode != 2) __builtin_amdgcn_s_setprio(3);   // the short staging section goes ahead of the co-resident workgroup's MFMA stream
+                __builtin_amdgcn_s_setprio(3);   // the short staging section goes ahead of the co-resident workgroup's MFMA stream
                 __syncthreads();                 // every wave is done with the previous stage's operands
                 if (ky == 0) store_A();
                 store_B();
@@ -240,7 +238,7 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a) {
                     if constexpr (!BFIRST) issue_B();
                 }
                 uint4 fx[DB ? 2 : 1][3][RPW], fw[DB ? 2 : 1][3][NT];
-                if (a.pp_mode != 2) __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_setprio(0);
                 auto read_tap = [&](int kx, uint4 (&X)[3][RPW], uint4 (&Wt)[3][NT]) {
 #pragma unroll
                     for (int r = 0; r < RPW; ++r) {
@@ -368,14 +366,6 @@ __device__ __forceinline__ void conv_x3_body(const ConvArgs& a) {
         for (int d = (n_half0 - n_mine) * stages; d > 0; --d) { __syncthreads(); __syncthreads(); }
         if (half == 0) __syncthreads();
     }
-}
-
-template <int BN, int RPW, bool DB, bool BFIRST = false, bool PP = false>
-__global__ __launch_bounds__(PP ? 512 : 256, 2) void conv_x3_kernel(const ConvArgs a) {
-    if constexpr (PP) {
-        if (threadIdx.x < 256) conv_x3_body<BN, RPW, DB, BFIRST, true, 0>(a);      // wave-uniform: waves 0-3 / 4-7
-        else conv_x3_body<BN, RPW, DB, BFIRST, true, 1>(a);
-    } else conv_x3_body<BN, RPW, DB, BFIRST, false, 0>(a);
 }
 
 // =============================================================================================================================
@@ -1091,7 +1081,6 @@ int launch_conv_x3(const ConvArgs& a_in, hipStream_t st) {
     // round-4 order for A/B runs
     static const int bfirst = [] { const char* e = getenv("ELD_X3_BFIRST"); return e ? atoi(e) : 1; }();
     static const int pp = [] { const char* e = getenv("ELD_X3_PP"); return e ? atoi(e) : 0; }();      // round 5 experiment: two phase-locked 4-wave halves in one workgroup
-    a.pp_mode = pp;
     if (pp) return launch_x3<32, 4, false, true, true>(a, st);
     if (bfirst) return launch_x3<32, 4, false, true>(a, st);
     return launch_x3<32, 4, false>(a, st);
