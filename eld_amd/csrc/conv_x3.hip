@@ -95,24 +95,16 @@ __device__ __forceinline__ void pool_epilogue(const ConvArgs& a, const f32x16 (&
     }
 }
 
-// PP (round 5, "ping-pong"): ONE 8-wave workgroup per CU made of two 4-wave halves, each the 4-wave kernel on its own tile stream and its own LDS region.
-// Wave w of half 0 and wave w of half 1 share a SIMD (waves are dealt to the four SIMDs in order).  Every segment of a half's program -- cut-and-store,
-// matrix work -- already begins with a barrier; as WORKGROUP barriers, with half 1 started one barrier late, they lock the halves in opposite phases:
-// while one half's waves cut, the other half's run MFMAs, and a SIMD's matrix pipe is never asked for by both of its waves at once.  (Two independent
-// 4-wave workgroups per CU drift: when their matrix segments overlap, the waves of a SIMD halve each other's MFMA rate, segment lengths scatter
-// and every barrier waits for the slowest wave: 52 % matrix-pipe busy.)  The halves execute the same number of barriers: half 1's extra one at the start
-// is half 0's extra one at the end, and a half with one tile fewer runs that tile's stages as bare barrier pairs.
-template <int BN, int RPW, bool DB, bool BFIRST = false, bool PP = false>
-__global__ __launch_bounds__(PP ? 512 : 256, 2) void conv_x3_kernel(const ConvArgs a) {
+template <int BN, int RPW, bool DB, bool BFIRST = false>
+__global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
     constexpr int CK = 16;
     constexpr int TH = 4 * RPW, NT = BN / 32, A_PIX = (TH + 2) * (TW + 2);
     constexpr int A_WORDS = A_PIX * PX, B_ROWS = 3 * BN;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int half = PP ? (int)(threadIdx.x >> 8) : 0;                 // wave-uniform
-    float* ldsA = lds + half * (A_WORDS + B_ROWS * PX);
-    float* ldsB = ldsA + A_WORDS;
+    float* ldsA = lds;
+    float* ldsB = lds + A_WORDS;
 
-    const int tid = PP ? (int)(threadIdx.x & 255) : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 31, hi = lane >> 5;
     const int NB = a.Nout / BN;
     const int Cin = a.C0 + a.C1;
@@ -186,13 +178,8 @@ __global__ __launch_bounds__(PP ? 512 : 256, 2) void conv_x3_kernel(const ConvAr
         }
     };
 
-    const int stride = PP ? 2 * (int)gridDim.x : (int)gridDim.x;
-    int t = PP ? 2 * (int)blockIdx.x + half : (int)blockIdx.x;
-    auto count_tiles = [&](int first) { return first < total_tiles ? (total_tiles - first + stride - 1) / stride : 0; };
-    const int n_mine = count_tiles(t), n_half0 = PP ? count_tiles(2 * (int)blockIdx.x) : n_mine;      // n_half0 >= half 1's count >= n_half0 - 1
-    if (n_half0 == 0) return;                                          // (the whole workgroup: no barrier has been executed)
-    if (PP && half == 1) __syncthreads();                              // half 1 runs one barrier behind half 0: opposite phases from here on
-    if (n_mine > 0) {
+    int t = blockIdx.x;
+    if (t >= total_tiles) return;
     setup_load(t);
     load_A(0);
     {
@@ -203,7 +190,7 @@ __global__ __launch_bounds__(PP ? 512 : 256, 2) void conv_x3_kernel(const ConvAr
     for (;;) {
         int nb, img, y0, x0;
         decode(t, nb, img, y0, x0);
-        const int t_next = t + stride;
+        const int t_next = t + gridDim.x;
         f32x16 acc[RPW][NT];
 #pragma unroll
         for (int r = 0; r < RPW; ++r)
@@ -359,12 +346,6 @@ __global__ __launch_bounds__(PP ? 512 : 256, 2) void conv_x3_kernel(const ConvAr
         }
         if (t_next >= total_tiles) break;
         t = t_next;
-    }
-    }
-    if constexpr (PP) {                                                // the same number of barriers in both halves (see the head of the kernel)
-        const int stages = 3 * (Cin / CK);
-        for (int d = (n_half0 - n_mine) * stages; d > 0; --d) { __syncthreads(); __syncthreads(); }
-        if (half == 0) __syncthreads();
     }
 }
 
@@ -945,27 +926,24 @@ int launch_x3_splitk_finish(const ConvArgs& a, hipStream_t st) {
     return 0;
 }
 
-template <int BN, int RPW, bool DB, bool BFIRST = false, bool PP = false>
+template <int BN, int RPW, bool DB, bool BFIRST = false>
 int launch_x3(ConvArgs a, hipStream_t st) {
     constexpr int TH = 4 * RPW;
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + TH - 1) / TH;
-    const size_t lds_half = (size_t)((TH + 2) * (TW + 2) + 3 * BN) * PX * sizeof(float);
-    const size_t lds_bytes = PP ? 2 * lds_half : lds_half;             // PP: one 8-wave workgroup = two 4-wave halves with their own regions
+    const size_t lds_bytes = (size_t)((TH + 2) * (TW + 2) + 3 * BN) * PX * sizeof(float);
     const long long tiles = (long long)a.tiles_x * a.tiles_y * a.N * (a.Nout / BN);
     if (tiles <= 0) return 0;
-    if (tiles > 0x3fffffffLL) return ELD_ENOTSUP;
-    if (lds_bytes > 160 * 1024) return ELD_ENOTSUP;
-    auto kern = conv_x3_kernel<BN, RPW, DB, BFIRST, PP>;
+    if (tiles > 0x7fffffffLL) return ELD_ENOTSUP;
+    auto kern = conv_x3_kernel<BN, RPW, DB, BFIRST>;
     static EldAttrOnce once;
     { const int rc = once.ensure(kern, lds_bytes); if (rc) return rc; }
     int per_cu = (int)((160 * 1024) / lds_bytes);
     if (per_cu > 2) per_cu = 2;
     if (per_cu < 1) per_cu = 1;
     long long grid = (long long)eld_num_cus() * per_cu;
-    const long long items = PP ? (tiles + 1) / 2 : tiles;              // PP: a workgroup walks two tile streams
-    if (grid > items) grid = items;
-    ELD_LAUNCH(kern, dim3((unsigned)grid), dim3(PP ? 512 : 256), lds_bytes, st, a);
+    if (grid > tiles) grid = tiles;
+    ELD_LAUNCH(kern, dim3((unsigned)grid), dim3(256), lds_bytes, st, a);
     ELD_LAUNCH_CHECK();
     return 0;
 }
@@ -1080,8 +1058,6 @@ int launch_conv_x3(const ConvArgs& a_in, hipStream_t st) {
     // round 5: the next stage's slab loads are issued AHEAD of the halo loads (template BFIRST; -2.7 % per launch, same box); ELD_X3_BFIRST=0 restores the
     // round-4 order for A/B runs
     static const int bfirst = [] { const char* e = getenv("ELD_X3_BFIRST"); return e ? atoi(e) : 1; }();
-    static const int pp = [] { const char* e = getenv("ELD_X3_PP"); return e ? atoi(e) : 0; }();      // round 5 experiment: two phase-locked 4-wave halves in one workgroup
-    if (pp) return launch_x3<32, 4, false, true, true>(a, st);
     if (bfirst) return launch_x3<32, 4, false, true>(a, st);
     return launch_x3<32, 4, false>(a, st);
 }
