@@ -56,6 +56,7 @@ def close(got, ref64, tol=1e-5, scale=None):
 CASES = [  # N, H, W, C0, C1, Cout
     (2, 20, 37, 32, 0, 32), (1, 9, 133, 64, 0, 64), (1, 16, 40, 32, 32, 32), (2, 12, 33, 64, 64, 64),
     (1, 8, 34, 16, 0, 32), (1, 7, 31, 128, 0, 256), (1, 5, 17, 512, 0, 64),
+    (1, 16, 96, 32, 0, 32), (3, 16, 32, 32, 0, 32), (1, 48, 160, 32, 32, 32),      # odd tile counts of the 32-output-channel kernel (3, 3, 15 tiles)
 ]
 
 
