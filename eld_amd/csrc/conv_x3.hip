@@ -96,7 +96,7 @@ __device__ __forceinline__ void pool_epilogue(const ConvArgs& a, const f32x16 (&
 }
 
 template <int BN, int RPW, bool DB, bool BFIRST = false>
-__global__ __launch_bounds__(256, RPW == 2 ? 3 : 2) void conv_x3_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
     constexpr int CK = 16;
     constexpr int TH = 4 * RPW, NT = BN / 32, A_PIX = (TH + 2) * (TW + 2);
     constexpr int A_WORDS = A_PIX * PX, B_ROWS = 3 * BN;
@@ -939,7 +939,7 @@ int launch_x3(ConvArgs a, hipStream_t st) {
     static EldAttrOnce once;
     { const int rc = once.ensure(kern, lds_bytes); if (rc) return rc; }
     int per_cu = (int)((160 * 1024) / lds_bytes);
-    if (per_cu > (RPW == 2 ? 3 : 2)) per_cu = RPW == 2 ? 3 : 2;
+    if (per_cu > 2) per_cu = 2;
     if (per_cu < 1) per_cu = 1;
     long long grid = (long long)eld_num_cus() * per_cu;
     if (grid > tiles) grid = tiles;
@@ -1058,8 +1058,6 @@ int launch_conv_x3(const ConvArgs& a_in, hipStream_t st) {
     // round 5: the next stage's slab loads are issued AHEAD of the halo loads (template BFIRST; -2.7 % per launch, same box); ELD_X3_BFIRST=0 restores the
     // round-4 order for A/B runs
     static const int bfirst = [] { const char* e = getenv("ELD_X3_BFIRST"); return e ? atoi(e) : 1; }();
-    static const int th8 = [] { const char* e = getenv("ELD_X3_TH8"); return e ? atoi(e) : 0; }();      // round 5 experiment: 8-row tiles, three workgroups per CU
-    if (th8) return launch_x3<32, 2, false, true>(a, st);
     if (bfirst) return launch_x3<32, 4, false, true>(a, st);
     return launch_x3<32, 4, false>(a, st);
 }
