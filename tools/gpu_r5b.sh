@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 5, call B: quick regression of what changed since call A, then same-box A/B of the experimental tile variants of the fp32 laggard layers
+# NOTE: the experimental switches this script toggles were removed after the measurement (profiles/r05_ab_notes.md names the commits that carried them).
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/${1:-r5b}; mkdir -p $O

@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 5, call C: batched weight-gradient reduction (small steps) + counted halo wait (ELD_X3D_KEEPA): regression, then same-box A/B on the full frame and on the 512 x 512 patch
+# NOTE: the experimental switches this script toggles were removed after the measurement (profiles/r05_ab_notes.md names the commits that carried them).
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/${1:-r5c}; mkdir -p $O
