@@ -39,6 +39,13 @@ struct ConvArgs {
     int split;
     const void* act0;   // EPI_GRAD: saved post-activation tensor (layout of out0) -> multiply by lrelu slope; may be null
     const void* act1;
+    // Slope codes (round 5, fp32 three-piece kernels): 2 bits per element of an activation tensor -- bit 0 = negative, bit 1 = zero -- 16 elements per 32-bit word
+    // in the MFMA result layout: word ((pixel * (C / 32) + block) * 2 + hi) holds, at bits 2i .. 2i+1 (i = 4q + j), channel 8q + 4hi + j of the 32-channel block.
+    // EPI_FWD with lrelu: codes_out != null -> also written for the layer's output.  EPI_GRAD: codes0 / codes1 != null -> read INSTEAD of act0 / act1
+    // (1/16 of the bytes, one load per row and block instead of four).
+    unsigned* codes_out;
+    const unsigned* codes0;
+    const unsigned* codes1;
     int Cout_t;         // EPI_CONVT_FWD: real Cout (Nout = 4*Cout_t, n = tap*Cout_t + co)
     int tiles_x, tiles_y;
     int vp;             // virtual-row pitch of the strip tiles_y was counted on (vrow_pitch; set by the launchers that tile the strip)
@@ -103,6 +110,21 @@ __device__ __forceinline__ void lrelu4(f32x16& acc, int i, float sl) {
     acc[i] = fmax_raw(t01.x, s01.x); acc[i + 1] = fmax_raw(t01.y, s01.y); acc[i + 2] = fmax_raw(t23.x, s23.x); acc[i + 3] = fmax_raw(t23.y, s23.y);
 }
 __device__ __forceinline__ float lrelu_slope(float y) { return y > 0.f ? 1.0f : (y < 0.f ? 0.2f : 0.6f); }
+// 2-bit slope code of a post-activation value (its sign is the pre-activation's): bit 0 = sign bit, bit 1 = zero (+0 or -0); lrelu_slope of the code
+__device__ __forceinline__ unsigned slope_code(float v) {
+    const unsigned b = __float_as_uint(v);
+    return (b >> 31) | ((b << 1) == 0u ? 2u : 0u);
+}
+__device__ __forceinline__ unsigned slope_codes16(const f32x16& acc) {
+    unsigned w = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w |= slope_code(acc[i]) << (2 * i);
+    return w;
+}
+__device__ __forceinline__ float slope_of_code(unsigned w, int i) {
+    const unsigned c = w >> (2 * i);
+    return (c & 2u) ? 0.6f : ((c & 1u) ? 0.2f : 1.0f);
+}
 
 // bfloat16 <-> float.  Rounding to nearest even is the hardware's (v_cvt_pk_bf16_f32, one instruction per PAIR of values): a software
 // round costs five VALU instructions per value, which made the bf16 conv epilogues VALU-bound (DESIGN.md, bf16 path).

@@ -140,7 +140,7 @@ __device__ __forceinline__ void first_cut(float v, bf16_t (&p)[NPC]) {      // v
 
 template <typename TO, int NPC>
 __global__ __launch_bounds__(256) void conv_first_fwd_mma_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                                 TO* __restrict__ out, int N, int H, int W, int lrelu) {
+                                                                 TO* __restrict__ out, int N, int H, int W, int lrelu, unsigned* __restrict__ codes) {
     constexpr int CIN = 4, HPX = FHP + 2;                     // + 2 pixels: slot 3 of the last halo row reads one pixel past it (zero weights, finite data)
     __shared__ __attribute__((aligned(16))) bf16_t halo[NPC][HPX][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, hi = lane >> 5;
@@ -242,6 +242,13 @@ __global__ __launch_bounds__(256) void conv_first_fwd_mma_kernel(const float* __
             }
             TO* blk = out + ((size_t)(img * H + (yok ? y : 0)) * W + x0) * 32;
             if constexpr (sizeof(TO) == 4) {
+                if (codes != nullptr && yok && x0 + m < W) {             // slope codes of the finished values (conv.h ConvArgs::codes_out): word (pixel, hi) of the one 32-channel block
+                    unsigned cwd = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        cwd |= (slope_code(v[q].x) | (slope_code(v[q].y) << 2) | (slope_code(v[q].z) << 4) | (slope_code(v[q].w) << 6)) << (8 * q);
+                    codes[((size_t)(img * H + y) * W + x0 + m) * 2 + hi] = cwd;
+                }
                 f32_line_store(v, reinterpret_cast<float*>(blk), 32, lane, yok, W - x0);
             } else {
                 uint2 pk[4];
@@ -258,14 +265,16 @@ __global__ __launch_bounds__(256) void conv_first_fwd_mma_kernel(const float* __
     }
 }
 
+static int first_mma_on() { static const int mma = [] { const char* e = getenv("ELD_FIRST_MMA"); return e ? atoi(e) : 1; }(); return mma; }      // ELD_FIRST_MMA=0: the K = 36 kernel on the fp32 MFMA for every Cin
+bool conv_first_writes_codes(int Cin) { return Cin == 4 && first_mma_on(); }      // which launches honour the `codes` argument of launch_conv_first_fwd
 template <typename TO>
-static int launch_first_t(const float* x, const float* w, const float* bias, TO* out, int N, int Cin, int H, int W, int lrelu, hipStream_t st) {
+static int launch_first_t(const float* x, const float* w, const float* bias, TO* out, int N, int Cin, int H, int W, int lrelu, hipStream_t st, unsigned* codes = nullptr) {
     const int tiles = ((W + FTW - 1) / FTW) * ((H + FTH - 1) / FTH) * N;
     if (tiles <= 0) return 0;
     const int grid = tiles < 2048 ? tiles : 2048;
-    static const int mma = [] { const char* e = getenv("ELD_FIRST_MMA"); return e ? atoi(e) : 1; }();      // ELD_FIRST_MMA=0: the K = 36 kernel on the fp32 MFMA for every Cin
+    const int mma = first_mma_on();
     if (Cin == 4 && mma) {                        // packed Bayer raw: the bf16-MFMA kernel (fp32 output: exact three-piece products; bf16 output: two pieces)
-        ELD_LAUNCH((conv_first_fwd_mma_kernel<TO, sizeof(TO) == 4 ? 3 : 2>), dim3(grid), dim3(256), 0, st, x, w, bias, out, N, H, W, lrelu);
+        ELD_LAUNCH((conv_first_fwd_mma_kernel<TO, sizeof(TO) == 4 ? 3 : 2>), dim3(grid), dim3(256), 0, st, x, w, bias, out, N, H, W, lrelu, codes);
         ELD_LAUNCH_CHECK();
         return 0;
     }
@@ -280,8 +289,8 @@ static int launch_first_t(const float* x, const float* w, const float* bias, TO*
     return 0;
 }
 
-int launch_conv_first_fwd(const float* x, const float* w, const float* bias, float* out, int N, int Cin, int H, int W, int lrelu, hipStream_t st) {
-    return launch_first_t<float>(x, w, bias, out, N, Cin, H, W, lrelu, st);
+int launch_conv_first_fwd(const float* x, const float* w, const float* bias, float* out, int N, int Cin, int H, int W, int lrelu, hipStream_t st, unsigned* codes) {
+    return launch_first_t<float>(x, w, bias, out, N, Cin, H, W, lrelu, st, codes);
 }
 int launch_conv_first_fwd_bf16(const float* x, const float* w, const float* bias, bf16_t* out, int N, int Cin, int H, int W, int lrelu, hipStream_t st) {
     return launch_first_t<bf16_t>(x, w, bias, out, N, Cin, H, W, lrelu, st);

@@ -299,6 +299,33 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
 #pragma unroll
                         for (int r = 0; r < RPW; ++r) bias_lrelu4(acc[r][tt], 4 * q, bq, sl);
                     }
+                if (a.codes_out != nullptr && xok) {                     // slope codes of the finished values, for the backward-data epilogue that will want them
+#pragma unroll
+                    for (int r = 0; r < RPW; ++r) {
+                        const int y = y0 + wave * RPW + r;
+                        if (y >= a.H) continue;
+                        const size_t pix = (size_t)(img * a.H + y) * a.W + x;
+#pragma unroll
+                        for (int tt = 0; tt < NT; ++tt)
+                            a.codes_out[(pix * (size_t)(a.Nout >> 5) + (size_t)(nb * NT + tt)) * 2 + hi] = slope_codes16(acc[r][tt]);
+                    }
+                }
+            }
+            unsigned cw[RPW][NT];                                      // EPI_GRAD with slope codes: the whole tile's words, one load each, issued together
+            if (a.epi != EPI_FWD && (a.codes0 != nullptr || a.codes1 != nullptr)) {
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) {
+                    const int y = y0 + wave * RPW + r;
+                    const size_t pix = (size_t)(img * a.H + (y < a.H ? y : 0)) * a.W + (xok ? x : 0);
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt) {
+                        const int nb32 = nb * BN + tt * 32;
+                        const bool lo = nb32 < a.split;
+                        const unsigned* cd = lo ? a.codes0 : a.codes1;
+                        const int C = lo ? a.split : a.Nout - a.split, cb = lo ? nb32 : nb32 - a.split;
+                        cw[r][tt] = cd != nullptr ? cd[(pix * (size_t)(C >> 5) + (size_t)(cb >> 5)) * 2 + hi] : 0u;
+                    }
+                }
             }
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
@@ -323,7 +350,14 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
                         const int cb = lo ? nb32 : nb32 - a.split;
                         blk = static_cast<float*>(lo ? a.out0 : a.out1) + (rowpix + x0) * C + cb;
                         const float* act = static_cast<const float*>(lo ? a.act0 : a.act1);
-                        if (act != nullptr) {
+                        if ((lo ? a.codes0 : a.codes1) != nullptr) {
+                            const unsigned w = cw[r][tt];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                v[q].x *= slope_of_code(w, 4 * q); v[q].y *= slope_of_code(w, 4 * q + 1);
+                                v[q].z *= slope_of_code(w, 4 * q + 2); v[q].w *= slope_of_code(w, 4 * q + 3);
+                            }
+                        } else if (act != nullptr) {
                             float4 s[4];
 #pragma unroll
                             for (int q = 0; q < 4; ++q) s[q] = *reinterpret_cast<const float4*>(act + pix * C + cb + 4 * hi + 8 * q);
@@ -381,6 +415,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
     constexpr int CK = 16, THREADS = 64 * WAVES;
     constexpr int TH = WAVES * RPW, NT = BN / 32, A_PIX = (TH + 2) * (TW + 2);
     constexpr int B_ROWS = 3 * BN;
+    constexpr bool CODES = NT <= 2;                                     // slope codes (ConvArgs::codes_out / codes0 / codes1) are honoured by the 32- / 64-channel tiles
     constexpr int B_WORDS = (B_ROWS * PX * 4 + 1023) / 1024 * 256;     // slab stride (global and LDS): rows padded to whole 1 KiB DMA pieces
     constexpr int B_PIECES = B_WORDS * 4 / 1024;                      // 1 KiB per wave-instruction
     constexpr int DMA_IT = (B_PIECES + WAVES - 1) / WAVES;
@@ -624,12 +659,36 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
 #pragma unroll
                         for (int r = 0; r < RPW; ++r) bias_lrelu4(acc[r][tt], 4 * q, bq, sl);
                     }
+                // slope codes of the finished values (conv.h ConvArgs::codes_out); the 32- / 64-channel tiles only: the 128-channel tile has no register to spare
+                // (its instantiation spills 40 bytes more with this code, checked offline) and its launches gain least (34 ... 173 us each)
+                if (CODES && a.codes_out != nullptr) {
+#pragma unroll
+                    for (int r = 0; r < RPW; ++r) {
+                        size_t pix;
+                        if (!slot_pixel(r, m, pix)) continue;
+#pragma unroll
+                        for (int tt = 0; tt < NT; ++tt)
+                            a.codes_out[(pix * (size_t)(a.Nout >> 5) + (size_t)(nb * NT + tt)) * 2 + hi] = slope_codes16(acc[r][tt]);
+                    }
+                }
             }
+            const bool coded = CODES && a.epi != EPI_FWD && (a.codes0 != nullptr || a.codes1 != nullptr);
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
                 size_t pix, pix0, pix1;
                 slot_pixel(r, m, pix);                                  // own slot (0 where there is none: the load re-reads a valid pixel)
                 const bool ok0 = slot_pixel(r, lane & 15, pix0), ok1 = slot_pixel(r, (lane & 15) + 16, pix1);
+                unsigned cw[NT];                                        // slope-code words of this row's channel blocks: one load each, issued together
+                if (coded) {
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt) {
+                        const int nb32 = nb * BN + tt * 32;
+                        const bool lo = nb32 < a.split;
+                        const unsigned* cd = lo ? a.codes0 : a.codes1;
+                        const int C = lo ? a.split : a.Nout - a.split, cb = lo ? nb32 : nb32 - a.split;
+                        cw[tt] = cd != nullptr ? cd[(pix * (size_t)(C >> 5) + (size_t)(cb >> 5)) * 2 + hi] : 0u;
+                    }
+                }
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt) {
                     const int nb32 = nb * BN + tt * 32;
@@ -647,7 +706,14 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
                         const int cb = lo ? nb32 : nb32 - a.split;
                         blk = static_cast<float*>(lo ? a.out0 : a.out1) + cb;
                         const float* act = static_cast<const float*>(lo ? a.act0 : a.act1);
-                        if (act != nullptr) {
+                        if (CODES && (lo ? a.codes0 : a.codes1) != nullptr) {
+                            const unsigned w = cw[tt];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                v[q].x *= slope_of_code(w, 4 * q); v[q].y *= slope_of_code(w, 4 * q + 1);
+                                v[q].z *= slope_of_code(w, 4 * q + 2); v[q].w *= slope_of_code(w, 4 * q + 3);
+                            }
+                        } else if (act != nullptr) {
                             float4 s[4];
 #pragma unroll
                             for (int q = 0; q < 4; ++q) s[q] = *reinterpret_cast<const float4*>(act + pix * C + cb + 4 * hi + 8 * q);

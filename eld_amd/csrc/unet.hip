@@ -107,9 +107,10 @@ inline void take_amax(ConvArgs& a) { a.algo = g_algo; a.amax_in0 = g_am.in0; a.a
 inline void take_amax(WgradArgs& a) { a.algo = g_algo; a.amax_g = g_am.in0; a.amax_x0 = g_am.w; a.amax_x1 = g_am.in1; g_am = Amax(); }      // wgrad: in0 = G, w = X0, in1 = X1
 enum { S_W = 0, S_X = 23, S_EA = 24, S_EB = 29, S_UP = 34, S_DA = 38, S_DB = 42, S_GA = 46, S_GB = 47, S_SKIP = 48, S_COUNT = 64 };
 int conv_fwd(const float* in0, int C0, const float* in1, int C1, const float* wp, const float* bias, float* out, int N, int H, int W,
-             int Cout, int lrelu, hipStream_t st, float* pool_out = nullptr) {
+             int Cout, int lrelu, hipStream_t st, float* pool_out = nullptr, unsigned* codes_out = nullptr) {
     ConvArgs a = {};
     a.pool_out = pool_out;
+    a.codes_out = codes_out;
     a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1; a.wp = wp; a.N = N; a.H = H; a.W = W; a.Nout = Cout;
     a.epi = EPI_FWD; a.bias = bias; a.lrelu = lrelu; a.out0 = out;
     a.kpart = g_kp.p; a.kpart_floats = g_kp.floats;
@@ -119,8 +120,9 @@ int conv_fwd(const float* in0, int C0, const float* in1, int C1, const float* wp
 
 // g: [N,H,W,Cout] -> din (Cin channels, split over out0/out1), wb packed [9][Cin][Cout]
 int conv_bwd_data(const float* g, const float* wb, float* out0, float* out1, int split, const float* act0, const float* act1, int N, int H,
-                  int W, int Cin, int Cout, hipStream_t st) {
+                  int W, int Cin, int Cout, hipStream_t st, const unsigned* codes0 = nullptr) {
     ConvArgs a = {};
+    a.codes0 = codes0;
     a.in0 = g; a.C0 = Cout; a.wp = wb; a.N = N; a.H = H; a.W = W; a.Nout = Cin;
     a.epi = EPI_GRAD; a.out0 = out0; a.out1 = out1; a.split = split; a.act0 = act0; a.act1 = act1;
     a.kpart = g_kp.p; a.kpart_floats = g_kp.floats;
@@ -191,6 +193,10 @@ struct Plan {
     size_t x16, ea[NLEV], eb[NLEV], pool[NLEV - 1], up[NLEV - 1], da[NLEV - 1], db[NLEV - 1];
     size_t gA, gB, skip[NLEV - 1], part, part_floats, amax;
     size_t head_part; // partials of the fused training head (eld_unet_forward_loss_ex -> the backward)
+    // slope codes (conv.h ConvArgs::codes_out) of the activations the 32- / 64-channel backward-data epilogues multiply by: ea[0], ea[1], da[0], da[1]
+    // (2 bits per element); written by the fp32 three-piece forward and read by its backward when `codes` is set (see make_plan)
+    size_t cd_ea[2], cd_da[2];
+    bool codes;
     size_t total;     // floats
 };
 
@@ -263,6 +269,13 @@ int make_plan(Plan& P, int N, int H, int W, int in_ch, int out_ch) {
     }
     P.part = take(pmax);
     P.part_floats = pmax;
+    // Slope codes only where the 64-channel level-1 layers run the unsplit 8-wave kernel (conv_x3.hip x3_slab_bn: every CU gets a 16-row tile): the
+    // split-K finish kernel of small problems does not write them.  A pure function of the shape: forward and backward agree without shared state.
+    P.codes = conv_tile_count(N, P.Hl[1], P.Wl[1], 16, false) >= eld_num_cus();
+    for (int l = 0; l < 2; ++l) {
+        P.cd_ea[l] = take(act(l, chan(l)) / 16 + 64);
+        P.cd_da[l] = take(act(l, chan(l)) / 16 + 64);
+    }
     P.amax = take(S_COUNT);
     P.total = off;
     return 0;
@@ -351,6 +364,8 @@ int unet_forward(const Plan& P, const float* x, const float* prm, float* out, fl
     if (h2 && hipMemsetAsync(am, 0, S_COUNT * sizeof(float), st) != hipSuccess) return (int)hipGetLastError();
     RC(pack_weights(P, prm, ws, hl ? PACK_BOTH : PACK_FWD, st, false, h2 ? am : nullptr));
     const bool first_direct = P.in_ch <= 4;        // conv1_1 straight from the NCHW planes (conv_first.hip)
+    const bool use_codes = P.codes && g_algo == 1;   // slope codes for the backward-data epilogues of levels 0 / 1 (Plan::codes)
+    auto CD = [&](size_t off) -> unsigned* { return use_codes ? reinterpret_cast<unsigned*>(ws + off) : nullptr; };
     if (first_direct && hl) {
         // fused training forward: the backward reads the caller's x (include/eld_amd.h: it must stay valid and unchanged until that call)
     } else if (first_direct) {
@@ -365,12 +380,13 @@ int unet_forward(const Plan& P, const float* x, const float* prm, float* out, fl
         const float* src = l == 0 ? ws + P.x16 : ws + P.pool[l - 1];
         const int cin = l == 0 ? 16 : chan(l - 1);
         if (l == 0 && first_direct) {
-            RC(launch_conv_first_fwd(x, prm + A.w_off, prm + A.b_off, ws + P.ea[0], N, P.in_ch, P.H, P.W, 1, st));
+            RC(launch_conv_first_fwd(x, prm + A.w_off, prm + A.b_off, ws + P.ea[0], N, P.in_ch, P.H, P.W, 1, st, CD(P.cd_ea[0])));
             if (h2) RC(launch_absmax(ws + P.ea[0], (size_t)N * P.H * P.W * chan(0), am + S_EA, st));
         } else {
             if (h2 && l == 0) RC(launch_absmax(ws + P.x16, (size_t)N * P.H * P.W * 16, am + S_X, st));
             AM(l == 0 ? S_X : S_EB + l - 1, -1, S_W + 2 * l, S_EA + l);          // pooled input is bounded by its source's bound
-            RC(conv_fwd(src, cin, nullptr, 0, ws + P.wp_fwd[2 * l], prm + A.b_off, ws + P.ea[l], N, P.Hl[l], P.Wl[l], chan(l), 1, st));
+            RC(conv_fwd(src, cin, nullptr, 0, ws + P.wp_fwd[2 * l], prm + A.b_off, ws + P.ea[l], N, P.Hl[l], P.Wl[l], chan(l), 1, st, nullptr,
+                        l < 2 ? CD(P.cd_ea[l]) : nullptr));
         }
         AM(S_EA + l, -1, S_W + 2 * l + 1, S_EB + l);
         // three-piece scheme: the conv's epilogue also writes the pooled tensor (no second pass over eb[l])
@@ -385,7 +401,8 @@ int unet_forward(const Plan& P, const float* x, const float* prm, float* out, fl
         AM(l == 3 ? S_EB + 4 : S_DB + l + 1, -1, S_W + iu, S_UP + l);
         RC(convt_fwd(src, ws + P.wp_fwd[iu], prm + P.L[iu].b_off, ws + P.up[l], N, P.Hl[l + 1], P.Wl[l + 1], chan(l + 1), chan(l), st));
         AM(S_UP + l, S_EB + l, S_W + iu + 1, S_DA + l);
-        RC(conv_fwd(ws + P.up[l], chan(l), ws + P.eb[l], chan(l), ws + P.wp_fwd[iu + 1], prm + P.L[iu + 1].b_off, ws + P.da[l], N, P.Hl[l], P.Wl[l], chan(l), 1, st));
+        RC(conv_fwd(ws + P.up[l], chan(l), ws + P.eb[l], chan(l), ws + P.wp_fwd[iu + 1], prm + P.L[iu + 1].b_off, ws + P.da[l], N, P.Hl[l], P.Wl[l], chan(l), 1, st, nullptr,
+                    l < 2 ? CD(P.cd_da[l]) : nullptr));
         AM(S_DA + l, -1, S_W + iu + 2, S_DB + l);
         RC(conv_fwd(ws + P.da[l], chan(l), nullptr, 0, ws + P.wp_fwd[iu + 2], prm + P.L[iu + 2].b_off, ws + P.db[l], N, P.Hl[l], P.Wl[l], chan(l), 1, st));
     }
@@ -455,6 +472,9 @@ int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd
     if (h2 && hipMemsetAsync(am + S_GA, 0, (S_COUNT - S_GA) * sizeof(float), st) != hipSuccess) return (int)hipGetLastError();
     if (!fused.packed) RC(pack_weights(P, prm, ws, PACK_BWD, st, false, h2 ? am : nullptr));
     float* gA = ws + P.gA; float* gB = ws + P.gB; float* part = ws + P.part;
+    // slope codes the forward left for levels 0 / 1 (Plan::codes); ea[0]'s only where the first layer's kernel writes them
+    const bool use_codes = P.codes && g_algo == 1;
+    auto CD = [&](size_t off, bool have = true) -> const unsigned* { return use_codes && have ? reinterpret_cast<const unsigned*>(ws + off) : nullptr; };
     auto gs = [&](const float* buf) { return buf == gA ? (int)S_GA : (int)S_GB; };                 // slot of a ping-pong gradient buffer
     auto fresh = [&](int slot) -> int {                                                               // zero a slot before its tensor is rewritten
         if (!h2) return 0;
@@ -477,7 +497,7 @@ int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd
         RC(conv_wgrad(cur, C, ws + P.da[l], C, nullptr, 0, C, grd + P.L[iu + 2].w_off, grd + P.L[iu + 2].b_off, part, N, H, W, st));
         RC(marks.done(P, iu + 2, st));
         RC(fresh(gs(oth))); BD(gs(cur), S_W + iu + 2, gs(oth), -1);
-        RC(conv_bwd_data(cur, ws + P.wp_bwd[iu + 2], oth, nullptr, C, ws + P.da[l], nullptr, N, H, W, C, C, st));
+        RC(conv_bwd_data(cur, ws + P.wp_bwd[iu + 2], oth, nullptr, C, ws + P.da[l], nullptr, N, H, W, C, C, st, l < 2 ? CD(P.cd_da[l]) : nullptr));
         { float* t = cur; cur = oth; oth = t; }
         // conv_1: input cat[up[l], eb[l]] -> d_up (raw) in oth, skip grad (raw) in skip[l]
         WG(gs(cur), S_UP + l, S_EB + l);
@@ -503,7 +523,8 @@ int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd
         RC(conv_wgrad(cur, C, ws + P.ea[l], C, nullptr, 0, C, grd + P.L[ib].w_off, grd + P.L[ib].b_off, part, N, H, W, st));
         RC(marks.done(P, ib, st));
         RC(fresh(gs(oth))); BD(gs(cur), S_W + ib, gs(oth), -1);
-        RC(conv_bwd_data(cur, ws + P.wp_bwd[ib], oth, nullptr, C, ws + P.ea[l], nullptr, N, H, W, C, C, st));
+        RC(conv_bwd_data(cur, ws + P.wp_bwd[ib], oth, nullptr, C, ws + P.ea[l], nullptr, N, H, W, C, C, st,
+                         l < 2 ? CD(P.cd_ea[l], l > 0 || P.in_ch > 4 || conv_first_writes_codes(P.in_ch)) : nullptr));
         { float* t = cur; cur = oth; oth = t; }
         if (l == 0) {
             if (P.in_ch <= 4)

@@ -31,7 +31,8 @@ int launch_adam(float* p, const float* g, float* m, float* v, size_t n, double l
                 int step, double gscale, hipStream_t st);
 
 // first layer (conv_first.hip): NCHW input with Cin <= 4 -> NHWC 32 channels
-int launch_conv_first_fwd(const float* x, const float* w, const float* bias, float* out, int N, int Cin, int H, int W, int lrelu, hipStream_t st);
+int launch_conv_first_fwd(const float* x, const float* w, const float* bias, float* out, int N, int Cin, int H, int W, int lrelu, hipStream_t st, unsigned* codes = nullptr);      // codes: slope codes of the output (conv.h ConvArgs::codes_out), honoured when conv_first_writes_codes(Cin)
+bool conv_first_writes_codes(int Cin);
 size_t conv_first_wgrad_ws_floats();
 int launch_conv_first_wgrad(const float* g, const float* x, float* dw, float* db, float* part, int N, int Cin, int H, int W, hipStream_t st, bool x3 = false);
 
