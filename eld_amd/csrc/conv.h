@@ -43,6 +43,8 @@ struct ConvArgs {
     // in the MFMA result layout: word ((pixel * (C / 32) + block) * 2 + hi) holds, at bits 2i .. 2i+1 (i = 4q + j), channel 8q + 4hi + j of the 32-channel block.
     // EPI_FWD with lrelu: codes_out != null -> also written for the layer's output.  EPI_GRAD: codes0 / codes1 != null -> read INSTEAD of act0 / act1
     // (1/16 of the bytes, one load per row and block instead of four).
+    // The bf16 network (conv_bfs.hip, conv_first.hip) keeps the same word addressing for its two 32-channel tensors but another bit order inside a word
+    // (slope_codes_bf16 below).
     unsigned* codes_out;
     const unsigned* codes0;
     const unsigned* codes1;
@@ -135,6 +137,49 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_hw));
 }
 __device__ __forceinline__ uint2 pack_bf4(float4 v) { return make_uint2(pack_bf2(v.x, v.y), pack_bf2(v.z, v.w)); }
+// Slope codes of the bf16 network: 16 packed bf16 activations of a lane (pack_bf4 of accumulator elements 4q .. 4q+3 -> pk[q]; element e = 4q + b) ->
+// one 32-bit word, 2 bits per element, taken from the ROUNDED values (the ones the bf16 backward's lrelu_slope(saved activation) would see: a tiny
+// fp32 value may round to a bf16 zero).  The bit order is whatever is cheapest to build from the packed words -- the epilogues that write these words
+// sit on the critical path of HBM-latency-bound kernels (conv_bfs.hip), and the element-by-element form of slope_codes16 cost 11 % of conv9_1:
+//   sign of element e      at bit 8 (e & 3) + (e >> 2)                        (v_perm_b32 gathers the four high bytes of pk[q]; one mask and shift per q)
+//   "nonzero" of element e at bit P(e >> 1) + 16 (e & 1), P(k) = k + 4 + 4 (k >> 2)   (v_pk_min_u16(|half|, 1) leaves the flags of a word's halves at bits 0 / 16)
+// i.e. signs in the low nibble of every byte, nonzero flags in the high nibbles.  slope = nonzero ? (sign ? 0.2 : 1) : 0.6 (conv.h lrelu_slope; -0 is a zero).
+constexpr unsigned BF16_CODES_NZ_ALL = 0xF0F0F0F0u;
+__device__ __forceinline__ unsigned slope_codes_bf16(const uint2 (&pk)[4]) {
+    unsigned sg = 0, nz = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const unsigned hb = __builtin_amdgcn_perm(pk[q].y, pk[q].x, 0x07050301u);      // high bytes of elements 4q .. 4q+3
+        sg |= (hb & 0x80808080u) >> (7 - q);
+        const unsigned w[2] = {pk[q].x, pk[q].y};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = 2 * q + h;                                                    // word k holds elements 2k, 2k + 1
+            unsigned f;                                                                  // (hipcc expands a two-lane umin into compares, selects and a perm: name the instruction)
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(f) : "v"(w[h] & 0x7fff7fffu), "v"(0x00010001u));
+            nz |= f << (k + 4 + 4 * (k >> 2));
+        }
+    }
+    return sg | nz;
+}
+// the slopes of a lane's 16 elements from its code word: f[e] = sign ? 0.2 : 1 as a bit-field extract and a bit select (two instructions); all_nz
+// (wave-uniform: no element of this wave's words is a zero -- the usual case) skips the 0.6 fix-up of exact zeros
+__device__ __forceinline__ void slopes_of_bf16_codes(unsigned w, bool all_nz, float (&f)[16]) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int sp = 8 * (e & 3) + (e >> 2);
+        unsigned neg;                                                                   // all ones for a negative value (named instruction: written as shifts,
+        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(neg) : "v"(w), "n"(sp));                    // hipcc turns the whole expression back into and + compare + select)
+        asm("v_bfi_b32 %0, %1, %2, 1.0" : "=v"(f[e]) : "v"(neg), "s"(0x3E4CCCCDu));       // neg ? 0.2f : 1.0f
+    }
+    if (!all_nz) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int np = (e >> 1) + 4 + 4 * (e >> 3) + 16 * (e & 1);
+            f[e] = ((w >> np) & 1u) ? f[e] : 0.6f;
+        }
+    }
+}
 __device__ __forceinline__ float4 unpack_bf4(uint2 p) {
     return make_float4(__uint_as_float(p.x << 16), __uint_as_float(p.x & 0xFFFF0000u), __uint_as_float(p.y << 16), __uint_as_float(p.y & 0xFFFF0000u));
 }

@@ -39,9 +39,10 @@ __device__ __forceinline__ void bfs_wait_vm() { asm volatile("s_waitcnt vmcnt(%0
 constexpr int BFS_NAB = 3;                               // activation ring depth
 constexpr int BFS_WCHUNK = 9 * 32 * 64;                  // packed weights of one 32-channel chunk: 18 DMA pieces
 
-// ACT: EPI_GRAD with a saved activation (slope epilogue) -- compile time, because the activation loads are hand-issued asm loads whose destination
-// registers must not pass through a phi (cdna_hip_programming.md 5.7 item 1: the compiler may copy them before the data has landed)
-template <int RPW, int WAVES, bool ACT>
+// ACT: EPI_GRAD with a slope epilogue -- 1: from the saved activation (four 16-byte loads per row), 2: from its 2-bit slope codes (conv.h
+// ConvArgs::codes0: one 4-byte load per row) -- compile time, because these loads are hand-issued asm loads whose destination registers must not
+// pass through a phi (cdna_hip_programming.md 5.7 item 1: the compiler may copy them before the data has landed)
+template <int RPW, int WAVES, int ACT>
 __global__ __launch_bounds__(64 * WAVES) void conv_bfs_kernel(const ConvArgs a) {
     constexpr int TH = WAVES * RPW, HW2 = TW + 2, A_PIX = (TH + 2) * HW2;
     constexpr int A_UNITS = A_PIX * 4, A_PIECES = (A_UNITS + 63) / 64, A_BYTES = A_PIECES * 1024;
@@ -155,6 +156,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfs_kernel(const ConvArgs a) 
     const float sl = a.lrelu ? 0.2f : 1.0f;                // max(1 v, v) = v
     static_assert(RPW == 2, "the activation-load wait names ac[2][2]");
     u32x4 ac[RPW][2];                                      // native vector type: one 128-bit register tuple per asm operand
+    unsigned cw[RPW];                                      // ACT == 2: this lane's code word of each row (16 channels x 2 bits)
 
     issue_A(0);
     issue_A(1);
@@ -166,7 +168,18 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfs_kernel(const ConvArgs a) 
         // this wave's pieces of item j (and, the first time, of the weights) have landed; item j+1's may still fly
         bfs_wait_vm<A_IT>();
         __syncthreads();                         // ... and everybody else's; everybody is done reading ring slot (j - 1) % 3 = (j + 2) % 3
-        if constexpr (ACT) {                      // (NCH == 1 in these launches: every item ends a tile)
+        if constexpr (ACT == 2) {                 // slope codes of this tile's output pixels: word (pixel x0 + m, hi) -- the MFMA result layout itself
+            int img, y0, x0;
+            decode(t, img, y0, x0);
+            const int xx = min(x0 + m, a.W - 1);
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int y = min(y0 + wave * RPW + r, a.H - 1);
+                const unsigned* p = a.codes0 + ((size_t)(img * a.H + y) * a.W + xx) * 2 + hi;
+                asm volatile("global_load_dword %0, %1, off" : "=&v"(cw[r]) : "v"(p) : "memory");     // (hand-issued for the same reason as ACT == 1's; early clobber: not the address pair, whose registers the compiler reuses as don't-care operands)
+            }
+        }
+        if constexpr (ACT == 1) {                 // (NCH == 1 in these launches: every item ends a tile)
             // saved activations of this tile's output pixels (slope epilogue), in the line layout; loaded by hand so that the compiler does not
             // wait for them with a vmcnt that would drain the younger halo DMAs: they are OLDER than item j+2's pieces, so the epilogue's
             // wait leaves exactly those A_IT pieces in flight.  Out-of-range pixels re-read a valid address (the value is not used).
@@ -211,7 +224,8 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfs_kernel(const ConvArgs a) 
                 }
         }
         if constexpr (!ACT) { if (chunk + 1 < NCH) continue; }      // (ACT launches have one chunk per tile: no path from the activation loads past their wait)
-        if constexpr (ACT) {                     // the hand-issued activation loads have landed (item j+2's A_IT DMA pieces, issued after them, may still fly)
+        if constexpr (ACT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(cw[0]), "+v"(cw[1]) : "n"(A_IT));
+        if constexpr (ACT == 1) {                // the hand-issued activation loads have landed (item j+2's A_IT DMA pieces, issued after them, may still fly)
             // (whole 128-bit tuples as operands: with sixteen 32-bit operands the compiler shuffled the registers -- v_mov copies of data that had
             // not landed yet -- to build the statement's operand list)
             asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ac[0][0]), "+v"(ac[0][1]), "+v"(ac[1][0]), "+v"(ac[1][1]) : "n"(A_IT));
@@ -229,13 +243,21 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfs_kernel(const ConvArgs a) 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) bias_lrelu4(acc[r], 4 * q, bs[q], sl);
         }
+        bool all_nz = true;
+        if constexpr (ACT == 2) all_nz = __builtin_amdgcn_ballot_w64((cw[0] & cw[1] & BF16_CODES_NZ_ALL) != BF16_CODES_NZ_ALL) == 0;
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             const int y = y0 + wave * RPW + r;
             float4 v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = make_float4(acc[r][4 * q], acc[r][4 * q + 1], acc[r][4 * q + 2], acc[r][4 * q + 3]);
-            if constexpr (ACT) {                                            // EPI_GRAD: times the LeakyReLU slope of the saved activation
+            if constexpr (ACT == 2) {                                       // EPI_GRAD: times the LeakyReLU slope its code names (the same three values)
+                float f[16];
+                slopes_of_bf16_codes(cw[r], all_nz, f);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[q].x *= f[4 * q]; v[q].y *= f[4 * q + 1]; v[q].z *= f[4 * q + 2]; v[q].w *= f[4 * q + 3]; }
+            }
+            if constexpr (ACT == 1) {                                       // EPI_GRAD: times the LeakyReLU slope of the saved activation
                 uint2 sp[4];
                 bf16_line_unswap(make_uint4(ac[r][0][0], ac[r][0][1], ac[r][0][2], ac[r][0][3]), make_uint4(ac[r][1][0], ac[r][1][1], ac[r][1][2], ac[r][1][3]), sp);
 #pragma unroll
@@ -247,6 +269,11 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfs_kernel(const ConvArgs a) 
             uint2 pk[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) pk[q] = pack_bf4(v[q]);
+            if constexpr (ACT == 0) {
+                if (a.codes_out != nullptr && a.epi == EPI_FWD && y < a.H && x0 + m < a.W) {      // slope codes of the ROUNDED activations (wave-uniform pointer test)
+                    a.codes_out[((size_t)(img * a.H + y) * a.W + x0 + m) * 2 + hi] = slope_codes_bf16(pk);
+                }
+            }
             uint4 s0, s1;
             bf16_line_swap(pk, s0, s1);                                     // every lane takes part; only the stores are predicated
             bf16_t* row = static_cast<bf16_t*>(a.out0) + ((size_t)(img * a.H + y) * a.W + x0) * 32 + 8 * lg;
@@ -282,7 +309,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfs_kernel(const ConvArgs a) 
     }
 }
 
-template <int RPW, int WAVES, bool ACT>
+template <int RPW, int WAVES, int ACT>
 int launch_bfs(ConvArgs a, hipStream_t st) {
     constexpr int TH = WAVES * RPW;
     a.tiles_x = (a.W + TW - 1) / TW;
@@ -327,7 +354,7 @@ int launch_conv_bfs(const ConvArgs& a, hipStream_t st) {
     if (a.epi != EPI_FWD && a.epi != EPI_GRAD) return ELD_ENOTSUP;
     if (a.epi == EPI_GRAD && a.act0 != nullptr) {
         if (a.C0 + a.C1 != 32) return ELD_ENOTSUP;      // the slope variant assumes one chunk per tile (the U-Net's two such launches have K = 32)
-        return launch_bfs<2, 8, true>(a, st);
+        return a.codes0 ? launch_bfs<2, 8, 2>(a, st) : launch_bfs<2, 8, 1>(a, st);
     }
-    return launch_bfs<2, 8, false>(a, st);
+    return launch_bfs<2, 8, 0>(a, st);
 }

@@ -254,6 +254,9 @@ __global__ __launch_bounds__(256) void conv_first_fwd_mma_kernel(const float* __
                 uint2 pk[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) pk[q] = pack_bf4(v[q]);
+                if (codes != nullptr && yok && x0 + m < W) {             // the bf16 network's codes come from the ROUNDED values (conv.h slope_codes_bf16)
+                    codes[((size_t)(img * H + y) * W + x0 + m) * 2 + hi] = slope_codes_bf16(pk);
+                }
                 uint4 s0, s1;
                 bf16_line_swap(pk, s0, s1);
                 const int lp = lane & 15;
@@ -292,8 +295,8 @@ static int launch_first_t(const float* x, const float* w, const float* bias, TO*
 int launch_conv_first_fwd(const float* x, const float* w, const float* bias, float* out, int N, int Cin, int H, int W, int lrelu, hipStream_t st, unsigned* codes) {
     return launch_first_t<float>(x, w, bias, out, N, Cin, H, W, lrelu, st, codes);
 }
-int launch_conv_first_fwd_bf16(const float* x, const float* w, const float* bias, bf16_t* out, int N, int Cin, int H, int W, int lrelu, hipStream_t st) {
-    return launch_first_t<bf16_t>(x, w, bias, out, N, Cin, H, W, lrelu, st);
+int launch_conv_first_fwd_bf16(const float* x, const float* w, const float* bias, bf16_t* out, int N, int Cin, int H, int W, int lrelu, hipStream_t st, unsigned* codes) {
+    return launch_first_t<bf16_t>(x, w, bias, out, N, Cin, H, W, lrelu, st, codes);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -194,7 +194,8 @@ struct Plan {
     size_t gA, gB, skip[NLEV - 1], part, part_floats, amax;
     size_t head_part; // partials of the fused training head (eld_unet_forward_loss_ex -> the backward)
     // slope codes (conv.h ConvArgs::codes_out) of the activations the 32- / 64-channel backward-data epilogues multiply by: ea[0], ea[1], da[0], da[1]
-    // (2 bits per element); written by the fp32 three-piece forward and read by its backward when `codes` is set (see make_plan)
+    // (2 bits per element); written by the fp32 three-piece forward where `codes` is set (see make_plan) and, for ea[0] / da[0], by the bf16 forward
+    // (unet_forward_bf16); read by the backward for the regions the last forward reports (FusedFwd::codes)
     size_t cd_ea[2], cd_da[2];
     bool codes;
     size_t total;     // floats
@@ -270,7 +271,8 @@ int make_plan(Plan& P, int N, int H, int W, int in_ch, int out_ch) {
     P.part = take(pmax);
     P.part_floats = pmax;
     // Slope codes only where the 64-channel level-1 layers run the unsplit 8-wave kernel (conv_x3.hip x3_slab_bn: every CU gets a 16-row tile): the
-    // split-K finish kernel of small problems does not write them.  A pure function of the shape: forward and backward agree without shared state.
+    // split-K finish kernel of small problems does not write them.  Which regions a forward actually filled travels to the backward through the
+    // workspace's CodesState (the fp32 scheme, the first layer's kernel and the debug mask are per-call choices).
     P.codes = conv_tile_count(N, P.Hl[1], P.Wl[1], 16, false) >= eld_num_cus();
     for (int l = 0; l < 2; ++l) {
         P.cd_ea[l] = take(act(l, chan(l)) / 16 + 64);
@@ -350,9 +352,12 @@ struct HeadLoss { const float* target; float* loss; int mse; float grad_scale; }
 
 // What eld_unet_forward_loss_ex leaves for the backward that follows it with dout == NULL (besides the head's partials): both pack directions done, and
 // -- when the first layer reads the NCHW input directly -- the caller's input tensor itself instead of a copy in the workspace (8 frames: 388 MB, 0.13 ms).
-struct FusedFwd { bool packed = false; const float* x = nullptr; };
+struct FusedFwd { bool packed = false; const float* x = nullptr; unsigned codes = 0; };
+// FusedFwd::codes / the forwards' have_out: which slope-code regions the LAST forward on this workspace filled (it decides per launch: kernel choice,
+// fp32 scheme, debug mask) -- the backward reads a region only when its bit is set, whatever its own switches say
+enum { CODES_EA0 = 1, CODES_EA1 = 2, CODES_DA0 = 4, CODES_DA1 = 8 };
 
-int unet_forward(const Plan& P, const float* x, const float* prm, float* out, float* ws, hipStream_t st, const HeadLoss* hl = nullptr) {
+int unet_forward(const Plan& P, const float* x, const float* prm, float* out, float* ws, hipStream_t st, const HeadLoss* hl = nullptr, unsigned* have_out = nullptr) {
     const int N = P.N;
     KPartScope kp(ws + P.part, P.part_floats);
     const bool h2 = g_algo == 2;                                 // operand bounds ride along in the workspace
@@ -364,8 +369,9 @@ int unet_forward(const Plan& P, const float* x, const float* prm, float* out, fl
     if (h2 && hipMemsetAsync(am, 0, S_COUNT * sizeof(float), st) != hipSuccess) return (int)hipGetLastError();
     RC(pack_weights(P, prm, ws, hl ? PACK_BOTH : PACK_FWD, st, false, h2 ? am : nullptr));
     const bool first_direct = P.in_ch <= 4;        // conv1_1 straight from the NCHW planes (conv_first.hip)
-    const bool use_codes = P.codes && g_algo == 1;   // slope codes for the backward-data epilogues of levels 0 / 1 (Plan::codes)
+    const bool use_codes = P.codes && g_algo == 1 && !(debug_kernel_mask(-1) & 128);   // slope codes for the backward-data epilogues of levels 0 / 1 (Plan::codes)
     auto CD = [&](size_t off) -> unsigned* { return use_codes ? reinterpret_cast<unsigned*>(ws + off) : nullptr; };
+    if (have_out) *have_out = !use_codes ? 0u : ((!first_direct || conv_first_writes_codes(P.in_ch)) ? CODES_EA0 : 0u) | CODES_EA1 | CODES_DA0 | CODES_DA1;
     if (first_direct && hl) {
         // fused training forward: the backward reads the caller's x (include/eld_amd.h: it must stay valid and unchanged until that call)
     } else if (first_direct) {
@@ -417,15 +423,16 @@ int unet_forward(const Plan& P, const float* x, const float* prm, float* out, fl
 // bf16 forward (inference): bf16 activations and packed weights, fp32 accumulation / bias; the first layer reads the
 // fp32 NCHW planes and the head writes fp32 NCHW.  Buffers of the fp32 plan are reused (half filled).
 int conv_fwd_bf16(const bf16_t* in0, int C0, const bf16_t* in1, int C1, const bf16_t* wp, const float* bias, bf16_t* out, int N, int H, int W,
-                  int Cout, int lrelu, hipStream_t st, bf16_t* pool_out = nullptr) {
+                  int Cout, int lrelu, hipStream_t st, bf16_t* pool_out = nullptr, unsigned* codes_out = nullptr) {
     ConvArgs a = {};
     a.pool_out = pool_out;
+    a.codes_out = codes_out;
     a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1; a.wp = wp; a.N = N; a.H = H; a.W = W; a.Nout = Cout;
     a.epi = EPI_FWD; a.bias = bias; a.lrelu = lrelu; a.out0 = out; a.dtype = DT_BF16;
     return launch_conv(a, CONV_3X3, st);
 }
 
-int unet_forward_bf16(const Plan& P, const float* x, const float* prm, float* out, float* ws, hipStream_t st, const HeadLoss* hl = nullptr) {
+int unet_forward_bf16(const Plan& P, const float* x, const float* prm, float* out, float* ws, hipStream_t st, const HeadLoss* hl = nullptr, unsigned* have_out = nullptr) {
     const int N = P.N;
     if (P.in_ch > 4) return ELD_ENOTSUP;
     RC(pack_weights(P, prm, ws, hl ? PACK_BOTH : PACK_FWD, st, true));
@@ -434,10 +441,17 @@ int unet_forward_bf16(const Plan& P, const float* x, const float* prm, float* ou
         if (e != hipSuccess) return (int)e;
     }
     auto B = [&](size_t off) { return reinterpret_cast<bf16_t*>(ws + off); };
+    // Slope codes of the two full-resolution activations whose backward-data epilogues run on conv_bfs_kernel (conv9_2's and conv1_2's: HBM-bound
+    // launches that would otherwise re-read the saved 32-channel tensor): written by conv1_1's and conv9_1's epilogues where those kernels are the
+    // ones that run (conv_first's MFMA kernel; conv_bfs for the 64 -> 32 layer) -- 8 bytes per pixel instead of 64 in the backward
+    const bool bfs0 = bfs_takes(32, 32, N, P.H, P.W) && !(debug_kernel_mask(-1) & 128);
+    const bool c_ea0 = bfs0 && conv_first_writes_codes(P.in_ch), c_da0 = bfs0 && bfs_takes(32, 64, N, P.H, P.W);
+    if (have_out) *have_out = (c_ea0 ? CODES_EA0 : 0u) | (c_da0 ? CODES_DA0 : 0u);
     for (int l = 0; l < NLEV; ++l) {
         const LayerDef& A = P.L[2 * l]; const LayerDef& Bd = P.L[2 * l + 1];
         if (l == 0)
-            RC(launch_conv_first_fwd_bf16(x, prm + A.w_off, prm + A.b_off, B(P.ea[0]), N, P.in_ch, P.H, P.W, 1, st));
+            RC(launch_conv_first_fwd_bf16(x, prm + A.w_off, prm + A.b_off, B(P.ea[0]), N, P.in_ch, P.H, P.W, 1, st,
+                                          c_ea0 ? reinterpret_cast<unsigned*>(ws + P.cd_ea[0]) : nullptr));
         else
             RC(conv_fwd_bf16(B(P.pool[l - 1]), chan(l - 1), nullptr, 0, B(P.wp_fwd[2 * l]), prm + A.b_off, B(P.ea[l]), N, P.Hl[l], P.Wl[l], chan(l), 1, st));
         // layers on the DMA kernel (conv_bfd.hip) write the pooled tensor from their epilogue
@@ -453,7 +467,8 @@ int unet_forward_bf16(const Plan& P, const float* x, const float* prm, float* ou
         a.in0 = src; a.C0 = chan(l + 1); a.wp = B(P.wp_fwd[iu]); a.N = N; a.H = P.Hl[l + 1]; a.W = P.Wl[l + 1]; a.Nout = 4 * chan(l);
         a.epi = EPI_CONVT_FWD; a.bias = prm + P.L[iu].b_off; a.out0 = B(P.up[l]); a.Cout_t = chan(l); a.dtype = DT_BF16;
         RC(launch_conv(a, CONV_1X1, st));
-        RC(conv_fwd_bf16(B(P.up[l]), chan(l), B(P.eb[l]), chan(l), B(P.wp_fwd[iu + 1]), prm + P.L[iu + 1].b_off, B(P.da[l]), N, P.Hl[l], P.Wl[l], chan(l), 1, st));
+        RC(conv_fwd_bf16(B(P.up[l]), chan(l), B(P.eb[l]), chan(l), B(P.wp_fwd[iu + 1]), prm + P.L[iu + 1].b_off, B(P.da[l]), N, P.Hl[l], P.Wl[l], chan(l), 1, st, nullptr,
+                         l == 0 && c_da0 ? reinterpret_cast<unsigned*>(ws + P.cd_da[0]) : nullptr));
         RC(conv_fwd_bf16(B(P.da[l]), chan(l), nullptr, 0, B(P.wp_fwd[iu + 2]), prm + P.L[iu + 2].b_off, B(P.db[l]), N, P.Hl[l], P.Wl[l], chan(l), 1, st));
     }
     const LayerDef& Hd = P.L[L_HEAD];
@@ -472,9 +487,8 @@ int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd
     if (h2 && hipMemsetAsync(am + S_GA, 0, (S_COUNT - S_GA) * sizeof(float), st) != hipSuccess) return (int)hipGetLastError();
     if (!fused.packed) RC(pack_weights(P, prm, ws, PACK_BWD, st, false, h2 ? am : nullptr));
     float* gA = ws + P.gA; float* gB = ws + P.gB; float* part = ws + P.part;
-    // slope codes the forward left for levels 0 / 1 (Plan::codes); ea[0]'s only where the first layer's kernel writes them
-    const bool use_codes = P.codes && g_algo == 1;
-    auto CD = [&](size_t off, bool have = true) -> const unsigned* { return use_codes && have ? reinterpret_cast<const unsigned*>(ws + off) : nullptr; };
+    // slope codes the forward left for levels 0 / 1 (FusedFwd::codes names the regions it filled)
+    auto CD = [&](size_t off, unsigned bit) -> const unsigned* { return g_algo == 1 && (fused.codes & bit) ? reinterpret_cast<const unsigned*>(ws + off) : nullptr; };
     auto gs = [&](const float* buf) { return buf == gA ? (int)S_GA : (int)S_GB; };                 // slot of a ping-pong gradient buffer
     auto fresh = [&](int slot) -> int {                                                               // zero a slot before its tensor is rewritten
         if (!h2) return 0;
@@ -497,7 +511,7 @@ int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd
         RC(conv_wgrad(cur, C, ws + P.da[l], C, nullptr, 0, C, grd + P.L[iu + 2].w_off, grd + P.L[iu + 2].b_off, part, N, H, W, st));
         RC(marks.done(P, iu + 2, st));
         RC(fresh(gs(oth))); BD(gs(cur), S_W + iu + 2, gs(oth), -1);
-        RC(conv_bwd_data(cur, ws + P.wp_bwd[iu + 2], oth, nullptr, C, ws + P.da[l], nullptr, N, H, W, C, C, st, l < 2 ? CD(P.cd_da[l]) : nullptr));
+        RC(conv_bwd_data(cur, ws + P.wp_bwd[iu + 2], oth, nullptr, C, ws + P.da[l], nullptr, N, H, W, C, C, st, l < 2 ? CD(P.cd_da[l], l ? CODES_DA1 : CODES_DA0) : nullptr));
         { float* t = cur; cur = oth; oth = t; }
         // conv_1: input cat[up[l], eb[l]] -> d_up (raw) in oth, skip grad (raw) in skip[l]
         WG(gs(cur), S_UP + l, S_EB + l);
@@ -524,7 +538,7 @@ int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd
         RC(marks.done(P, ib, st));
         RC(fresh(gs(oth))); BD(gs(cur), S_W + ib, gs(oth), -1);
         RC(conv_bwd_data(cur, ws + P.wp_bwd[ib], oth, nullptr, C, ws + P.ea[l], nullptr, N, H, W, C, C, st,
-                         l < 2 ? CD(P.cd_ea[l], l > 0 || P.in_ch > 4 || conv_first_writes_codes(P.in_ch)) : nullptr));
+                         l < 2 ? CD(P.cd_ea[l], l ? CODES_EA1 : CODES_EA0) : nullptr));
         { float* t = cur; cur = oth; oth = t; }
         if (l == 0) {
             if (P.in_ch <= 4)
@@ -553,8 +567,9 @@ int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd
 // bf16 backward: activation gradients bf16 (igemm on v_mfma_f32_32x32x16_bf16), weight gradients accumulated and written
 // in fp32 (the wgrad kernels convert the bf16 operands while staging; fp32 MFMA).  Mirrors unet_backward step for step.
 int conv_bwd_data_bf16(const bf16_t* g, const bf16_t* wb, bf16_t* out0, bf16_t* out1, int split, const bf16_t* act0, const bf16_t* act1, int N, int H,
-                       int W, int Cin, int Cout, hipStream_t st) {
+                       int W, int Cin, int Cout, hipStream_t st, const unsigned* codes0 = nullptr) {
     ConvArgs a = {};
+    a.codes0 = codes0;
     a.in0 = g; a.C0 = Cout; a.wp = wb; a.N = N; a.H = H; a.W = W; a.Nout = Cin;
     a.epi = EPI_GRAD; a.out0 = out0; a.out1 = out1; a.split = split; a.act0 = act0; a.act1 = act1; a.dtype = DT_BF16;
     return launch_conv(a, CONV_3X3, st);
@@ -587,7 +602,8 @@ int unet_backward_bf16(const Plan& P, const float* dout, const float* prm, float
         const int H = P.Hl[l], W = P.Wl[l], C = chan(l);
         RC(conv_wgrad_bf16(cur, C, B(P.da[l]), C, nullptr, 0, grd + P.L[iu + 2].w_off, grd + P.L[iu + 2].b_off, part, N, H, W, st));
         RC(marks.done(P, iu + 2, st));
-        RC(conv_bwd_data_bf16(cur, B(P.wp_bwd[iu + 2]), oth, nullptr, C, B(P.da[l]), nullptr, N, H, W, C, C, st));
+        RC(conv_bwd_data_bf16(cur, B(P.wp_bwd[iu + 2]), oth, nullptr, C, B(P.da[l]), nullptr, N, H, W, C, C, st,
+                              l == 0 && (fused.codes & CODES_DA0) ? reinterpret_cast<const unsigned*>(ws + P.cd_da[0]) : nullptr));
         swap();
         RC(conv_wgrad_bf16(cur, C, B(P.up[l]), C, B(P.eb[l]), C, grd + P.L[iu + 1].w_off, grd + P.L[iu + 1].b_off, part, N, H, W, st));
         RC(marks.done(P, iu + 1, st));
@@ -616,7 +632,8 @@ int unet_backward_bf16(const Plan& P, const float* dout, const float* prm, float
         const int ia = 2 * l, ib = 2 * l + 1;
         RC(conv_wgrad_bf16(cur, C, B(P.ea[l]), C, nullptr, 0, grd + P.L[ib].w_off, grd + P.L[ib].b_off, part, N, H, W, st));
         RC(marks.done(P, ib, st));
-        RC(conv_bwd_data_bf16(cur, B(P.wp_bwd[ib]), oth, nullptr, C, B(P.ea[l]), nullptr, N, H, W, C, C, st));
+        RC(conv_bwd_data_bf16(cur, B(P.wp_bwd[ib]), oth, nullptr, C, B(P.ea[l]), nullptr, N, H, W, C, C, st,
+                              l == 0 && (fused.codes & CODES_EA0) ? reinterpret_cast<const unsigned*>(ws + P.cd_ea[0]) : nullptr));
         swap();
         if (l == 0) {
             RC(launch_conv_first_wgrad_bf16(cur, fused.x ? fused.x : ws + P.x16, grd + P.L[ia].w_off, grd + P.L[ia].b_off, part, N, P.in_ch, H, W, st));
@@ -661,6 +678,22 @@ namespace {
 struct HeadState { int N, H, W, in_ch, out_ch, precision; const float* x; };
 std::mutex g_head_mu;
 std::unordered_map<const void*, HeadState> g_head;
+// Which slope-code regions the last forward on a workspace filled, and for which problem (FusedFwd::codes): same bookkeeping, for EVERY forward
+struct CodesState { int N, H, W, in_ch, out_ch, precision; unsigned have; };
+std::unordered_map<const void*, CodesState> g_codes;
+void codes_state_set(const void* ws, const CodesState& cs) {
+    std::lock_guard<std::mutex> lk(g_head_mu);
+    if (cs.have == 0) { g_codes.erase(ws); return; }
+    if (g_codes.size() > 256) g_codes.clear();           // (a lost entry only sends the backward to the saved activations)
+    g_codes[ws] = cs;
+}
+unsigned codes_state_get(const void* ws, int N, int H, int W, int in_ch, int out_ch, int precision) {
+    std::lock_guard<std::mutex> lk(g_head_mu);
+    const auto it = g_codes.find(ws);
+    if (it == g_codes.end()) return 0;
+    const CodesState& c = it->second;
+    return c.N == N && c.H == H && c.W == W && c.in_ch == in_ch && c.out_ch == out_ch && c.precision == precision ? c.have : 0u;
+}
 void head_state_set(const void* ws, const HeadState* st) {
     std::lock_guard<std::mutex> lk(g_head_mu);
     if (st) {
@@ -694,7 +727,11 @@ extern "C" int eld_unet_forward_ex(const float* x, const float* params, float* o
     RC(unet_entry_checks(P, x, params, out, ws, ws_bytes, N, H, W, in_ch, out_ch));
     AlgoScope scope(fp32_algo);
     head_state_set(ws, nullptr);      // whatever fused head state the workspace held is overwritten
-    return precision == 1 ? unet_forward_bf16(P, x, params, out, (float*)ws, as_stream(stream)) : unet_forward(P, x, params, out, (float*)ws, as_stream(stream));
+    unsigned have = 0;
+    const int rc = precision == 1 ? unet_forward_bf16(P, x, params, out, (float*)ws, as_stream(stream), nullptr, &have)
+                                  : unet_forward(P, x, params, out, (float*)ws, as_stream(stream), nullptr, &have);
+    codes_state_set(ws, CodesState{N, H, W, in_ch, out_ch, precision, rc == 0 ? have : 0u});
+    return rc;
 }
 
 extern "C" int eld_unet_forward_loss_ex(const float* x, const float* params, const float* target, float* out, float* loss, void* ws, size_t ws_bytes,
@@ -706,7 +743,10 @@ extern "C" int eld_unet_forward_loss_ex(const float* x, const float* params, con
     AlgoScope scope(fp32_algo);
     const HeadLoss hl = {target, loss, loss_kind, grad_scale};
     head_state_set(ws, nullptr);
-    const int rc = precision == 1 ? unet_forward_bf16(P, x, params, out, (float*)ws, as_stream(stream), &hl) : unet_forward(P, x, params, out, (float*)ws, as_stream(stream), &hl);
+    unsigned have = 0;
+    const int rc = precision == 1 ? unet_forward_bf16(P, x, params, out, (float*)ws, as_stream(stream), &hl, &have)
+                                  : unet_forward(P, x, params, out, (float*)ws, as_stream(stream), &hl, &have);
+    codes_state_set(ws, CodesState{N, H, W, in_ch, out_ch, precision, rc == 0 ? have : 0u});
     if (rc == 0) { const HeadState hs = {N, H, W, in_ch, out_ch, precision, x}; head_state_set(ws, &hs); }
     return rc;
 }
@@ -729,6 +769,7 @@ extern "C" int eld_unet_backward_ex(const float* dout, const float* params, floa
         // input with the caller instead of copying it into the workspace, so the first layer's weight gradient must read it there as well.
         if (after_fused) fused.x = in_ch <= 4 ? hs.x : nullptr;      // (more input planes: the forward converted x to NHWC16 in the workspace)
         fused.packed = !dout;                                         // with an explicit dout the backward packs its own weights (params may have changed)
+        fused.codes = codes_state_get(ws, N, H, W, in_ch, out_ch, precision);
     }
     for (int k = 0; k < n_buckets; ++k)
         if (!bucket_event[k] || bucket_start[k] < 0 || (k > 0 && bucket_start[k] <= bucket_start[k - 1]) || (size_t)bucket_start[k] >= P.nparams) return ELD_EINVAL;

@@ -39,7 +39,7 @@ int launch_conv_first_wgrad(const float* g, const float* x, float* dw, float* db
 // bf16 activations (forward / inference path)
 int launch_maxpool_fwd_bf16(const bf16_t* in, bf16_t* out, int N, int Ho, int Wo, int C, hipStream_t st);
 int launch_head_fwd_bf16(const bf16_t* in, const float* w, const float* b, float* out, int N, int H, int W, int OC, hipStream_t st);
-int launch_conv_first_fwd_bf16(const float* x, const float* w, const float* bias, bf16_t* out, int N, int Cin, int H, int W, int lrelu, hipStream_t st);
+int launch_conv_first_fwd_bf16(const float* x, const float* w, const float* bias, bf16_t* out, int N, int Cin, int H, int W, int lrelu, hipStream_t st, unsigned* codes = nullptr);
 int launch_maxpool_bwd_bf16(const bf16_t* act, const bf16_t* dp, const bf16_t* skip, bf16_t* g, int N, int Ho, int Wo, int C, hipStream_t st);
 int launch_head_bwd_bf16(const float* dout, const bf16_t* act, const float* w, bf16_t* g, float* dw, float* db, float* part,
                          int N, int H, int W, int OC, hipStream_t st);

@@ -100,10 +100,11 @@ def test_plugin_constructor_and_sample_params(golden_dir, capsys):
     assert tuple(base) == tuple(full) and full.tl_scale > 0 and full.row_scale > 0 and -0.25 < full.tl_lambda < 0.25
 
 
-@pytest.mark.parametrize('src_name,kernel,wait', [('conv_bfs.hip', 'conv_bfs_kernelILi2ELi8ELb1EEEv8ConvArgs:', 's_waitcnt vmcnt(5)'),
+@pytest.mark.parametrize('src_name,kernel,wait', [('conv_bfs.hip', 'conv_bfs_kernelILi2ELi8ELi1EEEv8ConvArgs:', 's_waitcnt vmcnt(5)'),
+                                                  ('conv_bfs.hip', 'conv_bfs_kernelILi2ELi8ELi2EEEv8ConvArgs:', 's_waitcnt vmcnt(5)'),
                                                   ('conv_bfw.hip', 'conv_bfw_kernelILb1EEEv8ConvArgs:', 's_waitcnt vmcnt(3)')])
 def test_hand_issued_loads_are_not_touched_before_their_wait(src_name, kernel, wait):
-    """conv_bfs_kernel<.., ACT = true> and conv_bfw_kernel<ACT = true> load the saved activations with inline-asm global loads that hipcc
+    """conv_bfs_kernel<.., ACT = 1 / 2> and conv_bfw_kernel<ACT = true> load the saved activations (ACT = 2: their slope codes) with inline-asm global loads that hipcc
     does not count (cdna_hip_programming.md 5.7 item 1): between such a load and the hand-written `s_waitcnt vmcnt(n)` that retires it the
     compiler must neither read nor copy nor overwrite the destination registers.  Audit of the generated gfx950 assembly (cross-compiles
     without a GPU); silent corruption otherwise -- a passing numerical test is not evidence for this hazard."""
@@ -166,6 +167,18 @@ def test_hand_issued_loads_are_not_touched_before_their_wait(src_name, kernel, w
             regs |= set(range(int(a_), int(b_) + 1))
         return regs
 
+    def undef_high_addend(code, pending):
+        """hipcc's 32-bit multiply-add on gfx9 is v_mad_u64_u32 / v_mad_i64_i32 with a 64-bit addend pair whose HIGH register is an undefined
+        placeholder (only the low half of the result is used) -- any register will do for it, also one that holds an in-flight load's destination:
+        a read whose value cannot reach the used half of the result.  Nothing else is excused: the pending register must be exactly the addend's
+        high half and appear nowhere else in the instruction (in particular not in the destination pair)."""
+        m = re.match(r'v_mad_[ui]64_[ui]32 v\[(\d+):(\d+)\], (?:s\[\d+:\d+\]|vcc), (\S+), (\S+), v\[(\d+):(\d+)\]$', code)
+        if not m:
+            return False
+        hi = int(m.group(6))
+        others = set(range(int(m.group(1)), int(m.group(2)) + 1)) | regs_of(m.group(3)) | regs_of(m.group(4)) | {int(m.group(5))}
+        return (regs_of(code) & pending) == {hi} and hi not in others
+
     pend_in = [set() for _ in blocks]
     checked, violations = 0, []
     changed = True
@@ -177,14 +190,17 @@ def test_hand_issued_loads_are_not_touched_before_their_wait(src_name, kernel, w
             for is_asm, code in b['ins']:
                 if is_asm:
                     m = re.match(r'global_load_dwordx4 v\[(\d+):(\d+)\]', code)
+                    m1 = re.match(r'global_load_dword v(\d+),', code)
                     if m:
                         pending |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+                    elif m1:
+                        pending.add(int(m1.group(1)))
                     elif code.startswith(wait):
                         if pending:
                             checked += 1
                         pending = set()
                     continue
-                if pending and (regs_of(code) & pending):
+                if pending and (regs_of(code) & pending) and not undef_high_addend(code, pending):
                     violations.append(code)
             for j in succ[i]:
                 if not pending <= pend_in[j]:

@@ -675,6 +675,74 @@ def test_explicit_dout_backward_after_the_fused_forward(lib, prec):
     assert torch.equal(g1, g0), int((g1 != g0).sum())
 
 
+def _codes_case(prec, shape, seed=11):
+    from eld_amd.unet import UNetSeeInDark
+    torch.manual_seed(seed)
+    net = UNetSeeInDark(4, 4).cuda()
+    if prec == 'fp32':
+        net.fp32_products = 1
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    x = torch.rand(*shape, device='cuda', generator=g) ** 2.2
+    junk = torch.rand(*shape, device='cuda', generator=g)
+    dout = torch.randn(*shape, device='cuda', generator=g) / x.numel()
+    return net, x, junk, dout
+
+
+@pytest.mark.parametrize('prec,shape', [('fp32', (1, 4, 528, 1072)), ('bf16', (1, 4, 256, 512)), ('bf16', (2, 4, 272, 560)), ('bf16', (1, 4, 1424, 2128))])
+def test_slope_codes_give_the_gradients_of_the_saved_activations_bit_for_bit(lib, prec, shape):
+    """Round 5: the forward epilogues of levels 0 / 1 (fp32 three-piece scheme) and of conv1_1 / conv9_1 (bf16) also write 2-bit slope codes, and the
+    backward-data epilogues read them instead of the saved activations (conv.h ConvArgs::codes_out / codes0).  eld_debug_kernel_mask bit 7 switches
+    the codes off: the same kernels then multiply by lrelu_slope(saved activation) -- the same three slope values, so every gradient must agree to
+    the last bit (ragged tiles included: 272 x 560 is 17 x 17.5 tiles)."""
+    net, x, junk, dout = _codes_case(prec, shape)
+    bf16 = prec == 'bf16'
+    _, key, _ = net._engine_forward(x, save=True, bf16=bf16)
+    g1 = net._engine_backward(dout, key, shape).clone()
+    old = lib.eld_debug_kernel_mask(128)
+    try:
+        _, key, _ = net._engine_forward(x, save=True, bf16=bf16)
+        g0 = net._engine_backward(dout, key, shape).clone()
+    finally:
+        lib.eld_debug_kernel_mask(old)
+    torch.cuda.synchronize()
+    assert torch.isfinite(g0).all() and float(g0.abs().max()) > 0
+    assert torch.equal(g1, g0), int((g1 != g0).sum())
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+def test_backward_reads_slope_codes_only_from_the_forward_that_wrote_them(lib, prec):
+    """Which code regions are valid is a property of the LAST forward on a workspace (its fp32 scheme, its kernels), not of the backward's own
+    switches: a forward that writes none (fp32: the two-piece scheme; bf16: conv_bfs switched off) followed by a backward whose kernels could read
+    them (a legal call order: the saved tensors have one layout) must fall back to the saved activations -- not read what an earlier forward left."""
+    shape = (1, 4, 528, 1072) if prec == 'fp32' else (1, 4, 256, 512)
+    net, x, junk, dout = _codes_case(prec, shape, seed=12)
+    bf16 = prec == 'bf16'
+
+    def step(codes_off):
+        old = lib.eld_debug_kernel_mask(128) if codes_off else None
+        try:
+            net.fp32_products = 1
+            net._engine_forward(junk, save=True, bf16=bf16)                   # leaves junk's codes in the workspace (unless switched off)
+            if bf16:
+                m = lib.eld_debug_kernel_mask(0)                              # (returns the previous mask)
+                lib.eld_debug_kernel_mask(m | 1)                              # the forward of x: no conv_bfs, so no codes
+                _, key, _ = net._engine_forward(x, save=True, bf16=True)
+                lib.eld_debug_kernel_mask(m)                                  # the backward: conv_bfs again
+            else:
+                net.fp32_products = 2                                         # the forward of x: a scheme that writes no codes
+                _, key, _ = net._engine_forward(x, save=True)
+                net._ws.algo[key] = 1                                         # the backward: the three-piece kernels
+            return net._engine_backward(dout, key, shape).clone()
+        finally:
+            if codes_off:
+                lib.eld_debug_kernel_mask(old)
+
+    ga = step(False)
+    gb = step(True)
+    torch.cuda.synchronize()
+    assert torch.equal(ga, gb), int((ga != gb).sum())
+
+
 def test_forward_loss_argument_checks(lib):
     """eld_unet_forward_loss_ex rejects what it cannot run (include/eld_amd.h): a missing target / loss pointer, an unknown loss kind, a workspace
     that is too small -- error codes, no launch."""
