@@ -355,9 +355,10 @@ struct HeadLoss { const float* target; float* loss; int mse; float grad_scale; }
 struct FusedFwd { bool packed = false; const float* x = nullptr; unsigned codes = 0; };
 // FusedFwd::codes / the forwards' have_out: which slope-code regions the LAST forward on this workspace filled (it decides per launch: kernel choice,
 // fp32 scheme, debug mask) -- the backward reads a region only when its bit is set, whatever its own switches say
-enum { CODES_EA0 = 1, CODES_EA1 = 2, CODES_DA0 = 4, CODES_DA1 = 8 };
+enum { CODES_EA0 = 1, CODES_EA1 = 2, CODES_DA0 = 4, CODES_DA1 = 8, CODES_INFER = 256 };      // CODES_INFER: the forward was eld_unet_infer_ex -- nothing for a backward
 
-int unet_forward(const Plan& P, const float* x, const float* prm, float* out, float* ws, hipStream_t st, const HeadLoss* hl = nullptr, unsigned* have_out = nullptr) {
+int unet_forward(const Plan& P, const float* x, const float* prm, float* out, float* ws, hipStream_t st, const HeadLoss* hl = nullptr, unsigned* have_out = nullptr,
+                 bool infer = false) {
     const int N = P.N;
     KPartScope kp(ws + P.part, P.part_floats);
     const bool h2 = g_algo == 2;                                 // operand bounds ride along in the workspace
@@ -369,11 +370,12 @@ int unet_forward(const Plan& P, const float* x, const float* prm, float* out, fl
     if (h2 && hipMemsetAsync(am, 0, S_COUNT * sizeof(float), st) != hipSuccess) return (int)hipGetLastError();
     RC(pack_weights(P, prm, ws, hl ? PACK_BOTH : PACK_FWD, st, false, h2 ? am : nullptr));
     const bool first_direct = P.in_ch <= 4;        // conv1_1 straight from the NCHW planes (conv_first.hip)
-    const bool use_codes = P.codes && g_algo == 1 && !(debug_kernel_mask(-1) & 128);   // slope codes for the backward-data epilogues of levels 0 / 1 (Plan::codes)
+    const bool use_codes = !infer && P.codes && g_algo == 1 && !(debug_kernel_mask(-1) & 128);   // slope codes for the backward-data epilogues of levels 0 / 1 (Plan::codes)
     auto CD = [&](size_t off) -> unsigned* { return use_codes ? reinterpret_cast<unsigned*>(ws + off) : nullptr; };
     if (have_out) *have_out = !use_codes ? 0u : ((!first_direct || conv_first_writes_codes(P.in_ch)) ? CODES_EA0 : 0u) | CODES_EA1 | CODES_DA0 | CODES_DA1;
-    if (first_direct && hl) {
-        // fused training forward: the backward reads the caller's x (include/eld_amd.h: it must stay valid and unchanged until that call)
+    if (first_direct && (hl || infer)) {
+        // fused training forward: the backward reads the caller's x (include/eld_amd.h: it must stay valid and unchanged until that call);
+        // inference (eld_unet_infer_ex): no backward follows
     } else if (first_direct) {
         // keep the input for the backward's weight gradient (the backward entry point does not receive x)
         hipError_t e = hipMemcpyAsync(ws + P.x16, x, (size_t)N * P.in_ch * P.H * P.W * sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -432,11 +434,12 @@ int conv_fwd_bf16(const bf16_t* in0, int C0, const bf16_t* in1, int C1, const bf
     return launch_conv(a, CONV_3X3, st);
 }
 
-int unet_forward_bf16(const Plan& P, const float* x, const float* prm, float* out, float* ws, hipStream_t st, const HeadLoss* hl = nullptr, unsigned* have_out = nullptr) {
+int unet_forward_bf16(const Plan& P, const float* x, const float* prm, float* out, float* ws, hipStream_t st, const HeadLoss* hl = nullptr, unsigned* have_out = nullptr,
+                      bool infer = false) {
     const int N = P.N;
     if (P.in_ch > 4) return ELD_ENOTSUP;
     RC(pack_weights(P, prm, ws, hl ? PACK_BOTH : PACK_FWD, st, true));
-    if (!hl) {   // keep the fp32 input for the first layer's weight gradient (the fused training forward leaves it with the caller: see FusedFwd)
+    if (!hl && !infer) {   // keep the fp32 input for the first layer's weight gradient (the fused training forward leaves it with the caller: see FusedFwd)
         hipError_t e = hipMemcpyAsync(ws + P.x16, x, (size_t)N * P.in_ch * P.H * P.W * sizeof(float), hipMemcpyDeviceToDevice, st);
         if (e != hipSuccess) return (int)e;
     }
@@ -444,7 +447,7 @@ int unet_forward_bf16(const Plan& P, const float* x, const float* prm, float* ou
     // Slope codes of the two full-resolution activations whose backward-data epilogues run on conv_bfs_kernel (conv9_2's and conv1_2's: HBM-bound
     // launches that would otherwise re-read the saved 32-channel tensor): written by conv1_1's and conv9_1's epilogues where those kernels are the
     // ones that run (conv_first's MFMA kernel; conv_bfs for the 64 -> 32 layer) -- 8 bytes per pixel instead of 64 in the backward
-    const bool bfs0 = bfs_takes(32, 32, N, P.H, P.W) && !(debug_kernel_mask(-1) & 128);
+    const bool bfs0 = !infer && bfs_takes(32, 32, N, P.H, P.W) && !(debug_kernel_mask(-1) & 128);
     const bool c_ea0 = bfs0 && conv_first_writes_codes(P.in_ch), c_da0 = bfs0 && bfs_takes(32, 64, N, P.H, P.W);
     if (have_out) *have_out = (c_ea0 ? CODES_EA0 : 0u) | (c_da0 ? CODES_DA0 : 0u);
     for (int l = 0; l < NLEV; ++l) {
@@ -719,8 +722,8 @@ static int unet_entry_checks(Plan& P, const void* a, const void* b, const void* 
     return 0;
 }
 
-extern "C" int eld_unet_forward_ex(const float* x, const float* params, float* out, void* ws, size_t ws_bytes, int N, int H, int W,
-                                   int in_ch, int out_ch, int precision, int fp32_algo, void* stream) {
+static int unet_forward_entry(const float* x, const float* params, float* out, void* ws, size_t ws_bytes, int N, int H, int W,
+                              int in_ch, int out_ch, int precision, int fp32_algo, void* stream, bool infer) {
     if (N == 0) return 0;
     if ((precision != 0 && precision != 1) || fp32_algo > 2) return ELD_EINVAL;
     Plan P;
@@ -728,10 +731,18 @@ extern "C" int eld_unet_forward_ex(const float* x, const float* params, float* o
     AlgoScope scope(fp32_algo);
     head_state_set(ws, nullptr);      // whatever fused head state the workspace held is overwritten
     unsigned have = 0;
-    const int rc = precision == 1 ? unet_forward_bf16(P, x, params, out, (float*)ws, as_stream(stream), nullptr, &have)
-                                  : unet_forward(P, x, params, out, (float*)ws, as_stream(stream), nullptr, &have);
-    codes_state_set(ws, CodesState{N, H, W, in_ch, out_ch, precision, rc == 0 ? have : 0u});
+    const int rc = precision == 1 ? unet_forward_bf16(P, x, params, out, (float*)ws, as_stream(stream), nullptr, &have, infer)
+                                  : unet_forward(P, x, params, out, (float*)ws, as_stream(stream), nullptr, &have, infer);
+    codes_state_set(ws, CodesState{N, H, W, in_ch, out_ch, precision, rc == 0 ? (infer ? (unsigned)CODES_INFER : have) : 0u});
     return rc;
+}
+extern "C" int eld_unet_forward_ex(const float* x, const float* params, float* out, void* ws, size_t ws_bytes, int N, int H, int W,
+                                   int in_ch, int out_ch, int precision, int fp32_algo, void* stream) {
+    return unet_forward_entry(x, params, out, ws, ws_bytes, N, H, W, in_ch, out_ch, precision, fp32_algo, stream, false);
+}
+extern "C" int eld_unet_infer_ex(const float* x, const float* params, float* out, void* ws, size_t ws_bytes, int N, int H, int W,
+                                 int in_ch, int out_ch, int precision, int fp32_algo, void* stream) {
+    return unet_forward_entry(x, params, out, ws, ws_bytes, N, H, W, in_ch, out_ch, precision, fp32_algo, stream, true);
 }
 
 extern "C" int eld_unet_forward_loss_ex(const float* x, const float* params, const float* target, float* out, float* loss, void* ws, size_t ws_bytes,
@@ -770,6 +781,7 @@ extern "C" int eld_unet_backward_ex(const float* dout, const float* params, floa
         if (after_fused) fused.x = in_ch <= 4 ? hs.x : nullptr;      // (more input planes: the forward converted x to NHWC16 in the workspace)
         fused.packed = !dout;                                         // with an explicit dout the backward packs its own weights (params may have changed)
         fused.codes = codes_state_get(ws, N, H, W, in_ch, out_ch, precision);
+        if (fused.codes & CODES_INFER) return ELD_EINVAL;               // the last forward on this workspace was eld_unet_infer_ex: it kept nothing for a backward
     }
     for (int k = 0; k < n_buckets; ++k)
         if (!bucket_event[k] || bucket_start[k] < 0 || (k > 0 && bucket_start[k] <= bucket_start[k - 1]) || (size_t)bucket_start[k] >= P.nparams) return ELD_EINVAL;

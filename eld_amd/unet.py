@@ -142,8 +142,10 @@ class UNetSeeInDark(nn.Module):
         self._ws.algo[key] = algo
         self._ws.fused_head[key] = False
         self._ws.x_ref.pop(key, None)
-        L.check(L.lib().eld_unet_forward_ex(L.dptr(x), L.dptr(self.flat_params), L.dptr(out), L.dptr(ws), ws.numel(),
-                                            N, H, W, self.in_channels, self.out_channels, 1 if bf16 else 0, algo, L.cur_stream()), 'eld_unet_forward_ex')
+        # save = False (torch.no_grad(): ELDModel.eval / test): the inference entry point -- same output bits, nothing kept for a backward
+        fwd, name = (L.lib().eld_unet_forward_ex, 'eld_unet_forward_ex') if save else (L.lib().eld_unet_infer_ex, 'eld_unet_infer_ex')
+        L.check(fwd(L.dptr(x), L.dptr(self.flat_params), L.dptr(out), L.dptr(ws), ws.numel(),
+                    N, H, W, self.in_channels, self.out_channels, 1 if bf16 else 0, algo, L.cur_stream()), name)
         return out, key, self._ws.gen[key]
 
     def _engine_forward_loss(self, x, target, loss_buf, bf16=False, mse=False, grad_scale=1.0):

@@ -205,6 +205,12 @@ int eld_unet_forward_ex(const float* x, const float* params, float* out, void* w
 int eld_unet_backward_ex(const float* dout, const float* params, float* grads, void* ws, size_t ws_bytes,
                          int N, int H, int W, int in_ch, int out_ch, int precision, int fp32_algo,
                          const int64_t* bucket_start, void* const* bucket_event, int n_buckets, void* stream);
+/* The forward under torch.no_grad() (ELD_model.py:203-307 eval / test: `self.netG(self.input)` with nothing kept): eld_unet_forward_ex's arguments and
+ * bit-identical output, but nothing a backward would need is produced -- no copy of the input in the workspace, no slope codes (round 5: the training
+ * forwards also write 2 bits per element of four activations for the backward-data epilogues).  eld_unet_backward_ex on a workspace whose last forward was
+ * this call returns ELD_EINVAL. */
+int eld_unet_infer_ex(const float* x, const float* params, float* out, void* ws, size_t ws_bytes,
+                      int N, int H, int W, int in_ch, int out_ch, int precision, int fp32_algo, void* stream);
 
 /* How the fp32 3x3 convolutions of eld_unet_forward/backward and eld_conv3x3_* form their products:
  *   0  v_mfma_f32_32x32x2_f32 (fp32 operands);

@@ -713,7 +713,8 @@ def test_slope_codes_give_the_gradients_of_the_saved_activations_bit_for_bit(lib
 def test_backward_reads_slope_codes_only_from_the_forward_that_wrote_them(lib, prec):
     """Which code regions are valid is a property of the LAST forward on a workspace (its fp32 scheme, its kernels), not of the backward's own
     switches: a forward that writes none (fp32: the two-piece scheme; bf16: conv_bfs switched off) followed by a backward whose kernels could read
-    them (a legal call order: the saved tensors have one layout) must fall back to the saved activations -- not read what an earlier forward left."""
+    them (the saved tensors have one layout; include/eld_amd.h asks for one scheme per forward / backward pair, but a caller who mixes them must not be
+    handed another input's slopes silently) falls back to the saved activations -- not to what an earlier forward left."""
     shape = (1, 4, 528, 1072) if prec == 'fp32' else (1, 4, 256, 512)
     net, x, junk, dout = _codes_case(prec, shape, seed=12)
     bf16 = prec == 'bf16'
@@ -741,6 +742,40 @@ def test_backward_reads_slope_codes_only_from_the_forward_that_wrote_them(lib, p
     gb = step(True)
     torch.cuda.synchronize()
     assert torch.equal(ga, gb), int((ga != gb).sum())
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16'])
+@pytest.mark.parametrize('shape', [(1, 4, 64, 144), (2, 4, 272, 560), (1, 4, 528, 1072)])
+def test_inference_entry_point_equals_the_training_forward(lib, prec, shape):
+    """eld_unet_infer_ex (the forward under torch.no_grad(): ELD_model.py:203-307) skips what only a backward reads (input copy, slope codes) and must
+    give eld_unet_forward_ex's output bit for bit; a backward on a workspace it filled last is refused, not served stale operands."""
+    from eld_amd import _lib as L
+    from eld_amd.unet import UNetSeeInDark
+    torch.manual_seed(3)
+    net = UNetSeeInDark(4, 4).cuda()
+    N, _, H, W = shape
+    g = torch.Generator(device='cuda').manual_seed(H)
+    x = torch.rand(*shape, device='cuda', generator=g) ** 2.2
+    p = 1 if prec == 'bf16' else 0
+    nbytes = lib.eld_unet_workspace_bytes(N, H, W, 4, 4)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+    o_train, o_inf, grads = torch.empty_like(x), torch.empty_like(x), torch.empty_like(net.flat_params)
+    args = (L.dptr(ws), nbytes, N, H, W, 4, 4, p, 1, L.cur_stream())
+    assert lib.eld_unet_forward_ex(L.dptr(x), L.dptr(net.flat_params), L.dptr(o_train), *args) == 0
+    assert lib.eld_unet_infer_ex(L.dptr(x), L.dptr(net.flat_params), L.dptr(o_inf), *args) == 0
+    dout = torch.randn(*shape, device='cuda', generator=g)
+    rc = lib.eld_unet_backward_ex(L.dptr(dout), L.dptr(net.flat_params), L.dptr(grads), L.dptr(ws), nbytes, N, H, W, 4, 4, p, 1, None, None, 0, L.cur_stream())
+    assert rc != 0                                                   # nothing was kept for a backward
+    assert lib.eld_unet_forward_ex(L.dptr(x), L.dptr(net.flat_params), L.dptr(o_train), *args) == 0
+    rc = lib.eld_unet_backward_ex(L.dptr(dout), L.dptr(net.flat_params), L.dptr(grads), L.dptr(ws), nbytes, N, H, W, 4, 4, p, 1, None, None, 0, L.cur_stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(o_inf, o_train)
+    # the module: no_grad forwards go through the inference entry point, and a training step on the same module still works afterwards
+    net.inference_precision = prec
+    net.fp32_products = 1
+    with torch.no_grad():
+        assert torch.equal(net(x), o_train)
 
 
 def test_forward_loss_argument_checks(lib):
