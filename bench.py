@@ -261,6 +261,7 @@ def main():
     ap.add_argument('--noise', default='PGRU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt', action='store_true', help='skip the alt_fp16x2_products leg (profiling runs: only the default kernels in the trace)')
+    ap.add_argument('--prefetch', type=int, default=1, help='1: synthesise batch i+1 on the side stream during step i (Engine.train default); 0: serial')
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'], help="U-Net precision; the contract's metric is quoted on fp32 (BASELINE configs[1]); bf16 = configs[2]")
     args = ap.parse_args()
 
@@ -293,9 +294,21 @@ def main():
     total_steps = args.steps + args.warmup
     plists = [[nm._sample_params() for _ in range(B)] for _ in range(total_steps)]     # _sample_params semantics, host side
 
+    batches = {}
+
+    def batch(i):
+        if i not in batches:
+            ids = [(i * world * B) + rank + world * k for k in range(B)]      # global sample indices
+            batches[i] = {'target': clean, 'params': plists[i % len(plists)], 'sample_ids': ids}
+        return batches[i]
+
     def step(i):
-        ids = [(i * world * B) + rank + world * k for k in range(B)]      # global sample indices
-        model.set_input({'target': clean, 'params': plists[i % len(plists)], 'sample_ids': ids}, 'train')
+        # Engine.train's loop body (eld_amd/engine.py): batch i (already synthesised on the side stream when the previous step prefetched it),
+        # then batch i+1's synthesis is started beside this step's U-Net kernels -- one sampler launch per step either way
+        model.set_input(batch(i), 'train')
+        batches.pop(i, None)
+        if args.prefetch:
+            model.prefetch_input(batch(i + 1), 'train')
         model.optimize_parameters()
         return model.get_current_errors()['Pixel']           # loss.item(): the reference's per-iteration device sync (ELD_model.py:480)
 
@@ -411,6 +424,36 @@ def main():
         torch.cuda.synchronize()
         t_in = [e0.elapsed_time(e1) for e0, e1 in evs[1:]]
         sampler_in_step_ms = min(t_in)
+        # ... and what of it the step still waits for when the launch was prefetched on the synthesis stream during the previous step
+        # (events on the launch stream around set_input: only the wait for the side stream's event is left there), beside the same steps
+        # with the prefetch switched off (same box, same process)
+        sampler_exposed_ms, serial_ms, prefetch_ms = None, None, None
+        if args.prefetch:
+            base = total_steps + 40
+            evs2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(4)]
+            model.set_input(batch(base), 'train'); model.prefetch_input(batch(base + 1), 'train'); model.optimize_parameters()
+            for i, (e0, e1) in enumerate(evs2):
+                e0.record()
+                model.set_input(batch(base + 1 + i), 'train')
+                e1.record()
+                model.prefetch_input(batch(base + 2 + i), 'train')
+                model.optimize_parameters()
+            torch.cuda.synchronize()
+            sampler_exposed_ms = min(e0.elapsed_time(e1) for e0, e1 in evs2[1:])
+            if world == 1 and not args.no_alt:
+                def timed_steps(first, n, pf):
+                    keep, args.prefetch = args.prefetch, pf
+                    try:
+                        step(first); torch.cuda.synchronize()
+                        t0_ = time.perf_counter()
+                        for k in range(n):
+                            step(first + 1 + k)
+                        torch.cuda.synchronize()
+                        return (time.perf_counter() - t0_) / n * 1e3
+                    finally:
+                        args.prefetch = keep
+                serial_ms = timed_steps(total_steps + 60, 5, 0)
+                prefetch_ms = timed_steps(total_steps + 70, 5, 1)
         model.exchange = True
         # BASELINE.json configs[2] (bf16 U-Net with MFMA convs, batch 8) beside the headline: the same step with the bf16 engine, its own
         # roofline against the 2.5 PF/s bf16 peak.  `value` above stays on configs[1] (fp32).
@@ -478,6 +521,10 @@ def main():
                                    'traffic_source': 'profiles/traffic.json (committed PMC pass; not re-measured in this run)',
                                    'algorithmic_bytes': 8 * yb.numel(), 'ms_per_launch': round(t_s, 4), 'mpix_s': round(yb.numel() / (t_s * 1e-3) / 1e6, 1),
                                    'in_step_ms': round(sampler_in_step_ms, 4),
+                                   'exposed_ms': (round(sampler_exposed_ms, 4) if sampler_exposed_ms is not None else None),
+                                   'exposed_note': 'what the launch stream still waits for when the launch was issued on the synthesis stream during the previous '
+                                                   'step (ELDModel.prefetch_input, the default of Engine.train and of this bench); step time with / without that '
+                                                   'prefetch, 5 steps each, same process: %s / %s ms' % (prefetch_ms and round(prefetch_ms, 3), serial_ms and round(serial_ms, 3)),
                                    'in_step_note': 'the same kernel on the step\'s own %d frames, HIP events around the synthesis call inside a full step '
                                                    '(clock and caches as the preceding Adam / MFMA kernels leave them); in-step frac %.4f' % (
                                                        B, 8.0 * B * 4 * Hh * Ww / (sampler_in_step_ms * 1e-3) / 1e9 / PEAK_HBM_GBS)}

@@ -54,6 +54,7 @@ SIGNATURES = {
     'eld_conv_fp32_algo': (_i, [_i]),
     'eld_debug_conv_prof': (None, [_vp]),
     'eld_debug_kernel_mask': (_i, [_i]),
+    'eld_debug_ws_state_entries': (_i, []),
     'eld_isp_process': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _i, _vp]),
     'eld_quality_assess_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'eld_quality_assess': (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _i, _i, _f, _vp]),
@@ -76,6 +77,7 @@ SIGNATURES = {
 }
 
 
+ABI_VERSION = 2         # ELD_ABI_VERSION of include/eld_amd.h this binding was written against
 PHILOX_ROUNDS = 7      # the sampler's generator: Philox4x32-7 (csrc/philox.h); checked against the library at load
 
 
@@ -102,14 +104,16 @@ def load_library(path=None):
     import torch  # noqa: F401
     lib_ = C.CDLL(p)
     any_philox = bool(os.environ.get('ELD_AMD_ANY_PHILOX'))
+    lib_.eld_abi_version.restype = C.c_int
+    if lib_.eld_abi_version() != ABI_VERSION and not any_philox:      # before binding: an older library fails here, not with a missing-symbol AttributeError
+        raise RuntimeError('libeld_amd ABI version %d, this package binds version %d of include/eld_amd.h: rebuild with `python __graft_entry__.py`'
+                           % (lib_.eld_abi_version(), ABI_VERSION))
     for name, (res, args) in SIGNATURES.items():
         if name == 'eld_philox_rounds' and any_philox and not hasattr(lib_, name):
             continue                      # dev A/B runs against a library older than the symbol (tools/build_variant.sh <old rev>)
         fn = getattr(lib_, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib_.eld_abi_version() != 1:
-        raise RuntimeError('libeld_amd ABI version mismatch')
     if not any_philox and lib_.eld_philox_rounds() != PHILOX_ROUNDS:
         # the noise stream of a (seed, sample id) pair depends on the round count: a library built with another -DELD_PHILOX_ROUNDS replays
         # different noise for the same checkpoint / seed ("noise streams")

@@ -95,7 +95,11 @@ __device__ __forceinline__ void pool_epilogue(const ConvArgs& a, const f32x16 (&
     }
 }
 
-template <int BN, int RPW, bool DB, bool BFIRST = false>
+// BSLAB (round 6): the weights arrive PRE-SPLIT in conv_x3d_kernel's slab layout (x3_store, unet_misc.hip: the exact LDS image of a stage's slab, rows of
+// 3 pieces x 16 bf16 + pad) and a stage's slab is copied global -> registers -> LDS as it is (three 16-byte units per thread): no weight cut per
+// stage and tile (a fifth of this kernel's VALU work and a third of its ds_write instructions); the register staging and the two 4-wave workgroups
+// per CU stay (the LDS-DMA variants of this layer shape, conv_x3d_kernel<32, ...>, need a second slab buffer and lose the second workgroup).
+template <int BN, int RPW, bool DB, bool BFIRST = false, bool BSLAB = false>
 __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
     constexpr int CK = 16;
     constexpr int TH = 4 * RPW, NT = BN / 32, A_PIX = (TH + 2) * (TW + 2);
@@ -111,19 +115,24 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
     const int total_tiles = a.tiles_x * a.tiles_y * a.N * NB;
     const int Cs0 = a.C0;
 
-    constexpr int A_UNITS = A_PIX * 4, B_UNITS = B_ROWS * 4;
+    constexpr int A_UNITS = A_PIX * 4, B_UNITS = BSLAB ? B_ROWS * 7 : B_ROWS * 4;      // BSLAB: 16-byte units of the slab image (112-byte rows)
     constexpr int A_IT = (A_UNITS + 255) / 256, B_IT = (B_UNITS + 255) / 256;
+    constexpr int SLAB_BYTES = (B_ROWS * PX * 4 + 1023) / 1024 * 1024;                      // x3_slab_stride(BN)
     float4 ra[A_IT], rb[B_IT];
     constexpr unsigned OOB = 0xFFFFFFF0u;
     unsigned a_voff[A_IT], b_voff[B_IT];
     int l_img = 0;
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (int)((size_t)9 * a.Nout * Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, BSLAB ? (int)((size_t)3 * (Cin / CK) * NB * SLAB_BYTES) : (int)((size_t)9 * a.Nout * Cin * 4), 0x00020000);
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
         const int u = tid + it * 256;
-        const int row = stage_row(u >> 2, B_ROWS), part = u & 3;
-        const int kx = row / BN, n = row - kx * BN;
-        b_voff[it] = u < B_UNITS ? (unsigned)((kx * a.Nout + n) * Cin * 4 + part * 16) : OOB;
+        if constexpr (BSLAB) {
+            b_voff[it] = u < B_UNITS ? (unsigned)(u * 16) : OOB;
+        } else {
+            const int row = stage_row(u >> 2, B_ROWS), part = u & 3;
+            const int kx = row / BN, n = row - kx * BN;
+            b_voff[it] = u < B_UNITS ? (unsigned)((kx * a.Nout + n) * Cin * 4 + part * 16) : OOB;
+        }
     }
 
     auto decode = [&](int t, int& nb, int& img, int& y0, int& x0) {
@@ -149,6 +158,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
         }
     };
     auto load_A = [&](int c0) {
+        if (ELD_DBG(a) & 4) return;              // (dev ablation, compiled out of production builds: no staging loads)
         const char* src = static_cast<const char*>(c0 < a.C0 ? a.in0 : a.in1);
         const int cs = c0 < a.C0 ? c0 : c0 - a.C0;
         const size_t img_bytes = (size_t)a.H * a.W * Cs0 * 4;
@@ -158,12 +168,14 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
             ra[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)a_voff[it], cs * 4, 0));
     };
     auto load_B = [&](int nb, int c0, int ky) {
-        const int wsoff = ((ky * 3 * a.Nout + nb * BN) * Cin + c0) * 4;
+        if (ELD_DBG(a) & 4) return;
+        const int wsoff = BSLAB ? ((ky * (Cin / CK) + c0 / CK) * NB + nb) * SLAB_BYTES : ((ky * 3 * a.Nout + nb * BN) * Cin + c0) * 4;
 #pragma unroll
         for (int it = 0; it < B_IT; ++it)
             rb[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)b_voff[it], wsoff, 0));
     };
     auto store_A = [&]() {
+        if (ELD_DBG(a) & 16) return;             // (dev ablation: no halo cut / LDS stores)
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int u = tid + it * 256;
@@ -171,10 +183,12 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
         }
     };
     auto store_B = [&]() {
+        if (ELD_DBG(a) & 8) return;              // (dev ablation: no slab stores)
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
             const int u = tid + it * 256;
-            if (u < B_UNITS) split_store(ldsB + stage_row(u >> 2, B_ROWS) * PX + (u & 3) * 2, rb[it]);
+            if constexpr (BSLAB) { if (u < B_UNITS) *reinterpret_cast<float4*>(ldsB + u * 4) = rb[it]; }      // the slab image as it is: consecutive lanes, consecutive 16 bytes
+            else if (u < B_UNITS) split_store(ldsB + stage_row(u >> 2, B_ROWS) * PX + (u & 3) * 2, rb[it]);
         }
     };
 
@@ -226,6 +240,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
                 }
                 uint4 fx[DB ? 2 : 1][3][RPW], fw[DB ? 2 : 1][3][NT];
                 __builtin_amdgcn_s_setprio(0);
+                if (ELD_DBG(a) & 2) continue;    // (dev ablation: no fragment reads, no MFMAs)
                 auto read_tap = [&](int kx, uint4 (&X)[3][RPW], uint4 (&Wt)[3][NT]) {
 #pragma unroll
                     for (int r = 0; r < RPW; ++r) {
@@ -282,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
         }
 
         // ---- epilogue: identical to conv_igemm.hip's (lane (m, hi) owns pixel x0+m and channels 8q+4hi..+3 of each 32-block)
-        {
+        if (!(ELD_DBG(a) & 1)) {
             // stores in the full-line layout (conv.h f32_line_store: 16 pixels x 64 contiguous bytes per instruction); bias / saved activations are
             // read in the MFMA layout (own pixel m); every lane computes and takes part in the exchange, only loads and stores are predicated
             const int x = x0 + m;
@@ -372,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
                 }
             }
         }
-        if (a.epi == EPI_FWD && a.pool_out != nullptr) {
+        if (a.epi == EPI_FWD && a.pool_out != nullptr && !(ELD_DBG(a) & 1)) {
             int img_p[RPW / 2], y_p[RPW / 2];
 #pragma unroll
             for (int rp = 0; rp < RPW / 2; ++rp) { img_p[rp] = img; y_p[rp] = y0 + wave * RPW + 2 * rp; }
@@ -486,6 +501,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
         }
     };
     auto load_A = [&](int c0) {
+        if (ELD_DBG(a) & 4) return;              // (dev ablation, compiled out of production builds: no halo loads)
         const char* src = static_cast<const char*>(c0 < a.C0 ? a.in0 : a.in1);
         const int cs = c0 < a.C0 ? c0 : c0 - a.C0;
         const size_t img_bytes = (size_t)a.H * a.W * Cs0 * 4;
@@ -496,6 +512,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
             ra[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)a_voff[it], cs * 4, 0));
     };
     auto store_A = [&]() {
+        if (ELD_DBG(a) & 16) return;             // (dev ablation: no halo cut / LDS stores)
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int u = tid + it * THREADS;
@@ -504,6 +521,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
     };
     // slab (nb, chunk, ky) -> LDS buffer `buf`: wave w moves pieces w, w + WAVES, ...
     auto dma_B = [&](int buf, int nb, int chunk, int ky) {
+        if (ELD_DBG(a) & 8) return;              // (dev ablation: no slab DMA)
         const unsigned soff = (unsigned)(((ky * NCH + chunk) * NB + nb) * (B_WORDS * 4));
 #pragma unroll
         for (int it = 0; it < DMA_IT; ++it) {
@@ -566,6 +584,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
                     else if (t_next < total_tiles) { setup_load(t_next / KS); load_A(chunk_begin(t_next) * CK); }
                 }
                 __builtin_amdgcn_s_setprio(0);
+                if (ELD_DBG(a) & 2) { buf ^= 1; continue; }      // (dev ablation: no fragment reads, no MFMAs)
                 const float* lb = ldsB + buf * B_WORDS;
                 uint4 fx[DB ? 2 : 1][3][RPW], fw[DB ? 2 : 1][3][NT];
                 auto read_tap = [&](int kx, uint4 (&X)[3][RPW], uint4 (&Wt)[3][NT]) {
@@ -631,7 +650,8 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
             pix = ok ? (size_t)((img0 + dimg) * a.H + y) * a.W + x : 0;
             return ok;
         };
-        if (KS > 1) {                            // split K: raw partial sums of this K part, [part][image][y][x][Nout]
+        if (ELD_DBG(a) & 1) {                    // (dev ablation: no epilogue)
+        } else if (KS > 1) {                     // split K: raw partial sums of this K part, [part][image][y][x][Nout]
             float* pbase = a.kpart + (size_t)(t % KS) * ((size_t)a.N * a.H * a.W * a.Nout);
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
@@ -728,7 +748,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
                 }
             }
         }
-        if (KS == 1 && a.epi == EPI_FWD && a.pool_out != nullptr) {     // pooled launches run TH x 32 tiles (launcher): slot m of column r = tile pixel (wave * RPW + r, m)
+        if (KS == 1 && a.epi == EPI_FWD && a.pool_out != nullptr && !(ELD_DBG(a) & 1)) {     // pooled launches run TH x 32 tiles (launcher): slot m of column r = tile pixel (wave * RPW + r, m)
             int img_p[RPW / 2], y_p[RPW / 2];                           // (a lane's row pairs may lie on both sides of a seam of the strip)
 #pragma unroll
             for (int rp = 0; rp < RPW / 2; ++rp) {
@@ -992,7 +1012,7 @@ int launch_x3_splitk_finish(const ConvArgs& a, hipStream_t st) {
     return 0;
 }
 
-template <int BN, int RPW, bool DB, bool BFIRST = false>
+template <int BN, int RPW, bool DB, bool BFIRST = false, bool BSLAB = false>
 int launch_x3(ConvArgs a, hipStream_t st) {
     constexpr int TH = 4 * RPW;
     a.tiles_x = (a.W + TW - 1) / TW;
@@ -1001,12 +1021,12 @@ int launch_x3(ConvArgs a, hipStream_t st) {
     const long long tiles = (long long)a.tiles_x * a.tiles_y * a.N * (a.Nout / BN);
     if (tiles <= 0) return 0;
     if (tiles > 0x7fffffffLL) return ELD_ENOTSUP;
-    auto kern = conv_x3_kernel<BN, RPW, DB, BFIRST>;
+    auto kern = conv_x3_kernel<BN, RPW, DB, BFIRST, BSLAB>;
     static EldAttrOnce once;
     { const int rc = once.ensure(kern, lds_bytes); if (rc) return rc; }
     int per_cu = (int)((160 * 1024) / lds_bytes);
     if (per_cu > 2) per_cu = 2;
-    if (per_cu < 1) per_cu = 1;
+    if (per_cu < 1 || (ELD_DBG(a) & 64)) per_cu = 1;
     long long grid = (long long)eld_num_cus() * per_cu;
     if (grid > tiles) grid = tiles;
     ELD_LAUNCH(kern, dim3((unsigned)grid), dim3(256), lds_bytes, st, a);
@@ -1080,6 +1100,15 @@ int launch_x3_gemm(ConvArgs a, hipStream_t st) {
 
 void conv_x3_set_prof(unsigned long long*) {}       // the s_memtime stage profiler of round 1 is gone with the kernel it instrumented
 
+static bool x3_32_slabs() {
+    static const int on = [] { const char* e = getenv("ELD_X3_BSLAB"); return e ? atoi(e) : 0; }();      // measured 0.0 ... +0.3 % against the per-stage cut (profiles/r06_ab_notes.md): opt-in
+    return on != 0;
+}
+static bool x3d_32_kernel(int N, int H, int W) {      // opt-in ELD_X3D_32=1: the 32-channel layers on the LDS-DMA kernel (measured slower, see x3_slab_bn)
+    static const int on = [] { const char* e = getenv("ELD_X3D_32"); return e ? atoi(e) : 0; }();
+    return on && x3_32_slabs() && conv_tile_count(N, H, W, 32, false) >= 2 * eld_num_cus();
+}
+
 // Tile shapes of the LDS-DMA kernel (measured, profiles/r02_*): 16-row tiles with ONE 8-wave workgroup per CU; 128 output channels per
 // tile where the layer has them (half the halo cuts per MFMA), else 64.  Layers with 32 output channels stay on the register-staged
 // conv_x3_kernel<32, 4> with two workgroups per CU: their K loop is 2-4 chunks long and a lone workgroup cannot hide its epilogue
@@ -1094,9 +1123,11 @@ int x3_slab_bn(int Nout, int N, int H, int W, int* waves) {
     // conv_x3_kernel<32, 4> (3087 vs 2917 us per launch, same box): one 8-wave workgroup per CU loses more to its barriers than the two 4-wave
     // workgroups of the register-staged kernel lose to the weight cut.  Off by default.
     if (Nout == 32) {
-        static const int on = [] { const char* e = getenv("ELD_X3D_32"); return e ? atoi(e) : 0; }();
         // (round 5: conv_x3d_kernel<32, 2, 4> -- the same slabs, 8-row tiles, two 4-wave workgroups per CU -- measured +10.7 %: not kept either)
-        return (on && conv_tile_count(N, H, W, 32, false) >= 2 * eld_num_cus()) ? 32 : 0;
+        // Round 6 (opt-in ELD_X3_BSLAB=1): the 32-channel layers take pre-split slabs too -- consumed through registers by conv_x3_kernel<32, 4, ..., BSLAB>:
+        // a fifth of the kernel's VALU instructions gone and no change in its time (2848-2862 vs 2842-2854 us per launch, same box, interleaved): the
+        // kernel is not bound by VALU issue.  Default: fp32 packed weights cut per stage, the round-5 kernel.
+        return x3_32_slabs() ? 32 : 0;
     }
     if (Nout % 64) return 0;
     const long long px_tiles = conv_tile_count(N, H, W, 16, false);
@@ -1116,9 +1147,10 @@ int launch_conv_x3(const ConvArgs& a_in, hipStream_t st) {
     int waves = 8;
     const int bn0 = x3_slab_bn(a.Nout, a.N, a.H, a.W, nullptr);
     // conv_x3d_kernel addresses a two-image window (virtual rows)
-    if (bn0 && a.N > 1 && (size_t)a.H * a.W * a.C0 * 8 >= 0xFFFFFFF0ull) return ELD_ENOTSUP;
+    if ((bn0 >= 64 || (bn0 == 32 && x3d_32_kernel(a.N, a.H, a.W))) && a.N > 1 && (size_t)a.H * a.W * a.C0 * 8 >= 0xFFFFFFF0ull) return ELD_ENOTSUP;
     const int bn = x3_slab_bn(a.Nout, a.N, a.H, a.W, &waves);
-    if (bn == 32) return launch_x3d<32, 4, 8, false>(a, st);
+    if (bn == 32 && x3d_32_kernel(a.N, a.H, a.W)) return launch_x3d<32, 4, 8, false>(a, st);
+    if (bn == 32) return launch_x3<32, 4, false, true, true>(a, st);      // pre-split slabs through registers (round 6)
     if (bn == 128) return launch_x3d<128, 2, 8, false>(a, st);      // weights pre-split in slab layout: LDS-DMA kernel
     if (bn == 64) return waves == 8 ? launch_x3d<64, 2, 8, false>(a, st) : launch_x3d<64, 2, 4, false>(a, st);
     // round 5: the next stage's slab loads are issued AHEAD of the halo loads (template BFIRST; -2.7 % per launch, same box); ELD_X3_BFIRST=0 restores the

@@ -679,36 +679,68 @@ extern "C" size_t eld_unet_workspace_bytes(int N, int H, int W, int in_ch, int o
 // workspace pointer; a plain forward on the same workspace clears the entry.  Host bookkeeping only: no device read, no synchronisation.
 namespace {
 struct HeadState { int N, H, W, in_ch, out_ch, precision; const float* x; };
-std::mutex g_head_mu;
-std::unordered_map<const void*, HeadState> g_head;
 // Which slope-code regions the last forward on a workspace filled, and for which problem (FusedFwd::codes): same bookkeeping, for EVERY forward
 struct CodesState { int N, H, W, in_ch, out_ch, precision; unsigned have; };
-std::unordered_map<const void*, CodesState> g_codes;
+// One table for both, keyed by the workspace pointer.  Workspaces come and go with their owners, so the table is bounded -- by evicting the ONE
+// least recently touched entry, never by clearing it: an entry that is still between its forward and its backward is by construction among the most
+// recently touched ones (it would take WS_STATE_MAX other workspaces run in between to push it out).  What a lost entry costs: no codes entry sends
+// the backward to the saved activations (same bits); no head entry makes the dout == NULL backward fail with ELD_EINVAL.
+struct WsState { HeadState head; bool has_head = false; CodesState codes; bool has_codes = false; unsigned long long stamp = 0; };
+constexpr size_t WS_STATE_MAX = 256;
+std::mutex g_head_mu;
+std::unordered_map<const void*, WsState> g_ws_state;
+unsigned long long g_ws_clock = 0;
+WsState& ws_state_touch(const void* ws) {          // caller holds g_head_mu
+    auto it = g_ws_state.find(ws);
+    if (it == g_ws_state.end()) {
+        if (g_ws_state.size() >= WS_STATE_MAX) {
+            auto old = g_ws_state.begin();
+            for (auto j = g_ws_state.begin(); j != g_ws_state.end(); ++j) if (j->second.stamp < old->second.stamp) old = j;
+            g_ws_state.erase(old);
+        }
+        it = g_ws_state.emplace(ws, WsState()).first;
+    }
+    it->second.stamp = ++g_ws_clock;
+    return it->second;
+}
+void ws_state_drop_if_empty(const void* ws) {       // caller holds g_head_mu
+    const auto it = g_ws_state.find(ws);
+    if (it != g_ws_state.end() && !it->second.has_head && !it->second.has_codes) g_ws_state.erase(it);
+}
 void codes_state_set(const void* ws, const CodesState& cs) {
     std::lock_guard<std::mutex> lk(g_head_mu);
-    if (cs.have == 0) { g_codes.erase(ws); return; }
-    if (g_codes.size() > 256) g_codes.clear();           // (a lost entry only sends the backward to the saved activations)
-    g_codes[ws] = cs;
+    if (cs.have == 0) {
+        const auto it = g_ws_state.find(ws);
+        if (it != g_ws_state.end()) { it->second.has_codes = false; ws_state_drop_if_empty(ws); }
+        return;
+    }
+    WsState& w = ws_state_touch(ws);
+    w.codes = cs; w.has_codes = true;
 }
 unsigned codes_state_get(const void* ws, int N, int H, int W, int in_ch, int out_ch, int precision) {
     std::lock_guard<std::mutex> lk(g_head_mu);
-    const auto it = g_codes.find(ws);
-    if (it == g_codes.end()) return 0;
-    const CodesState& c = it->second;
+    const auto it = g_ws_state.find(ws);
+    if (it == g_ws_state.end() || !it->second.has_codes) return 0;
+    it->second.stamp = ++g_ws_clock;
+    const CodesState& c = it->second.codes;
     return c.N == N && c.H == H && c.W == W && c.in_ch == in_ch && c.out_ch == out_ch && c.precision == precision ? c.have : 0u;
 }
 void head_state_set(const void* ws, const HeadState* st) {
     std::lock_guard<std::mutex> lk(g_head_mu);
     if (st) {
-        if (g_head.size() > 256) g_head.clear();      // workspaces come and go with their owners: stay small
-        g_head[ws] = *st;
-    } else g_head.erase(ws);
+        WsState& w = ws_state_touch(ws);
+        w.head = *st; w.has_head = true;
+    } else {
+        const auto it = g_ws_state.find(ws);
+        if (it != g_ws_state.end()) { it->second.has_head = false; ws_state_drop_if_empty(ws); }
+    }
 }
 bool head_state_is(const void* ws, HeadState& want) {      // fills want.x (the fused forward's input tensor) on a match
     std::lock_guard<std::mutex> lk(g_head_mu);
-    const auto it = g_head.find(ws);
-    if (it == g_head.end()) return false;
-    const HeadState& h = it->second;
+    const auto it = g_ws_state.find(ws);
+    if (it == g_ws_state.end() || !it->second.has_head) return false;
+    it->second.stamp = ++g_ws_clock;
+    const HeadState& h = it->second.head;
     if (!(h.N == want.N && h.H == want.H && h.W == want.W && h.in_ch == want.in_ch && h.out_ch == want.out_ch && h.precision == want.precision)) return false;
     want.x = h.x;
     return true;
@@ -816,6 +848,8 @@ extern "C" int eld_unet_backward_buckets(const float* dout, const float* params,
                                          int n_buckets, void* stream) {
     return eld_unet_backward_ex(dout, params, grads, ws, ws_bytes, N, H, W, in_ch, out_ch, precision, -1, bucket_start, bucket_event, n_buckets, stream);
 }
+
+extern "C" int eld_debug_ws_state_entries(void) { std::lock_guard<std::mutex> lk(g_head_mu); return (int)g_ws_state.size(); }
 
 extern "C" void eld_debug_conv_prof(void* buf) { conv_x3_set_prof((unsigned long long*)buf); }
 

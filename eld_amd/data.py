@@ -158,6 +158,12 @@ class ELDTrainDataset(tdata.Dataset):
         # the same target database, no `size` wrap-around) the clean patch IS the target: it is read once and travels once.  Decided once per
         # input dataset, so that every sample of a run carries the same keys (default_collate takes them from the first sample of a batch).
         self._shared = [self._shares_target(d) for d in input_datasets]
+        # Data parallel (the reference is single-device): every rank's DataLoader walks ITS shard of the pairs -- item i of rank r is
+        # pair i * world + r, ceil(total / world) items on every rank (the tail wraps: the gradient exchange averages per-rank means, so local batch
+        # sizes must agree) -- so that world x batchSize DIFFERENT pairs make up a global batch under the unmodified train_syn.py.  Taken from the
+        # torchrun environment at construction (the workers are forked later and inherit it).
+        from . import dist as D
+        self.world, self.rank = (D.world_size(), D.rank()) if D.world_size() > 1 else D.env_world()[:2]
 
     def _shares_target(self, d):
         if not isinstance(d, SynDataset):
@@ -172,14 +178,20 @@ class ELDTrainDataset(tdata.Dataset):
         except TypeError:
             return False
 
+    def _total(self):
+        return self.size or len(self.target_dataset) * len(self.input_datasets)
+
     def __getitem__(self, i):
         N = len(self.input_datasets)
+        if self.world > 1:
+            from .dist import shard_item
+            i = shard_item(i, self._total(), self.rank, self.world)
         inp = self.input_datasets[i % N][i // N]
         same = self._shared[i % N] and isinstance(inp, Deferred) and inp.isp is None and inp.index == i // N
         if self._shared[i % N] and isinstance(inp, Deferred) and inp.isp is None and not same:
             # the clean patch was declared to BE the target for this input dataset (no 'clean' key travels): a sample whose SynDataset index differs
             # from its pair index would be degraded from the wrong patch without a sign of trouble
-            raise IndexError('ELDTrainDataset: sample %d pairs target %d with SynDataset patch %d although both read the same database '
+            raise RuntimeError('ELDTrainDataset: sample %d pairs target %d with SynDataset patch %d although both read the same database '
                              '(index wrap-around): give the SynDataset its own dataset object' % (i, i // N, inp.index))
         target = inp.clean if same else self.target_dataset[i // N]
         bits = 0
@@ -215,7 +227,7 @@ class ELDTrainDataset(tdata.Dataset):
         return dic
 
     def __len__(self):
-        return self.size or len(self.target_dataset) * len(self.input_datasets)
+        return (self._total() + self.world - 1) // self.world
 
 
 def worker_init_fn(worker_id):                               # dataset/sid_dataset.py:17-18

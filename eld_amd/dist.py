@@ -60,12 +60,21 @@ def allreduce_sum_(flat, bucket=BUCKET_FLOATS):
     return w
 
 
+def bucket_ranges(numel, bucket=BUCKET_FLOATS):
+    """[(lo, hi)] of the buckets of a flat gradient buffer in REDUCTION order: top-down, the order in which the engine's backward makes them
+    final (it produces the flat buffer from its end towards its start: head, decoder, encoder -- the reverse of named_parameters())."""
+    numel, bucket = int(numel), int(bucket)
+    starts = list(range(0, numel, bucket))
+    return [(lo, min(lo + bucket, numel)) for lo in reversed(starts)]
+
+
 class GradBuckets:
     """Bucket table of a flat CUDA gradient buffer for the overlapped exchange: ascending start offsets, one CUDA event per
     bucket (recorded by the engine's backward on the compute stream) and a communication stream."""
 
     def __init__(self, numel, device, bucket=BUCKET_FLOATS):
         self.numel = int(numel)
+        self.bucket = int(bucket)
         self.starts = list(range(0, self.numel, int(bucket)))
         self.events = [torch.cuda.Event() for _ in self.starts]
         with torch.cuda.device(device):
@@ -84,9 +93,8 @@ class GradBuckets:
         if w == 1:
             return 1
         handles = []
-        for k in range(self.n - 1, -1, -1):
-            lo = self.starts[k]
-            hi = self.starts[k + 1] if k + 1 < self.n else self.numel
+        for k, (lo, hi) in zip(range(self.n - 1, -1, -1), bucket_ranges(self.numel, self.bucket)):
+            assert lo == self.starts[k]
             self.stream.wait_event(self.events[k])
             with torch.cuda.stream(self.stream):
                 handles.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
@@ -107,6 +115,36 @@ def shard_indices(n, rank_=None, world=None):
     r = rank() if rank_ is None else rank_
     w = world_size() if world is None else world
     return list(range(r, n, w))
+
+
+def shard_len(n, world=None):
+    """Length of every rank's shard of n items: ceil(n / world) -- equal on all ranks (the tail wraps around to the first items, as
+    torch.utils.data.DistributedSampler pads), because the gradient exchange averages per-rank MEANS (equal local batch sizes)."""
+    w = world_size() if world is None else world
+    return (int(n) + w - 1) // w
+
+
+def shard_item(i, n, rank_=None, world=None):
+    """Global index of item i of this rank's shard of n items (rank-strided; indices past n wrap to the start)."""
+    r = rank() if rank_ is None else rank_
+    w = world_size() if world is None else world
+    g = int(i) * w + r
+    return g % int(n) if n else g
+
+
+def allreduce_meters(sums, counts):
+    """Sum the (sum, count) pairs of running means over all ranks (evaluation sharded by image: SURVEY.md 8(e) "replicas only"); dicts of floats /
+    ints with the same keys on every rank.  Returns (sums, counts) of the whole job; identity for world size 1."""
+    if world_size() == 1:
+        return dict(sums), dict(counts)
+    keys = sorted(sums)
+    t = torch.tensor([float(sums[k]) for k in keys] + [float(counts[k]) for k in keys], dtype=torch.float64)
+    if dist.get_backend() == 'nccl':
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    v = t.cpu().tolist()
+    n = len(keys)
+    return {k: v[i] for i, k in enumerate(keys)}, {k: int(round(v[n + i])) for i, k in enumerate(keys)}
 
 
 def allreduce_mean_scalar(x):

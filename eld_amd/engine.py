@@ -49,12 +49,24 @@ class Engine(object):
         # ELD_AMD_LOG_EVERY=k: read the loss back (one device sync) every k-th iteration only.  Default 1 = the reference's behaviour: it reads
         # loss.item() every iteration (engine.py:48-53, ELD_model.py:480).  An environment switch, not an option: the reference's CLI has no such flag.
         log_every = max(1, int(os.environ.get('ELD_AMD_LOG_EVERY', '1') or 1))
-        for i, data in enumerate(train_loader):
+        # One batch of lookahead (ELD_AMD_PREFETCH=0 switches it off): batch i+1 is fetched from the loader and its on-device synthesis started on the
+        # model's synthesis stream before iteration i's U-Net kernels are enqueued -- the reference overlaps synthesis with training the same way,
+        # through its DataLoader workers (train_syn.py:78-80).  Batches, host draws and results are those of the plain loop, in the same order.
+        prefetch = os.environ.get('ELD_AMD_PREFETCH', '1') != '0' and hasattr(model, 'prefetch_input')
+        it = iter(train_loader)
+        data = next(it, None)
+        i = 0
+        while data is not None:
             model.set_input(data, mode='train')
+            nxt = next(it, None)
+            if prefetch and nxt is not None:
+                model.prefetch_input(nxt, mode='train')
             model.optimize_parameters(**kwargs)
             if i % log_every == 0:                   # the reference reads loss.item() every iteration (ELD_model.py:480)
                 avg_meters.update(model.get_current_errors())
             self.iterations += 1
+            data = nxt
+            i += 1
         self.epoch += 1
         if not getattr(self.opt, 'no_log', False):
             if self.epoch % getattr(self.opt, 'save_epoch_freq', 100) == 0:
@@ -67,9 +79,14 @@ class Engine(object):
 
     def eval(self, val_loader, dataset_name, savedir=None, loss_key=None, **kwargs):       # engine.py:75-99
         avg_meters = AverageMeters()
+        world, rank = D.world_size(), D.rank()
         with torch.no_grad():
-            for data in val_loader:
+            for i, data in enumerate(val_loader):
+                if world > 1 and i % world != rank:      # evaluation shards by image over the ranks ("replicas only": no data-path collective)
+                    continue
                 avg_meters.update(self.model.eval(data, savedir=savedir, **kwargs))
+        if world > 1:                                    # ... and only the scalar sums travel: every rank ends with the whole job's means
+            avg_meters.sum, avg_meters.n = D.allreduce_meters(avg_meters.sum, avg_meters.n)
         if loss_key is not None and avg_meters[loss_key] < self.best_val_loss:
             self.best_val_loss = avg_meters[loss_key]
             self.model.save(label='best_{}_{}'.format(loss_key, dataset_name))

@@ -154,6 +154,7 @@ class ELDModel:
         self._loss_buf = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.noise_model = NoiseModel.last_instance      # the plugin instance the entry script built (train_syn.py:38); may be None
         self._sample_counter = 0
+        self._synth_stream, self._prefetched = None, None    # prefetch_input(): synthesis of the NEXT batch on a side stream
         # Philox key: the run's --seed (base_option.py:22) unless overridden; per-image counters are global sample indices
         self.seed = int(os.environ.get('ELD_AMD_SEED', getattr(opt, 'seed', None) if getattr(opt, 'seed', None) is not None else 2018))
         if getattr(opt, 'resume', False):
@@ -169,7 +170,40 @@ class ELDModel:
         without 'input' is a batch of DEFERRED samples (eld_amd.data: clean 'target' codes + 'params' records + 'aug' bits +
         'burst'): what SynDataset / ELDTrainDataset.__getitem__ do per sample on the CPU (sid_dataset.py:259-280, 332-363) then
         happens here, batched, on the device: decode -> sampler + clip (burst frames concatenated on the channel axis) ->
-        flips / transpose of input AND target -> clip."""
+        flips / transpose of input AND target -> clip.
+        A batch that prefetch_input() already started (same dict object) is picked up from the synthesis stream instead."""
+        pre, self._prefetched = self._prefetched, None
+        if pre is not None and pre[0] is data and pre[1] == mode.lower():
+            _, _, prepared, ev = pre
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev)
+            for t in prepared[:2]:
+                if t is not None and t.is_cuda:
+                    t.record_stream(cur)                 # allocated on the synthesis stream, consumed (and released) on this one
+        else:
+            if pre is not None:                          # a prefetch nobody picks up: its draws were consumed; keep stream order sane and drop it
+                torch.cuda.current_stream().wait_event(pre[3])
+            prepared = self._prepare(data, mode)
+        self.input, self.target, self.data_name, self.rawpath = prepared
+
+    def prefetch_input(self, data, mode='train'):
+        """Start set_input(data, mode) on the synthesis stream and return at once: the sampler launch of iteration i+1 then runs beside the
+        U-Net kernels of iteration i (what the reference gets from its DataLoader workers, train_syn.py:78-80 / sid_dataset.py:259-280, where
+        synthesis of the next batch overlaps the training step).  Call it AFTER set_input() of the current batch and BEFORE optimize_parameters():
+        the synthesis stream first waits for everything the current stream holds at this point (the previous iteration), so host-side draws
+        (_sample_params, sample ids) and device results are exactly those of the serial order.  set_input(data) with the same dict picks the
+        tensors up; any other set_input() discards the prefetch."""
+        if self._synth_stream is None:
+            self._synth_stream = torch.cuda.Stream(self.device)
+        s = self._synth_stream
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            prepared = self._prepare(data, mode)
+            ev = torch.cuda.Event()
+            ev.record(s)
+        self._prefetched = (data, mode.lower(), prepared, ev)
+
+    def _prepare(self, data, mode):
         mode = mode.lower()
         if mode not in ('train', 'eval', 'test'):
             raise NotImplementedError('Mode [%s] is not implemented' % mode)
@@ -208,9 +242,7 @@ class ELDModel:
             target = decode_augment_u16(target, bits) if is_u16_codes(target) else augment(target, bits, clip=False)
         elif is_u16_codes(target):
             target = decode_augment_u16(target)
-        self.input, self.target = inp, target
-        self.data_name = data.get('fn')
-        self.rawpath = data.get('rawpath')
+        return inp, target, data.get('fn'), data.get('rawpath')
 
     def synthesize(self, clean, params=None, sample_ids=None, burst=1):
         """noisy = clip(noise_model(clean)) on device, one Philox sample id per synthesised frame (global index: rank-strided so

@@ -27,7 +27,10 @@
 extern "C" {
 #endif
 
-#define ELD_ABI_VERSION 1
+/* 2 (round 6): eld_unet_infer_ex and eld_debug_ws_state_entries exist; the U-Net workspace grew (slope-code regions) -- size it with
+ * eld_unet_workspace_bytes of the SAME library; eld_unet_backward_ex accepts an explicit dout after eld_unet_forward_loss_ex and refuses a backward
+ * after eld_unet_infer_ex.  A binding must compare eld_abi_version() with the ELD_ABI_VERSION it was written against. */
+#define ELD_ABI_VERSION 2
 
 /* negative = argument errors (hipError_t values are >= 0) */
 #define ELD_EINVAL   (-1)   /* bad shape / flag combination / null pointer                   */
@@ -267,6 +270,9 @@ void eld_debug_conv_prof(void* buf);
  * implementations of the same sums: tests/test_model_gpu.py runs the oracle comparison under each); bit 7 = the U-Net forwards write no slope codes (the backward-data
  * epilogues of levels 0 / 1 then read the saved activations, as before round 5: same slopes, bit-identical gradients).  Returns the previous mask.  Process-wide; production never calls it. */
 int eld_debug_kernel_mask(int mask);
+/* Test hook: live entries of the per-workspace host bookkeeping (which forward last filled a workspace: fused head, slope codes); bounded, evicted
+ * one least-recently-touched entry at a time. */
+int eld_debug_ws_state_entries(void);
 
 /* ---- single layers on NHWC float32 tensors with reference-layout weights; used by the parity tests ---- */
 size_t eld_layer_workspace_bytes(int N, int H, int W, int Cin, int Cout);

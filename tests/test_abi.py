@@ -23,7 +23,8 @@ def test_library_exports_every_declared_symbol(eld_lib):
         assert hasattr(eld_lib, n), 'libeld_amd.so does not export %s' % n
         assert n in _lib.SIGNATURES, 'eld_amd/_lib.py does not bind %s' % n
     assert sorted(_lib.SIGNATURES) == names
-    assert eld_lib.eld_abi_version() == 1
+    hdr = int(re.search(r'#define ELD_ABI_VERSION (\d+)', open(os.path.join(ROOT, 'include', 'eld_amd.h')).read()).group(1))
+    assert eld_lib.eld_abi_version() == hdr == _lib.ABI_VERSION      # header, library and binding name the same ABI
     assert b'gfx950' in eld_lib.eld_build_info()
     assert b'EINVAL' in eld_lib.eld_error_string(-1)
 
@@ -179,6 +180,43 @@ def test_hand_issued_loads_are_not_touched_before_their_wait(src_name, kernel, w
         others = set(range(int(m.group(1)), int(m.group(2)) + 1)) | regs_of(m.group(3)) | regs_of(m.group(4)) | {int(m.group(5))}
         return (regs_of(code) & pending) == {hi} and hi not in others
 
+    def reads_writes(code):
+        """(registers read, registers written) of one compiler instruction: the first operand is the destination except for stores / compares
+        into SGPRs (which write no VGPR); every other VGPR mentioned is a source.  Conservative: a destination that is also a source counts as read."""
+        ops = code.split(None, 1)
+        if len(ops) < 2:
+            return set(), set()
+        parts = [p_.strip() for p_ in ops[1].split(',')]
+        mnem = ops[0]
+        no_vdst = mnem.startswith(('global_store', 'buffer_store', 'ds_write', 'ds_store', 's_', 'v_cmp', 'v_cmpx', 'v_readfirstlane', 'v_readlane', 'scratch_store'))
+        wr = set() if no_vdst else regs_of(parts[0])
+        rd = set()
+        for p_ in (parts if no_vdst else parts[1:]):
+            rd |= regs_of(p_)
+        return rd, wr
+
+    def high_half_dead(block_idx, pos, dst_hi):
+        """The exemption above holds only if the HIGH half of the multiply-add's 64-bit result is never used: from the instruction on, every path
+        must overwrite v<dst_hi> before reading it (or end)."""
+        seen, work = set(), [(block_idx, pos + 1)]
+        while work:
+            bi, start = work.pop()
+            if (bi, start) in seen:
+                continue
+            seen.add((bi, start))
+            ins = blocks[bi]['ins']
+            killed = False
+            for is_asm, code in ins[start:]:
+                rd, wr = (regs_of(code), set()) if is_asm else reads_writes(code)
+                if dst_hi in rd:
+                    return False
+                if dst_hi in wr:
+                    killed = True
+                    break
+            if not killed:
+                work.extend((j, 0) for j in succ[bi])
+        return True
+
     pend_in = [set() for _ in blocks]
     checked, violations = 0, []
     changed = True
@@ -187,7 +225,7 @@ def test_hand_issued_loads_are_not_touched_before_their_wait(src_name, kernel, w
         checked, violations = 0, []
         for i, b in enumerate(blocks):
             pending = set(pend_in[i])
-            for is_asm, code in b['ins']:
+            for pos, (is_asm, code) in enumerate(b['ins']):
                 if is_asm:
                     m = re.match(r'global_load_dwordx4 v\[(\d+):(\d+)\]', code)
                     m1 = re.match(r'global_load_dword v(\d+),', code)
@@ -200,8 +238,13 @@ def test_hand_issued_loads_are_not_touched_before_their_wait(src_name, kernel, w
                             checked += 1
                         pending = set()
                     continue
-                if pending and (regs_of(code) & pending) and not undef_high_addend(code, pending):
-                    violations.append(code)
+                if pending and (regs_of(code) & pending):
+                    ok = undef_high_addend(code, pending)
+                    if ok:      # ... and the result's high half (the only place the placeholder's value can reach) must be dead
+                        mm = re.match(r'v_mad_[ui]64_[ui]32 v\[(\d+):(\d+)\]', code)
+                        ok = high_half_dead(i, pos, int(mm.group(2)))
+                    if not ok:
+                        violations.append(code)
             for j in succ[i]:
                 if not pending <= pend_in[j]:
                     pend_in[j] |= pending

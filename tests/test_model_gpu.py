@@ -231,6 +231,57 @@ def test_engine_train_loop(eld_lib, tmp_path, capsys):
     assert 'learning rate = 0.0000500' in out and 'Epoch: 0' in out
 
 
+def test_prefetched_synthesis_equals_the_serial_order_bit_for_bit(eld_lib, tmp_path, monkeypatch):
+    """Engine.train's one-batch lookahead (ELDModel.prefetch_input: the sampler launch of batch i+1 on the synthesis stream beside iteration i's
+    U-Net kernels -- the reference overlaps synthesis and training through DataLoader workers, train_syn.py:78-80) changes no bit: the same
+    host draws in the same order, the same sample ids, the same parameters after every epoch as the plain loop (ELD_AMD_PREFETCH=0)."""
+    from eld_amd.engine import Engine
+    from eld_amd.noise import NoiseModel
+    import io
+    import contextlib
+
+    def run(prefetch):
+        monkeypatch.setenv('ELD_AMD_PREFETCH', prefetch)
+        np.random.seed(7)
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            nm = NoiseModel(model='PGRU', include=4)
+            eng = Engine(make_opt(tmp_path / ('pf' + prefetch), no_log=True))
+        eng.model.set_noise_model(nm)
+        g = torch.Generator().manual_seed(3)
+        # deferred batches: clean targets only, parameters drawn by the model at synthesis time (np.random order matters), ragged last batch
+        loader = [{'target': torch.floor(65535.0 * torch.rand(n, 4, 48, 64, generator=g) ** 2.2) / 65535.0} for n in (2, 2, 1, 2, 1)]
+        inputs, losses = [], []
+        keep = eng.model.optimize_parameters
+
+        def spy(**kw):
+            inputs.append(eng.model.input.clone())
+            keep(**kw)
+        eng.model.optimize_parameters = spy
+        for _ in range(2):
+            with contextlib.redirect_stdout(io.StringIO()):
+                losses.append(eng.train(loader)['Pixel'])
+        torch.cuda.synchronize()
+        return inputs, losses, eng.model.netG.flat_params.detach().clone(), eng.model._sample_counter
+    a, b = run('1'), run('0')
+    assert len(a[0]) == len(b[0]) == 10 and a[3] == b[3] == 16
+    for x, y in zip(a[0], b[0]):
+        assert torch.equal(x, y)
+    assert a[1] == b[1]
+    assert torch.equal(a[2], b[2])
+    # a prefetch nobody picks up is dropped, and set_input of another batch is the plain path
+    from eld_amd.model import ELDModel  # noqa: F401
+    m = new_model(tmp_path / 'drop')
+    with contextlib.redirect_stdout(io.StringIO()):
+        m.set_noise_model(NoiseModel(model='Pg', include=4))
+    d1, d2 = {'target': torch.rand(1, 4, 32, 32)}, {'input': torch.rand(1, 4, 32, 32), 'target': torch.rand(1, 4, 32, 32)}
+    m.prefetch_input(d1)
+    m.set_input(d2)
+    assert m._prefetched is None and torch.equal(m.input.cpu(), d2['input'])
+    m.optimize_parameters()
+    assert np.isfinite(m.get_current_errors()['Pixel'])
+
+
 def test_model_requires_gpu_and_raw_stage(eld_lib, tmp_path):
     from eld_amd.model import ELDModel
     with pytest.raises(RuntimeError):

@@ -18,5 +18,6 @@ for r in csv.DictReader(open(f[0])):
     if any(p in r['Name'] for p in sys.argv[3].split(',')):
         print('   %-70s calls %5s avg %9.1f us' % (r['Name'][:70], r['Calls'], float(r['AverageNs']) / 1e3))
 PY
+  rm -rf $O/prof_$tag
  done
 done
