@@ -141,12 +141,13 @@ def cpu_baseline(h, w, seed=2018):
       * sampler: NumPy port, single thread like noise.py (np.random is single-threaded), on ONE full 4 x h x w image, for the
         full model 'PGRU' and for the reference's own 'Pg' (noise.py:158-166); plus the reference's real deployment, 8 forked
         DataLoader workers (--nThreads 8, base_option.py:26), one 'Pg' image each, as an aggregate rate;
-      * U-Net: one torch-CPU fp32 training step (forward + L1 + backward + Adam, up to 32 threads) on ONE full 4 x h x w frame
-        (after a warm-up step on a 512 x 512 crop).
+      * U-Net: one torch-CPU fp32 training step (forward + L1 + backward + Adam) on ONE full 4 x h x w frame, with the fastest thread count of a
+        sweep over {32, 64, 128, all host cores} made on a 512 x 512 crop (recorded on the line).
     value = combined per-pixel rate of (PGRU sampler, 1 thread) + (U-Net step)."""
     import multiprocessing as mp
     from oracle import noise_ref as O
     from oracle import unet_ref as U
+    t_begin = time.time()
     rs = np.random.RandomState(seed)
     y = (np.floor(65535.0 * rs.uniform(size=(4, h, w)) ** 2.2) / 65535.0).astype(np.float32)
     t_full = min(_cpu_sampler_worker((y, 'PGRU', seed + i)) for i in range(2))
@@ -156,8 +157,6 @@ def cpu_baseline(h, w, seed=2018):
     with mp.get_context('fork').Pool(workers) as pool:
         pool.map(_cpu_sampler_worker, [(y, 'Pg', seed + 100 + i) for i in range(workers)])
     t_pool = time.time() - t0
-    cores = min(os.cpu_count() or 1, 32)     # torch-CPU convs stop scaling (and oversubscribe) beyond a few dozen threads
-    torch.set_num_threads(cores)
     sd = U.seeded_state_dict(4, 4, seed=seed)
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     opt = torch.optim.Adam(list(params.values()), lr=1e-4)
@@ -170,23 +169,42 @@ def cpu_baseline(h, w, seed=2018):
         opt.step()
         loss.item()                      # the reference reads loss.item() every iteration (ELD_model.py:480)
         return time.time() - t0
+    # torch-CPU on the host cores of THIS box.  The thread count is swept once on the reference's own training shape (one 4x512x512
+    # crop: 32, 64, 128, all cores; each setting one warm-up step + min of 2) and the fastest setting runs the full frame -- torch-CPU convolutions
+    # stop scaling, and then lose, well before 256 threads, so "all cores" is measured rather than assumed.
+    ncpu = os.cpu_count() or 1
     x512 = torch.from_numpy(y[None, :, :min(512, h), :min(512, w)].copy())
-    cpu_step(x512)                                           # warm-up (thread pool, oneDNN primitives)
-    t_512 = min(cpu_step(x512) for _ in range(2))            # the reference's own training shape (BASELINE.md sec. 2 quotes this one)
-    xf = torch.from_numpy(y[None].copy())
-    t_unet = min(cpu_step(xf) for _ in range(2))             # full frame, min of 2
-    npx = 4.0 * h * w
     npx512 = 4.0 * min(512, h) * min(512, w)
+    sweep = {}
+    for nt in sorted(set(min(t, ncpu) for t in (32, 64, 128, ncpu))):
+        torch.set_num_threads(nt)
+        cpu_step(x512)                                       # warm-up (thread pool, oneDNN primitives)
+        sweep[nt] = min(cpu_step(x512) for _ in range(2))
+    cores = min(sweep, key=sweep.get)
+    torch.set_num_threads(cores)
+    t_512 = sweep[cores]                                     # the reference's own training shape (BASELINE.md sec. 2 quotes this one)
+    xf = torch.from_numpy(y[None].copy())
+    t_unet = cpu_step(xf)                                    # full frame (a second run only while the whole baseline stays near 30 s)
+    if time.time() - t_begin < 22.0:
+        t_unet = min(t_unet, cpu_step(xf))
+    npx = 4.0 * h * w
     per_pix = t_full / npx + t_unet / npx
     return {'value': round(1e-6 / per_pix, 4), 'unit': 'raw MPix/s', 'cores': cores, 'kind': 'port',
             'sample': 'one 4x%dx%d frame: NumPy sampler port PGRU %.2f s (1 thread, min of 2), Pg %.2f s (1 thread), 8 forked workers x 1 Pg image '
-                      '%.2f s wall; torch-CPU fp32 U-Net train step (fwd, L1, bwd, Adam, loss.item()) on the full frame %.2f s (%d threads, min of 2, after '
-                      '512x512 warm-up steps) and on one 4x512x512 crop %.3f s (min of 2); value = PGRU sampler + full-frame U-Net step per pixel' % (
+                      '%.2f s wall; torch-CPU fp32 U-Net train step (fwd, L1, bwd, Adam, loss.item()) on the full frame %.2f s (%d threads = the fastest of the '
+                      'thread sweep, after 512x512 warm-up steps) and on one 4x512x512 crop %.3f s (min of 2); value = PGRU sampler + full-frame U-Net step per pixel' % (
                           h, w, t_full, t_pg, t_pool, t_unet, cores, t_512),
             'sampler_mpix_s': round(npx / t_full / 1e6, 3), 'sampler_Pg_mpix_s': round(npx / t_pg / 1e6, 3),
             'sampler_Pg_8workers_mpix_s': round(workers * npx / t_pool / 1e6, 3), 'unet_step_mpix_s': round(npx / t_unet / 1e6, 4),
             'unet_step_512_mpix_s': round(npx512 / t_512 / 1e6, 4), 'unet_step_512_s': round(t_512, 3),
-            'os_cpu_count': os.cpu_count()}
+            'threads_sweep_512_mpix_s': {str(k): round(npx512 / v / 1e6, 4) for k, v in sorted(sweep.items())},
+            'os_cpu_count': ncpu, 'seconds': round(time.time() - t_begin, 1),
+            # kind "port": what the port costs relative to the reference itself, measured where both run (the build container, 8 cores, identical inputs,
+            # sampler outputs asserted bit-equal): profiles/r04_cpu_port_vs_reference.md
+            'port_over_reference_time': {'sampler_Pg_full_frame': 1.11, 'sampler_g_full_frame': 1.22, 'unet_step_512': 0.93,
+                                         'source': 'profiles/r04_cpu_port_vs_reference.md (tools/cpu_port_vs_reference.py, build container)',
+                                         'note': 'the port is 7-22 % slower than the reference on the sampler (it also records its variates) and 7 % faster on '
+                                                 'the U-Net step, which dominates value: the stated baseline is the reference\'s cost to within that'}}
 
 
 def eval_sweep_leg(dev, precision, frames=3, batch=8):
@@ -238,7 +256,16 @@ def eval_sweep_leg(dev, precision, frames=3, batch=8):
     gb_corr, gb_q = 16.0 * npx / (st[2] * 1e-3) / 1e9, 8.0 * npx / (st[3] * 1e-3) / 1e9
     psnr, ssim = q.mean(dim=0).tolist()
     net.release_workspaces()
+    # the reference evaluates with batch size 1 (test_ELD.py:44-52 -> DataLoader(batch_size=1)): the like-for-like single-frame figure rides beside
+    # the batched one (same chain, one frame per launch), so that neither is mistaken for the other
+    single = None
+    if B > 1:
+        r1 = eval_sweep_leg(dev, precision, frames=frames, batch=1)
+        single = {'value': r1['value'], 'unit': 'raw MPix/s', 'ms_per_frame': r1['ms_per_frame'], 'frames_per_launch': 1,
+                  'unet_inference_tflops': r1['unet_inference_tflops'], 'stage_ms_per_frame': r1['stage_ms_per_frame'],
+                  'note': "the reference's evaluation batch size (1 frame per launch); `value` of this leg is the BATCHED rate (%d frames per launch)" % B}
     return {'value': round(npx / (tot * 1e-3) / 1e6, 1), 'unit': 'raw MPix/s', 'ms_per_frame': round(tot / B, 3), 'frames_per_launch': B, 'launches': frames,
+            'batched': B > 1, 'single_frame_launches': single,
             'dtype': 'f32' if precision == 'fp32' else 'bf16',
             'config': {'workload': 'BASELINE.json configs[4], one setting: %s packed %dx%d, ISO %d, ratio x%d, %d synthetic frames per launch; synth (PGRU) -> U-Net '
                                    'inference -> IlluminanceCorrect -> tensor2im + PSNR + SSIM, all on the device' % (cam, H, W, iso, ratio, B)},

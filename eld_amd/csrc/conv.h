@@ -251,19 +251,24 @@ __device__ __forceinline__ void f32_rows_swap(float4& a, float4& b) {
     r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.z), __float_as_uint(b.z), false, false); a.z = __uint_as_float(r[0]); b.z = __uint_as_float(r[1]);
     r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a.w), __float_as_uint(b.w), false, false); a.w = __uint_as_float(r[0]); b.w = __uint_as_float(r[1]);
 }
-__device__ __forceinline__ void f32_line_store(float4 (&v)[4], float* blk, size_t pstride, int lane, bool row_ok, int valid_px) {
+// 16-byte global store, optionally write-through (sc1: the line leaves the XCD's L2 instead of staying there -- MI355X_MICROARCH.md, stores of each flavour)
+__device__ __forceinline__ void st16(float* p, float4 v, bool wt = false) {
+    if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    else *reinterpret_cast<float4*>(p) = v;
+}
+__device__ __forceinline__ void f32_line_store(float4 (&v)[4], float* blk, size_t pstride, int lane, bool row_ok, int valid_px, bool wt = false) {
     f32_rows_swap(v[0], v[1]);
     f32_rows_swap(v[2], v[3]);
     const int lp = lane & 15;
     float* p0 = blk + (size_t)lp * pstride + 4 * bf16_line_group(lane);      // same row -> piece map {0,2,1,3}
     if (row_ok && lp < valid_px) {
-        *reinterpret_cast<float4*>(p0) = v[0];
-        *reinterpret_cast<float4*>(p0 + 16) = v[2];
+        st16(p0, v[0], wt);
+        st16(p0 + 16, v[2], wt);
     }
     if (row_ok && lp + 16 < valid_px) {
         float* p1 = p0 + 16 * pstride;
-        *reinterpret_cast<float4*>(p1) = v[1];
-        *reinterpret_cast<float4*>(p1 + 16) = v[3];
+        st16(p1, v[1], wt);
+        st16(p1 + 16, v[3], wt);
     }
 }
 
@@ -307,17 +312,17 @@ long long conv_tile_count(int N, int H, int W, int TH, bool pooled);
 
 // f32_line_store for pixel slots whose pixels are per-lane: p0 / p1 = channel 0 of the 32-channel block in the pixels of slot lane & 15 and slot
 // (lane & 15) + 16 of the MFMA column (nullptr: nothing to store).  EVERY lane must take part in the exchange.
-__device__ __forceinline__ void f32_line_store2(float4 (&v)[4], float* p0, float* p1, int lane) {
+__device__ __forceinline__ void f32_line_store2(float4 (&v)[4], float* p0, float* p1, int lane, bool wt = false) {
     f32_rows_swap(v[0], v[1]);
     f32_rows_swap(v[2], v[3]);
     const int g = 4 * bf16_line_group(lane);      // same row -> piece map {0,2,1,3}
     if (p0 != nullptr) {
-        *reinterpret_cast<float4*>(p0 + g) = v[0];
-        *reinterpret_cast<float4*>(p0 + g + 16) = v[2];
+        st16(p0 + g, v[0], wt);
+        st16(p0 + g + 16, v[2], wt);
     }
     if (p1 != nullptr) {
-        *reinterpret_cast<float4*>(p1 + g) = v[1];
-        *reinterpret_cast<float4*>(p1 + g + 16) = v[3];
+        st16(p1 + g, v[1], wt);
+        st16(p1 + g + 16, v[3], wt);
     }
 }
 

@@ -99,7 +99,41 @@ __device__ __forceinline__ void pool_epilogue(const ConvArgs& a, const f32x16 (&
 // 3 pieces x 16 bf16 + pad) and a stage's slab is copied global -> registers -> LDS as it is (three 16-byte units per thread): no weight cut per
 // stage and tile (a fifth of this kernel's VALU work and a third of its ds_write instructions); the register staging and the two 4-wave workgroups
 // per CU stay (the LDS-DMA variants of this layer shape, conv_x3d_kernel<32, ...>, need a second slab buffer and lose the second workgroup).
-template <int BN, int RPW, bool DB, bool BFIRST = false, bool BSLAB = false>
+// Streamed fragment blocks (round 6).  A stage's MFMA work is a sequence of blocks b = (tap kx, pixel row r, channel block tt), six piece products on ONE
+// accumulator each (smallest first: the per-accumulator summation order of the round-5 loops, so results are the same bits).  hipcc's own schedule of the
+// round-5 loops -- with the register file full -- reused one fragment register set serially at the head of every tap (ds_read, s_waitcnt lgkmcnt(0), MFMA,
+// four to five times per tap: an LDS round trip per MFMA) and left the matrix pipe idle for about as long as it ran.  Here the operands a block needs
+// beyond its predecessor's (the pixel fragments when (kx, r) changes, the weight fragments when (kx, tt) changes) are read into the OTHER half of two
+// small double buffers while the predecessor's six MFMAs run, and __builtin_amdgcn_sched_barrier pins that order: 2 x (12 + 12) fragment registers
+// instead of 60 ... 72, no LDS latency in front of any MFMA but a stage's first.
+//   readX(kx, r, X[3]) / readW(kx, tt, W[3]): the three piece fragments of pixel row r / channel block tt at tap kx.
+template <int RPW, int NT, typename RX, typename RW>
+__device__ __forceinline__ void x3_stage_blocks(f32x16 (&acc)[RPW][NT], RX&& readX, RW&& readW) {
+    constexpr int NBLK = 3 * RPW * NT;
+    constexpr int WI[6] = {0, 1, 2, 0, 1, 0};
+    constexpr int XI[6] = {2, 1, 0, 1, 0, 0};
+    uint4 X[2][3], Wf[2][3];
+    readX(0, 0, X[0]);
+    readW(0, 0, Wf[0]);
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+        const int kx = b / (RPW * NT), r = (b / NT) % RPW, tt = b % NT;
+        const int xi = (b / NT) & 1;                                   // the pixel fragments change every NT blocks,
+        const int wi = NT > 1 ? (b & 1) : ((b / RPW) & 1);            // the weight fragments every block (NT > 1) or every tap (NT == 1)
+        if (b + 1 < NBLK) {
+            const int kx1 = (b + 1) / (RPW * NT), r1 = ((b + 1) / NT) % RPW, tt1 = (b + 1) % NT;
+            if (kx1 != kx || r1 != r) readX(kx1, r1, X[xi ^ 1]);
+            if (kx1 != kx || tt1 != tt) readW(kx1, tt1, Wf[wi ^ 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+            acc[r][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Wf[wi][WI[q]]), __builtin_bit_cast(bf16x8, X[xi][XI[q]]), acc[r][tt], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int BN, int RPW, bool DB, bool BFIRST = false, bool BSLAB = false, bool STREAM = false>
 __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
     constexpr int CK = 16;
     constexpr int TH = 4 * RPW, NT = BN / 32, A_PIX = (TH + 2) * (TW + 2);
@@ -154,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
             const int hy = hp / (TW + 2), hx = hp - hy * (TW + 2);
             const int gy = y0 + hy - 1, gx = x0 + hx - 1;
             const bool ok = u < A_UNITS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            a_voff[it] = ok ? (unsigned)(gy * a.W + gx) * (unsigned)(Cs0 * 4) + (unsigned)part * 16u : OOB;
+            a_voff[it] = ok ? (unsigned)(gy * a.W + gx) * (unsigned)((ELD_DBG(a) & 32) ? 64 : Cs0 * 4) + (unsigned)part * 16u : OOB;      // (dev probe 32: a chunk-planar tensor's addresses -- wrong data, full-line fetches)
         }
     };
     auto load_A = [&](int c0) {
@@ -163,9 +197,10 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
         const int cs = c0 < a.C0 ? c0 : c0 - a.C0;
         const size_t img_bytes = (size_t)a.H * a.W * Cs0 * 4;
         const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)l_img * img_bytes), 0, (int)img_bytes, 0x00020000);
+        const int so = (ELD_DBG(a) & 32) ? (cs / 16) * a.H * a.W * 64 : cs * 4;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it)
-            ra[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)a_voff[it], cs * 4, 0));
+            ra[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)a_voff[it], so, 0));
     };
     auto load_B = [&](int nb, int c0, int ky) {
         if (ELD_DBG(a) & 4) return;
@@ -194,6 +229,9 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
 
     int t = blockIdx.x;
     if (t >= total_tiles) return;
+    if ((ELD_DBG(a) & 256) && blockIdx.x >= (gridDim.x >> 1)) {      // (dev probe 256: the second workgroup of a CU starts half a tile period late)
+        for (int i = 0; i < 4; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     setup_load(t);
     load_A(0);
     {
@@ -218,10 +256,10 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
 #pragma unroll BFIRST ? 3 : 1            // (BFIRST: three explicit stages, so that every wait sees a static queue -- see the issue order below)
             for (int ky = 0; ky < 3; ++ky) {
                 __builtin_amdgcn_s_setprio(3);   // the short staging section goes ahead of the co-resident workgroup's MFMA stream
-                __syncthreads();                 // every wave is done with the previous stage's operands
+                if (!(ELD_DBG(a) & 512)) __syncthreads();                 // every wave is done with the previous stage's operands  (dev probe 512: no barriers)
                 if (ky == 0) store_A();
                 store_B();
-                __syncthreads();
+                if (!(ELD_DBG(a) & 512)) __syncthreads();
                 {
                     // Order matters: vmcnt retires in order, so the loads the NEXT stage needs (its weight slab) go first and the halo tile -- needed
                     // three stages from now -- behind them: the compiler's wait for the slab registers then leaves the halo loads in flight (round 5;
@@ -238,9 +276,23 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
                     }
                     if constexpr (!BFIRST) issue_B();
                 }
-                uint4 fx[DB ? 2 : 1][3][RPW], fw[DB ? 2 : 1][3][NT];
                 __builtin_amdgcn_s_setprio(0);
                 if (ELD_DBG(a) & 2) continue;    // (dev ablation: no fragment reads, no MFMAs)
+                if constexpr (STREAM) {
+                    x3_stage_blocks<RPW, NT>(acc,
+                        [&](int kx, int r, uint4 (&X)[3]) {
+                            const float* p = ldsA + ((wave * RPW + r + ky) * (TW + 2) + m + kx) * PX + hi * 4;
+#pragma unroll
+                            for (int pc = 0; pc < 3; ++pc) X[pc] = *reinterpret_cast<const uint4*>(p + pc * 8);
+                        },
+                        [&](int kx, int tt, uint4 (&Wt)[3]) {
+                            const float* p = ldsB + (kx * BN + tt * 32 + m) * PX + hi * 4;
+#pragma unroll
+                            for (int pc = 0; pc < 3; ++pc) Wt[pc] = *reinterpret_cast<const uint4*>(p + pc * 8);
+                        });
+                    continue;
+                }
+                uint4 fx[DB ? 2 : 1][3][RPW], fw[DB ? 2 : 1][3][NT];
                 auto read_tap = [&](int kx, uint4 (&X)[3][RPW], uint4 (&Wt)[3][NT]) {
 #pragma unroll
                     for (int r = 0; r < RPW; ++r) {
@@ -278,6 +330,18 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
                                         acc[r][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[cur][i][tt]),
                                                                                              __builtin_bit_cast(bf16x8, fx[cur][j][r]), acc[r][tt], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else if (ELD_DBG(a) & 1024) {  // (dev probe 1024: the fragment reads without the MFMAs)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        read_tap(kx, fx[0], fw[0]);
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+                            for (int r = 0; r < RPW; ++r) asm volatile("" ::"v"(fx[0][pc][r]));
+#pragma unroll
+                            for (int tt = 0; tt < NT; ++tt) asm volatile("" ::"v"(fw[0][pc][tt]));
+                        }
                     }
                 } else {                         // register budget: one fragment set, the compiler interleaves reads and MFMAs
 #pragma unroll
@@ -383,7 +447,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
                             }
                         }
                     }
-                    f32_line_store(v, blk, (size_t)C, lane, yok, a.W - x0);
+                    f32_line_store(v, blk, (size_t)C, lane, yok, a.W - x0, (ELD_DBG(a) & 128) != 0);      // (dev probe 128: write-through stores)
                 }
             }
         }
@@ -425,7 +489,7 @@ __device__ __forceinline__ void bdma16(i32x4 rsrc, unsigned voff, unsigned soff,
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <int BN, int RPW, int WAVES, bool DB>
+template <int BN, int RPW, int WAVES, bool DB, bool STREAM = false>
 __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES == 8 ? 2 : 1)) void conv_x3d_kernel(const ConvArgs a) {
     constexpr int CK = 16, THREADS = 64 * WAVES;
     constexpr int TH = WAVES * RPW, NT = BN / 32, A_PIX = (TH + 2) * (TW + 2);
@@ -497,7 +561,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
             const bool rok = strip_row(vrel + hy - 1, dimg, y);
             const int gx = x0 + hx - 1;
             const bool ok = u < A_UNITS && hp < APX && rok && gx >= 0 && gx < a.W;      // rows of a second image that does not exist: outside the descriptor
-            a_voff[it] = ok ? (unsigned)((dimg * a.H + y) * a.W + gx) * (unsigned)(Cs0 * 4) + (unsigned)part * 16u : OOB;
+            a_voff[it] = ok ? (unsigned)((dimg * a.H + y) * a.W + gx) * (unsigned)((ELD_DBG(a) & 32) ? 64 : Cs0 * 4) + (unsigned)part * 16u : OOB;      // (dev probe 32, as in conv_x3_kernel)
         }
     };
     auto load_A = [&](int c0) {
@@ -507,9 +571,10 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
         const size_t img_bytes = (size_t)a.H * a.W * Cs0 * 4;
         const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)l_img * img_bytes), 0,
                                                                                 (int)(unsigned)(img_bytes * (size_t)(a.N - l_img < 2 ? a.N - l_img : 2)), 0x00020000);
+        const int so = (ELD_DBG(a) & 32) ? (cs / 16) * a.H * a.W * 64 : cs * 4;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it)
-            ra[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)a_voff[it], cs * 4, 0));
+            ra[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)a_voff[it], so, 0));
     };
     auto store_A = [&]() {
         if (ELD_DBG(a) & 16) return;             // (dev ablation: no halo cut / LDS stores)
@@ -586,6 +651,21 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
                 __builtin_amdgcn_s_setprio(0);
                 if (ELD_DBG(a) & 2) { buf ^= 1; continue; }      // (dev ablation: no fragment reads, no MFMAs)
                 const float* lb = ldsB + buf * B_WORDS;
+                if constexpr (STREAM) {
+                    x3_stage_blocks<RPW, NT>(acc,
+                        [&](int kx, int r, uint4 (&X)[3]) {
+                            const float* p = ldsA + pb[r] + (ky * HWL + kx) * PX;
+#pragma unroll
+                            for (int pc = 0; pc < 3; ++pc) X[pc] = *reinterpret_cast<const uint4*>(p + pc * 8);
+                        },
+                        [&](int kx, int tt, uint4 (&Wt)[3]) {
+                            const float* p = lb + (kx * BN + tt * 32 + m) * PX + hi * 4;
+#pragma unroll
+                            for (int pc = 0; pc < 3; ++pc) Wt[pc] = *reinterpret_cast<const uint4*>(p + pc * 8);
+                        });
+                    buf ^= 1;
+                    continue;
+                }
                 uint4 fx[DB ? 2 : 1][3][RPW], fw[DB ? 2 : 1][3][NT];
                 auto read_tap = [&](int kx, uint4 (&X)[3][RPW], uint4 (&Wt)[3][NT]) {
 #pragma unroll
@@ -744,7 +824,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
                             }
                         }
                     }
-                    f32_line_store2(v, ok0 ? blk + pix0 * C : nullptr, ok1 ? blk + pix1 * C : nullptr, lane);
+                    f32_line_store2(v, ok0 ? blk + pix0 * C : nullptr, ok1 ? blk + pix1 * C : nullptr, lane, (ELD_DBG(a) & 128) != 0);
                 }
             }
         }
@@ -1012,7 +1092,7 @@ int launch_x3_splitk_finish(const ConvArgs& a, hipStream_t st) {
     return 0;
 }
 
-template <int BN, int RPW, bool DB, bool BFIRST = false, bool BSLAB = false>
+template <int BN, int RPW, bool DB, bool BFIRST = false, bool BSLAB = false, bool STREAM = false>
 int launch_x3(ConvArgs a, hipStream_t st) {
     constexpr int TH = 4 * RPW;
     a.tiles_x = (a.W + TW - 1) / TW;
@@ -1021,7 +1101,7 @@ int launch_x3(ConvArgs a, hipStream_t st) {
     const long long tiles = (long long)a.tiles_x * a.tiles_y * a.N * (a.Nout / BN);
     if (tiles <= 0) return 0;
     if (tiles > 0x7fffffffLL) return ELD_ENOTSUP;
-    auto kern = conv_x3_kernel<BN, RPW, DB, BFIRST, BSLAB>;
+    auto kern = conv_x3_kernel<BN, RPW, DB, BFIRST, BSLAB, STREAM>;
     static EldAttrOnce once;
     { const int rc = once.ensure(kern, lds_bytes); if (rc) return rc; }
     int per_cu = (int)((160 * 1024) / lds_bytes);
@@ -1034,7 +1114,7 @@ int launch_x3(ConvArgs a, hipStream_t st) {
     return 0;
 }
 
-template <int BN, int RPW, int WAVES, bool DB>
+template <int BN, int RPW, int WAVES, bool DB, bool STREAM = false>
 int launch_x3d(ConvArgs a, hipStream_t st) {
     constexpr int TH = WAVES * RPW;
     conv_tile_shape(a.N, a.H, a.W, TH, a.pool_out != nullptr, a.tile_h, a.tile_w);
@@ -1058,7 +1138,7 @@ int launch_x3d(ConvArgs a, hipStream_t st) {
         if (ks >= 2) { a.ksplit = ks; tiles *= ks; }
     }
     if (tiles > 0x7fffffffLL) return ELD_ENOTSUP;
-    auto kern = conv_x3d_kernel<BN, RPW, WAVES, DB>;
+    auto kern = conv_x3d_kernel<BN, RPW, WAVES, DB, STREAM>;
     static EldAttrOnce once;
     { const int rc = once.ensure(kern, lds_bytes); if (rc) return rc; }
     int per_cu = (int)((160 * 1024) / lds_bytes);
@@ -1149,14 +1229,20 @@ int launch_conv_x3(const ConvArgs& a_in, hipStream_t st) {
     // conv_x3d_kernel addresses a two-image window (virtual rows)
     if ((bn0 >= 64 || (bn0 == 32 && x3d_32_kernel(a.N, a.H, a.W))) && a.N > 1 && (size_t)a.H * a.W * a.C0 * 8 >= 0xFFFFFFF0ull) return ELD_ENOTSUP;
     const int bn = x3_slab_bn(a.Nout, a.N, a.H, a.W, &waves);
+    // round 6: streamed fragment blocks (x3_stage_blocks) in the main loops; ELD_X3_STREAM=0 restores hipcc's own schedule of the round-5 loops (A/B runs),
+    // a bit mask selects per family: 1 = the 32-channel kernel, 2 = conv_x3d_kernel<64>, 4 = conv_x3d_kernel<128>
+    static const int stream = [] { const char* e = getenv("ELD_X3_STREAM"); return e ? atoi(e) : 7; }();
     if (bn == 32 && x3d_32_kernel(a.N, a.H, a.W)) return launch_x3d<32, 4, 8, false>(a, st);
-    if (bn == 32) return launch_x3<32, 4, false, true, true>(a, st);      // pre-split slabs through registers (round 6)
-    if (bn == 128) return launch_x3d<128, 2, 8, false>(a, st);      // weights pre-split in slab layout: LDS-DMA kernel
-    if (bn == 64) return waves == 8 ? launch_x3d<64, 2, 8, false>(a, st) : launch_x3d<64, 2, 4, false>(a, st);
+    if (bn == 32) return (stream & 1) ? launch_x3<32, 4, false, true, true, true>(a, st) : launch_x3<32, 4, false, true, true>(a, st);      // pre-split slabs through registers (round 6)
+    if (bn == 128) return (stream & 4) ? launch_x3d<128, 2, 8, false, true>(a, st) : launch_x3d<128, 2, 8, false>(a, st);      // weights pre-split in slab layout: LDS-DMA kernel
+    if (bn == 64) {
+        if (waves != 8) return launch_x3d<64, 2, 4, false>(a, st);
+        return (stream & 2) ? launch_x3d<64, 2, 8, false, true>(a, st) : launch_x3d<64, 2, 8, false>(a, st);
+    }
     // round 5: the next stage's slab loads are issued AHEAD of the halo loads (template BFIRST; -2.7 % per launch, same box); ELD_X3_BFIRST=0 restores the
     // round-4 order for A/B runs
     static const int bfirst = [] { const char* e = getenv("ELD_X3_BFIRST"); return e ? atoi(e) : 1; }();
-    if (bfirst) return launch_x3<32, 4, false, true>(a, st);
+    if (bfirst) return (stream & 1) ? launch_x3<32, 4, false, true, false, true>(a, st) : launch_x3<32, 4, false, true>(a, st);
     return launch_x3<32, 4, false>(a, st);
 }
 

@@ -527,10 +527,12 @@ def test_unet_step_is_hipgraph_capturable(eld_lib):
     assert torch.equal(out_r, out_e2) and torch.equal(grads_r, grads_e2) and torch.equal(net.flat_params.detach(), p_r)
 
 
-def test_bench_two_rank_line_has_the_scaling_keys(eld_lib):
-    """bench.py's N > 1 path end to end on ONE GPU (two ranks share the device over gloo; RCCL itself needs two devices:
+@pytest.mark.parametrize('world,batch', [(2, 1), (8, 8)], ids=['dp2', 'dp8_global_batch_64'])
+def test_bench_multi_rank_line_has_the_scaling_keys(eld_lib, world, batch):
+    """bench.py's N > 1 path end to end on ONE GPU (the ranks share the device over gloo; RCCL itself needs N devices:
     tests/test_dist_gpu.py): the line the driver's SCALE run parses must carry the whole-job value, per-rank step times and the
-    all-reduce accounting (bytes, buckets, exposed time, ring floor), so that the first 8-GPU run yields a complete record."""
+    all-reduce accounting (bytes, buckets, exposed time, ring floor), so that the first 8-GPU run yields a complete record.
+    dp8: BASELINE configs[3]'s shape of the job -- 8 ranks x 8 frames = global batch 64 (small frames here: eight processes on one device)."""
     import json
     import socket
     import subprocess
@@ -538,22 +540,24 @@ def test_bench_two_rank_line_has_the_scaling_keys(eld_lib):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, ELD_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-                        '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '1',
-                        '--height', '256', '--width', '256', '--no-cpu-baseline'], capture_output=True, text=True, timeout=900, env=env)
+    hw = '256' if world == 2 else '128'
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', str(world), '--steps', '2', '--warmup', '1', '--batch', str(batch),
+                        '--height', hw, '--width', hw, '--no-cpu-baseline'], capture_output=True, text=True, timeout=1500, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, lines                                   # rank 0 prints ONE line
     line = json.loads(lines[0])
-    assert line['n_gpus'] == 2 and line['steps'] == 2 and line['warmup'] == 1 and line['scaling'] == 'weak' and line['higher_is_better'] is True
+    assert line['n_gpus'] == world and line['steps'] == 2 and line['warmup'] == 1 and line['scaling'] == 'weak' and line['higher_is_better'] is True
     assert line['unit'] == 'raw MPix/s' and line['metric'].startswith('raw megapixels/sec')
-    assert line['config']['global_batch'] == 2 and line['config']['parallelism'] == 'dp2'
-    px = 2 * 1 * 4 * 256 * 256                                      # whole-job pixels per step: all ranks
+    assert line['config']['global_batch'] == world * batch and line['config']['parallelism'] == 'dp%d' % world
+    assert line['config']['images_per_gpu'] == batch
+    px = world * batch * 4 * int(hw) * int(hw)                      # whole-job pixels per step: all ranks
     assert abs(line['value'] - px / (line['ms_per_step'] * 1e-3) / 1e6) <= 1e-3 * line['value']
-    assert len(line['per_rank_ms_per_step']) == 2 and all(t > 0 for t in line['per_rank_ms_per_step'])
+    assert len(line['per_rank_ms_per_step']) == world and all(t > 0 for t in line['per_rank_ms_per_step'])
     ar = line['allreduce']
-    assert ar['bytes'] == 4 * 7760484 and ar['buckets'] >= 1
+    assert ar['bytes'] == 4 * 7760484 and ar['buckets'] == 4       # 8 MiB buckets of the 31 MB gradient buffer
     for k in ('exposed_ms', 'ring_floor_ms', 'ms_per_step_without_exchange'):
         assert isinstance(ar[k], float) and ar[k] >= 0.0, k
-    assert abs(ar['ring_floor_ms'] - 2.0 * (2 - 1) / 2 * ar['bytes'] / 153e9 * 1e3) < 1e-3
+    assert abs(ar['ring_floor_ms'] - 2.0 * (world - 1) / world * ar['bytes'] / 153e9 * 1e3) < 1e-3
     assert 'roofline' in line and 'roofline_sampler' in line

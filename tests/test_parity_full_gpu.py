@@ -250,17 +250,19 @@ def test_bench_shape_batch8_gradients_are_the_mean_of_single_frames(lib):
     assert not fails, fails
 
 
-def test_bf16_full_frame_step_vs_f64_oracle(lib):
-    """BASELINE configs[2] at frame size: the bf16 engine (conv_bfd_kernel, wgrad8_kernel<bf16>, bf16 transposed convs, fused pools)
-    against the FLOAT64 oracle -- not against the fp32 engine.  bf16 activations carry 8 significant bits, so the bound is not 1e-5:
-    output PSNR >= 60 dB, loss within 1e-3 relative, and per gradient tensor cosine >= 0.995 with relative L2
-    error <= 0.10; the measured per-tensor figures go to the parity table."""
+# bf16 engine against the FLOAT64 oracle.  Bounds = at most 3x the measured worst case of the round-5 build at frame size (profiles/r05_parity.md: cosine
+# 0.99981, relative L2 1.95 % on conv5_2's weight gradient; <= 1 % outside the 512-channel level): a regression of the kernels -- not only a wrong tensor --
+# must trip them.  conv5_x sums its weight gradient over the fewest pixels (89 x 133 per frame) of bf16-rounded gradients that passed through every layer.
+BF16_COS = 0.9995
+BF16_REL_DEEP, BF16_REL = 0.06, 0.03
+
+
+def bf16_compare(tag, lib, shape, zero=None):
     from eld_amd import _lib as L
     from eld_amd.unet import UNetSeeInDark, param_offsets
     torch.manual_seed(2018)
     net = UNetSeeInDark(4, 4)
     sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
-    shape = (1, 4, 1424, 2128)
     g = torch.Generator().manual_seed(11)
     x = torch.floor(65535.0 * torch.rand(*shape, generator=g) ** 2.2) / 65535.0
     t = torch.rand(*shape, generator=g)
@@ -276,27 +278,57 @@ def test_bf16_full_frame_step_vs_f64_oracle(lib):
     out, grads, loss = out.double().cpu(), grads.double().cpu(), float(loss.item())
     del net
     torch.cuda.empty_cache()
+    offs = param_offsets(4, 4)
+    names = list(sd.keys())
+    if zero is not None:                              # negative control: wipe one tensor's gradient, the check must notice
+        a_, b_ = offs[names.index(zero)], offs[names.index(zero) + 1]
+        grads[a_:b_] = 0
     r64 = oracle_f64(sd, x, t)
     assert r64 is not None, 'float64 oracle unavailable'
     o64, l64, g64 = r64
     mse = float(torch.mean((out * 255 - o64 * 255) ** 2))
     psnr = 10 * float(torch.log10(torch.tensor(255.0 ** 2 / mse)))
-    rec = {'case': 'bf16_frame1424x2128', 'shape': list(shape), 'loss': loss, 'loss_f64': l64, 'output_psnr_db': psnr, 'tensors': []}
-    offs = param_offsets(4, 4)
+    rec = {'case': tag, 'shape': list(shape), 'loss': loss, 'loss_f64': l64, 'output_psnr_db': psnr,
+           'bounds': {'cosine': BF16_COS, 'rel_l2_conv5': BF16_REL_DEEP, 'rel_l2': BF16_REL}, 'tensors': []}
     fails = []
-    for (name, ref), a, b in zip(g64.items(), offs[:-1], offs[1:]):
-        r, q = ref.reshape(-1).double(), grads[a:b]
+    for (name, ref), a_, b_ in zip(g64.items(), offs[:-1], offs[1:]):
+        r, q = ref.reshape(-1).double(), grads[a_:b_]
         cos = float(torch.dot(r, q) / (r.norm() * q.norm() + 1e-300))
         rel = float((q - r).norm() / (r.norm() + 1e-300))
+        lim = BF16_REL_DEEP if name.startswith('conv5_') else BF16_REL
         row = {'name': 'grad ' + name, 'ref_max': float(r.abs().max()), 'cosine': cos, 'rel_l2': rel, 'max_abs_err': float((q - r).abs().max()),
-               'ok': cos >= 0.995 and rel <= 0.10}
+               'rel_l2_bound': lim, 'ok': cos >= BF16_COS and rel <= lim}
         rec['tensors'].append(row)
         if not row['ok']:
             fails.append(row)
-    _dump('bf16_frame1424x2128', rec)
+    if zero is not None:
+        return fails
+    _dump(tag, rec)
     assert psnr >= 60.0, psnr
     assert abs(loss - l64) <= 1e-3 * abs(l64), (loss, l64)
     assert not fails, fails
+    return rec
+
+
+def test_bf16_full_frame_step_vs_f64_oracle(lib):
+    """BASELINE configs[2] at frame size: the bf16 engine (conv_bfd / conv_bfs / conv_bfw kernels, wgrad8_kernel<bf16>, bf16 transposed convs, fused pools)
+    against the FLOAT64 oracle -- not against the fp32 engine.  bf16 activations carry 8 significant bits, so the bound is not 1e-5:
+    output PSNR >= 60 dB, loss within 1e-3 relative, and per gradient tensor cosine >= 0.9995 with relative L2
+    error <= 0.03 (0.06 on the 512-channel level) -- at most 3x what the kernels measure; the per-tensor figures go to the parity table."""
+    bf16_compare('bf16_frame1424x2128', lib, (1, 4, 1424, 2128))
+
+
+@pytest.mark.parametrize('tag,shape', [('bf16_crop512', (2, 4, 512, 512)), ('bf16_chop736x1088', (1, 4, 736, 1088))])
+def test_bf16_crop_and_chop_tile_step_vs_f64_oracle(lib, tag, shape):
+    """The bf16 engine against the float64 oracle at the other two pinned sizes of this file: the training crop (two images) and the forward_chop tile."""
+    bf16_compare(tag, lib, shape)
+
+
+def test_bf16_zeroed_gradient_fails_the_check(lib):
+    """Negative control of the bf16 bounds (as test_zeroed_deep_gradient_fails_the_check for fp32): conv3_2's weight gradient zeroed after the
+    backward must be reported, and only it."""
+    fails = bf16_compare('bf16_neg_zero_conv3', lib, (2, 4, 512, 512), zero='conv3_2.weight')
+    assert [f['name'] for f in fails] == ['grad conv3_2.weight'], fails
 
 
 def test_sampler_batch8_equals_single_image_launches(lib):

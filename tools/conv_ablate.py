@@ -11,7 +11,7 @@ LAYERS = [  # name, level, C0, C1, Cout, direction
     ('conv9_2 f 32->32 L0', 0, 32, 0, 32, 'f'), ('conv9_1 f 64->32 L0', 0, 32, 32, 32, 'f'), ('conv9_1 b 32->64 L0', 0, 32, 32, 32, 'b'),
     ('conv2_2 f 64->64 L1', 1, 64, 0, 64, 'f'), ('conv8_1 f 128->64 L1', 1, 64, 64, 64, 'f'), ('conv7_2 f 128->128 L2', 2, 128, 0, 128, 'f'),
 ]
-DBGS = [0, 64, 1, 2, 3, 4, 16, 8, 1 | 4, 2 | 16]
+DBGS = [int(v) for v in os.environ.get('ABLATE_DBGS', '0,64,1,2,3,4,16,8,5,18').split(',')]
 
 
 def child():
