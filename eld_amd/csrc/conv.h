@@ -253,7 +253,9 @@ __device__ __forceinline__ void f32_rows_swap(float4& a, float4& b) {
 }
 // 16-byte global store, optionally write-through (sc1: the line leaves the XCD's L2 instead of staying there -- MI355X_MICROARCH.md, stores of each flavour)
 __device__ __forceinline__ void st16(float* p, float4 v, bool wt = false) {
-    if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v q = {v.x, v.y, v.z, v.w};
+    if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(q) : "memory");      // (dev probe only: measured within noise, profiles/r06_ab_notes.md)
     else *reinterpret_cast<float4*>(p) = v;
 }
 __device__ __forceinline__ void f32_line_store(float4 (&v)[4], float* blk, size_t pstride, int lane, bool row_ok, int valid_px, bool wt = false) {
@@ -340,6 +342,11 @@ int x3_slab_bn(int Nout, int N, int H, int W, int* waves = nullptr);      // (N,
 __host__ __device__ inline size_t x3_slab_stride(int BN) { return (size_t)(3 * BN * 112 + 1023) / 1024 * 1024; }      // bytes of one (ky, chunk, channel-block) slab
 void conv_x3_set_prof(unsigned long long* buf);      // dev tool: 8 workgroups x 4 waves x 128 stages x 6 stamps
 int launch_conv_x3_gemm(const ConvArgs& a, int mode, hipStream_t st);
+// conv_x3w.hip (round 6): the 32-output-channel full-resolution layers on a workgroup of specialised waves (4 MFMA + 4 load / cut waves); weights in the
+// BN = 32 slab layout.  x3w_enabled(): the process-wide switch (ELD_X3W, default on) -- it decides the pack layout of every 32-output-channel layer.
+bool x3w_enabled();
+bool x3w_takes(const ConvArgs& a);
+int launch_conv_x3w(const ConvArgs& a, hipStream_t st);
 // bf16 3x3 layers with Nout % 64 == 0 and K % 32 == 0 run on conv_bfd_kernel (conv_bfd.hip: both operands by LDS-DMA) and take their weights in its
 // slab layout; returns the slab's channel-block width BN (64 / 128) or 0 for layers that stay on conv_igemm_kernel<bf16_t>
 int bfd_slab_bn(int Nout, int K, int N, int H, int W);

@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 // fragment offsets below stay compile-time for all three) over the VIRTUAL-ROW strip of the batch (conv.h vrow_*).  Pixels are the K dimension
 // of this GEMM, so every padding pixel of a ragged level is a wasted MFMA column: 8-wide tiles bring 89 x 133 from 1.30x (2 x 32 tiles) to 1.03x,
 // and their 3x3 halo is smaller too (10 x 10 against 4 x 34 pixels of X per 64 pixels of G).
-template <typename T, int WCO, int WCI, int WPIX, int TH, int TWT>      // T = float (three bf16 pieces per operand, six products) or bf16_t (the tiles as they are, one product)
+template <typename T, int WCO, int WCI, int WPIX, int TH, int TWT, bool STREAM = false>      // T = float (three bf16 pieces per operand, six products) or bf16_t (the tiles as they are, one product)
 __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradArgs a) {
     constexpr int ES = sizeof(T), EPU = 16 / ES, NPC = ES == 4 ? 3 : 1, XQ = 32 / EPU;      // element size, elements per 16-byte unit, pieces, units per 32-channel pixel
     static_assert(WCO * WCI * WPIX == 8, "8 waves");
@@ -582,6 +582,40 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradArgs a) {
         store_tile();
         __syncthreads();
         if (tile + a.psplit < ntiles) load_tile(tile + a.psplit);
+        if constexpr (NPC == 3 && STREAM) {
+            // Streamed fragment blocks (round 6, as conv_x3.hip x3_stage_blocks): block b = (k-step ks, tap t) is six piece products on acc[t]; the
+            // fragments the NEXT block needs (its tap's three X pieces; at a k-step's last tap also the next k-step's three G pieces) are read into the
+            // other half of two double buffers while the block's MFMAs run.  Per-accumulator product order as below: the same bits.
+            constexpr int GI[6] = {0, 1, 2, 0, 1, 0};
+            constexpr int XI[6] = {2, 1, 0, 1, 0, 0};
+            constexpr int NBLK = KSB * TAPS;
+            bf16x8 ga[2][3], xb[2][3];
+            auto readG = [&](int ks, bf16x8 (&g3)[3]) {
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) g3[pc] = tr8(gq + pc * GPL + ks * 16 * 32);
+            };
+            auto readX = [&](int ks, int t, bf16x8 (&x3)[3]) {
+                const int lrel = ks * 16, dy0 = lrel / TWT, dxp = lrel - dy0 * TWT;
+                const int xoff = (dy0 + t / 3) * (TWT + 2) + dxp + t % 3;
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) x3[pc] = tr8(xq + pc * XPL + xoff * 32);
+            };
+            readG(0, ga[0]);
+            readX(0, 0, xb[0]);
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) {
+                const int ks = b / TAPS, t = b % TAPS;
+                if (b + 1 < NBLK) {
+                    const int ks1 = (b + 1) / TAPS, t1 = (b + 1) % TAPS;
+                    readX(ks1, t1, xb[(b + 1) & 1]);
+                    if (ks1 != ks) readG(ks1, ga[ks1 & 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 6; ++q) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[ks & 1][GI[q]], xb[b & 1][XI[q]], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
 #pragma unroll
         for (int ks = 0; ks < KSB; ++ks) {
             const int lrel = ks * 16;
@@ -926,7 +960,7 @@ int wgrad8_ntiles(int CA, int CBp, int N, int H, int W, bool bf16) {
     return ((W + TWo - 1) / TWo) * ((vrow_extent(N, H, VP) + TH - 1) / TH);
 }
 
-template <typename T, int WCO, int WCI, int WPIX, int TH, int TWT>
+template <typename T, int WCO, int WCI, int WPIX, int TH, int TWT, bool STREAM = false>
 static int launch_w8(WgradArgs a, hipStream_t st) {
     constexpr int COB = 32 * WCO, JBK = 32 * WCI;
     a.vp = vrow_pitch(a.N, a.H, TH);
@@ -937,7 +971,7 @@ static int launch_w8(WgradArgs a, hipStream_t st) {
     if (lds_bytes < red_bytes) lds_bytes = red_bytes;
     const long long blocks = (long long)(a.CA / COB) * (a.CBp / JBK) * a.psplit;
     if (blocks <= 0) return 0;
-    auto kern = wgrad8_kernel<T, WCO, WCI, WPIX, TH, TWT>;
+    auto kern = wgrad8_kernel<T, WCO, WCI, WPIX, TH, TWT, STREAM>;
     static EldAttrOnce once;
     { const int rc = once.ensure(kern, lds_bytes); if (rc) return rc; }
     ELD_LAUNCH(kern, dim3((unsigned)blocks), dim3(512), lds_bytes, st, a);
@@ -985,7 +1019,17 @@ static int launch_wgrad8(const WgradArgs& a, hipStream_t st) {
         if (JBK == 64) return launch_w8<bf16_t, 1, 2, 4, 8, 32>(a, st);
         return launch_w8<bf16_t, 1, 1, 8, 8, 32>(a, st);
     }
-    if (COB == 128) return launch_w8<float, 4, 2, 1, 8, 8>(a, st);
+    // round 6, opt-in (ELD_WG8_STREAM: bit 1 = the 128 x 64 blocks, bit 2 = the others): streamed fragment blocks in the main loop, as conv_x3.hip's.  Measured
+    // same-box against the round-5 loop: 128 x 64 blocks 1997 -> 2005 us (+0.4 %), 64 x 64 2872 -> 2860 (-0.4 %), 32 x 32 2456 -> 2482 (+1.0 %): this loop's
+    // eighteen-read bursts per kernel row were already covered by the SIMD's other wave.  Default: the round-5 loop.
+    static const int stream = [] { const char* e = getenv("ELD_WG8_STREAM"); return e ? atoi(e) : 0; }();
+    if (COB == 128) return (stream & 1) ? launch_w8<float, 4, 2, 1, 8, 8, true>(a, st) : launch_w8<float, 4, 2, 1, 8, 8>(a, st);
+    if (stream & 2) {
+        if (COB == 64 && JBK == 64) return launch_w8<float, 2, 2, 2, 2, 32, true>(a, st);
+        if (COB == 64) return launch_w8<float, 2, 1, 4, 4, 32, true>(a, st);
+        if (JBK == 64) return launch_w8<float, 1, 2, 4, 4, 32, true>(a, st);
+        return launch_w8<float, 1, 1, 8, 4, 32, true>(a, st);
+    }
     if (COB == 64 && JBK == 64) return launch_w8<float, 2, 2, 2, 2, 32>(a, st);
     if (COB == 64) return launch_w8<float, 2, 1, 4, 4, 32>(a, st);
     if (JBK == 64) return launch_w8<float, 1, 2, 4, 4, 32>(a, st);
