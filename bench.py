@@ -66,6 +66,7 @@ def load_traffic():
             t.pop(key, None)
             if key == 'unet_conv_bytes_per_pass':
                 t.pop('sampler_bytes_per_pixel', None)
+                t.pop('sampler_valu_lane_ops_per_pixel', None)
     return t
 
 
@@ -555,6 +556,17 @@ def main():
                                    'in_step_note': 'the same kernel on the step\'s own %d frames, HIP events around the synthesis call inside a full step '
                                                    '(clock and caches as the preceding Adam / MFMA kernels leave them); in-step frac %.4f' % (
                                                        B, 8.0 * B * 4 * Hh * Ww / (sampler_in_step_ms * 1e-3) / 1e9 / PEAK_HBM_GBS)}
+        # The full model is bound by VALU issue, not bytes: the fraction of the roofline it actually sits on.  Issued lane-operations per pixel from
+        # the committed SQ_INSTS_VALU pass (profiles/traffic.json, same source-hash gate as the byte counts) x this run's pixel rate, against 1024 SIMDs x 32 lanes
+        # x 2.4 GHz; quarter-rate instructions (32 x 32 multiplies, transcendentals) count once here, so the SIMDs' busy fraction is higher still.
+        if traffic and 'sampler_valu_lane_ops_per_pixel' in traffic:
+            lops = float(traffic['sampler_valu_lane_ops_per_pixel'])
+            ach = lops * yb.numel() / (t_s * 1e-3) / 1e12
+            peak_v = 1024 * 32 * 2.4e9 / 1e12
+            res['roofline_sampler']['valu'] = {'bound': 'valu', 'lane_ops_per_pixel': round(lops, 1), 'achieved': round(ach, 2), 'peak': round(peak_v, 2),
+                                               'unit': 'T lane-ops/s', 'frac': round(ach / peak_v, 4),
+                                               'source': 'profiles/traffic.json: rocprofv3 --pmc SQ_INSTS_VALU of this command on a library with the same source hash; '
+                                                         'full-rate issue peak = 256 CUs x 4 SIMD-32 x 2.4 GHz'}
         # the other model strings of the reference (noise.py:158-166: 'Pg', 'pg', 'g'), same launch shape: achieved GB/s and fraction per model
         per_model = {}
         for ms_ in ('Pg', 'pg', 'g'):

@@ -5,12 +5,14 @@
 // Why (profiles/r06_ab_notes.md): in conv_x3_kernel<32, 4> every wave does everything in turn -- wait for its halo loads, cut them into bf16 pieces, store
 // them to LDS, barrier, 72 MFMAs, ... epilogue -- and a tile's memory side (78 KB in, 64-80 KB out) takes about as long as its matrix side (13.8 K pipe
 // cycles per wave); with two such workgroups per CU the two sides ran almost back to back (matrix pipe 50 % busy), because a workgroup can hold only ONE
-// 16-channel chunk of loads in flight (40 staging VGPRs at a full register file).  Here ONE 8-wave workgroup owns the CU:
-//   * waves 0-3 (one per SIMD) are CONSUMERS: fragment reads + MFMAs (x3_stage_blocks) and the tile's epilogue, nothing else;
-//   * waves 4-7 (their SIMD partners) are PRODUCERS: they run the chunk sequence of the workgroup's tiles AHEAD of the consumers -- halo loads of chunk g+3
+// 16-channel chunk of loads in flight (40 staging VGPRs at a full register file).  Here ONE 16-wave workgroup owns the CU (the shipped configuration; the template
+// also builds 4 + 4 and 8 + 4 waves, profiles/r06_ab_notes.md):
+//   * waves 0-7 (two per SIMD, two pixel rows each) are CONSUMERS: fragment reads + MFMAs (x3_stage_blocks) and the tile's epilogue, nothing else;
+//   * waves 8-15 (two more per SIMD; 122 VGPRs per wave) are PRODUCERS: they run the chunk sequence of the workgroup's tiles AHEAD of the consumers -- halo loads of chunk g+3
 //     into one of two register sets (two chunks in flight per CU instead of one: the producers have the registers the consumers' accumulators do not
 //     leave the others) and the exact three-piece cut of chunk g+1 into the OTHER half of a double-buffered LDS tile while the consumers multiply chunk g.
-//     Three of them stage the halo; the fourth moves the next stage's pre-split weight slab (conv_x3d_kernel's slab layout, pack kernel) by LDS-DMA.
+//     Seven of them stage the halo; the eighth moves the next stage's pre-split weight slab (conv_x3d_kernel's slab layout, pack kernel) by LDS-DMA and has
+//     nothing else in flight (vmcnt retires in order: whoever waits for slab pieces also waits for every older load or store of its own).
 // VALU / LDS-write / VMEM work of a SIMD's producer wave and the MFMA stream of its consumer wave are different pipes: they overlap by construction instead of
 // by the luck of two workgroups' phases.  One workgroup barrier per stage (kernel row) hands the finished halves over.
 //
@@ -33,7 +35,7 @@ struct WProf {
     }
 };
 
-constexpr int W_BN = 32, W_PW = 4, W_TH = 16, W_CK = 16;          // (consumer waves x rows per consumer wave = W_TH: 4 x 4 or 8 x 2, template parameters)
+constexpr int W_BN = 32, W_TH = 16, W_CK = 16;          // (consumer waves x rows per consumer wave = W_TH: 4 x 4 or 8 x 2, template parameters)
 constexpr int W_APIX = (W_TH + 2) * (TW + 2);                       // 612 halo pixels
 constexpr int W_AWORDS = W_APIX * PX;                               // 17,136 words = 68,544 B
 constexpr int W_BROWS = 3 * W_BN;
@@ -43,13 +45,13 @@ constexpr int W_AUNITS = W_APIX * 4;
 
 // SLABW: the last producer wave moves the weight slabs and the other three stage the halo (13 units per thread and chunk: 216 VGPRs, so only with two waves per
 // SIMD = 4 consumer waves); else all four producer waves stage the halo (10 units) AND move the slabs, with a counted wait for their pieces.
-template <int W_CW, int W_RPW, bool SLABW, bool PRIO>
+template <int W_CW, int W_RPW, bool SLABW, bool PRIO, int W_PW = 4>
 __global__ __launch_bounds__(64 * (W_CW + W_PW), (W_CW + W_PW) / 4) void conv_x3w_kernel(const ConvArgs a) {
     static_assert(W_CW * W_RPW == W_TH, "tile rows");
     constexpr int W_HW = SLABW ? W_PW - 1 : W_PW;                     // producer waves that stage the halo
     constexpr int W_PTHREADS = 64 * W_HW;
     constexpr int W_AIT = (W_AUNITS + W_PTHREADS - 1) / W_PTHREADS;   // sixteen-byte units per halo thread and chunk: 13 / 10
-    constexpr int W_T0 = SLABW ? 5 : 4, W_T1 = SLABW ? 9 : 7;         // a chunk's units are cut in three parts, one per stage
+    constexpr int W_T0 = (W_AIT + 2) / 3, W_T1 = W_T0 + (W_AIT - W_T0 + 1) / 2;      // a chunk's units are cut in three parts, one per stage: 13 -> 5 4 4, 10 -> 4 3 3, 5 -> 2 2 1
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* ldsB = lds;                                                // [2][W_BWORDS]: the DMA destinations stay at low LDS addresses
     float* ldsA = lds + 2 * W_BWORDS;                                 // [2][W_AWORDS]
@@ -348,9 +350,9 @@ __global__ __launch_bounds__(64 * (W_CW + W_PW), (W_CW + W_PW) / 4) void conv_x3
 // 32-channel tensors), a single 32-channel output tensor, on a tile domain that gives every CU a tile; weights in conv_x3d_kernel's slab layout at BN = 32.
 // ELD_X3W=0 keeps these layers on conv_x3_kernel<32, 4>.
 // ELD_X3W: 0 = off (conv_x3_kernel<32, 4>), 1 = 4 consumer waves x 4 rows + 3 halo waves + 1 slab wave, 2 = 8 consumer waves x 2 rows + 4 producer waves (two MFMA
-// waves per SIMD cover each other's fragment-read latency), 3 = as 2 with the producers at s_setprio 3
+// waves per SIMD cover each other's fragment-read latency), 3 = as 2 with the producers at s_setprio 3, 4 = 8 consumer + 8 producer waves (four waves per SIMD), 5 = as 4 with one of the producer waves moving the slabs and nothing else (the default)
 static int x3w_mode() {
-    static const int on = [] { const char* e = getenv("ELD_X3W"); return e ? atoi(e) : 2; }();
+    static const int on = [] { const char* e = getenv("ELD_X3W"); return e ? atoi(e) : 5; }();
     return on;
 }
 bool x3w_enabled() { return x3w_mode() != 0; }
@@ -379,7 +381,15 @@ int launch_conv_x3w(const ConvArgs& a_in, hipStream_t st) {
     long long grid = (long long)eld_num_cus();
     if (grid > tiles) grid = tiles;
     const int mode = x3w_mode();
-    if (mode == 1) {
+    if (mode == 5) {
+        static EldAttrOnce once;
+        { const int rc = once.ensure(conv_x3w_kernel<8, 2, true, false, 8>, lds_bytes); if (rc) return rc; }
+        ELD_LAUNCH((conv_x3w_kernel<8, 2, true, false, 8>), dim3((unsigned)grid), dim3(1024), lds_bytes, st, a);
+    } else if (mode == 4) {
+        static EldAttrOnce once;
+        { const int rc = once.ensure(conv_x3w_kernel<8, 2, false, false, 8>, lds_bytes); if (rc) return rc; }
+        ELD_LAUNCH((conv_x3w_kernel<8, 2, false, false, 8>), dim3((unsigned)grid), dim3(1024), lds_bytes, st, a);
+    } else if (mode == 1) {
         static EldAttrOnce once;
         { const int rc = once.ensure(conv_x3w_kernel<4, 4, true, false>, lds_bytes); if (rc) return rc; }
         ELD_LAUNCH((conv_x3w_kernel<4, 4, true, false>), dim3((unsigned)grid), dim3(512), lds_bytes, st, a);

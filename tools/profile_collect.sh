@@ -17,7 +17,7 @@ for v in fp32 bf16; do
   ( echo "# $R SQ counters per kernel ($v): rocprofv3 --pmc (one pass, 8 SQ counters) of bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt --precision $v (counter mode serialises dispatches: ms are PMC-mode durations)"; echo
     python tools/pmc_summary.py $G/pmc/sq_${v}_counter_collection.csv 24 ) > $P/${R}_pmc_$v.md
 done
-python tools/traffic_from_pmc.py $G/pmc/fetch_fp32_counter_collection.csv $G/pmc/write_fp32_counter_collection.csv $P/traffic.json 8 > /dev/null
+python tools/traffic_from_pmc.py $G/pmc/fetch_fp32_counter_collection.csv $G/pmc/write_fp32_counter_collection.csv $P/traffic.json 8 --sq $G/pmc/sq_fp32_counter_collection.csv > /dev/null
 python tools/traffic_from_pmc.py $G/pmc/fetch_bf16_counter_collection.csv $G/pmc/write_bf16_counter_collection.csv $P/traffic.json 8 bf16 > /dev/null
 ( echo "# $R sampler SQ counters per model string: rocprofv3 --pmc, two passes, of tools/noise_microbench.py 8 (8 x 4x1424x2128 per launch; 23 launches per row; template flags: 57 = PGRU (two parameter sets: K = 2.29 and K = 0.1), 5 = Pg, 6 = pg, 4 = g, 0 = scale only)"; echo
   python tools/pmc_summary.py $G/pmc/noise_sq_counter_collection.csv 6; echo; python tools/pmc_summary.py $G/pmc/noise_sq2_counter_collection.csv 6 ) > $P/${R}_sampler_pmc_raw.md

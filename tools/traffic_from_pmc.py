@@ -79,6 +79,15 @@ def main():
         print(json.dumps({k: v for k, v in base.items() if not k.startswith('kernels')}, indent=1))
         return
     out['library_src_hash'] = src_hash_of(sys.argv[1])
+    # optional: --sq <counter_collection.csv of the SQ pass of the same command>: the sampler's issued VALU instructions (its real limiter)
+    if '--sq' in sys.argv:
+        sq = sys.argv[sys.argv.index('--sq') + 1]
+        v, vc, vg = load(sq, 'SQ_INSTS_VALU')
+        nz = [k for k in v if k.startswith('void noise_kernel')]
+        if nz:
+            px = sum(vg[k] / 256.0 * 4096.0 for k in nz)         # as above: 4096 pixels per 256-thread workgroup
+            out['sampler_valu_lane_ops_per_pixel'] = 64.0 * sum(v[k] for k in nz) / px
+            out['sampler_valu_source'] = 'rocprofv3 --pmc SQ_INSTS_VALU (wave instructions x 64 lanes / pixels) of the noise_kernel launches of the same bench.py command'
     json.dump(out, open(sys.argv[3], 'w'), indent=1)
     print(json.dumps({k: v for k, v in out.items() if k != 'kernels'}, indent=1))
 
