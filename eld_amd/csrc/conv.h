@@ -46,6 +46,10 @@ struct ConvArgs {
     // The bf16 network (conv_bfs.hip, conv_first.hip) keeps the same word addressing for its two 32-channel tensors but another bit order inside a word
     // (slope_codes_bf16 below).
     unsigned* codes_out;
+    // Pool codes (round 6): with pool_out, also the ARGMAX of every 2x2 window -- what the pool's backward needs of the un-pooled tensor besides its slope codes.
+    // Word ((pooled pixel * (Nout / 32) + block) * 2 + hi): bit i (i = 4q + j <-> channel 8q + 4hi + j of the block) = the winner lies in the window's BOTTOM row,
+    // bit 16 + i = in its RIGHT column; the winner is the first maximum in row-major window order (torch's max_pool2d backward; conv_x3_dev.h pool_epilogue).
+    unsigned* pool_codes_out;
     const unsigned* codes0;
     const unsigned* codes1;
     int Cout_t;         // EPI_CONVT_FWD: real Cout (Nout = 4*Cout_t, n = tap*Cout_t + co)

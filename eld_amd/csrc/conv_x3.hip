@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
             int img_p[RPW / 2], y_p[RPW / 2];
 #pragma unroll
             for (int rp = 0; rp < RPW / 2; ++rp) { img_p[rp] = img; y_p[rp] = y0 + wave * RPW + 2 * rp; }
-            pool_epilogue<RPW, NT, BN>(a, acc, img_p, nb, y_p, x0 + m, hi);
+            pool_epilogue<RPW, NT, BN, false>(a, acc, img_p, nb, y_p, x0 + m, hi);      // (no pool codes from this kernel: unet.hip asks for them only where conv_x3w_kernel runs)
         }
         if (t_next >= total_tiles) break;
         t = t_next;
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
 // knows about (s_waitcnt vmcnt(0) in front of the stage's first fragment read, which would serialise the prefetch and drain the halo
 // loads with it).  The kernel waits for its own pieces explicitly (dma_wait) before the barrier that publishes the slab.
 // s_nop 4: SALU-written soffset / descriptor -> VMEM read wait states; s_nop 0: M0 write -> LDS-DMA; M0 is saved and restored.
-template <int BN, int RPW, int WAVES, bool DB, bool STREAM = false>
+template <int BN, int RPW, int WAVES, bool DB, int STREAM = 0>       // STREAM: 0 = the round-5 loops, 1 = streamed blocks, 2 = streamed blocks in the weight-reuse order (conv_x3_dev.h)
 __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES == 8 ? 2 : 1)) void conv_x3d_kernel(const ConvArgs a) {
     constexpr int CK = 16, THREADS = 64 * WAVES;
     constexpr int TH = WAVES * RPW, NT = BN / 32, A_PIX = (TH + 2) * (TW + 2);
@@ -493,6 +493,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
     setup_load(t / KS);
     load_A(chunk_begin(t) * CK);
     int buf = 0;
+    bool after_epi = false;
     {
         int nb0, i0, v00, x00;
         decode(t / KS, nb0, i0, v00, x00);
@@ -516,6 +517,8 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
 #pragma unroll 1
             for (int ky = 0; ky < 3; ++ky) {
                 __builtin_amdgcn_s_setprio(3);   // the short staging section goes ahead of co-resident waves' MFMA streams
+                if ((ELD_DBG(a) & 2048) && after_epi) after_epi = false;      // (dev probe 2048: no drain of the epilogue's stores -- timing only, the slab is not waited for)
+                else
                 dma_wait();                      // this wave's pieces of the stage's slab (issued one stage ago) have landed (round 5: a counted wait that
                                                  // leaves the halo loads of the chunk's first stage in flight here measured 0.0 %: profiles/r05_ab_notes.md)
                 __syncthreads();                 // ... and so have everybody else's; the previous stage's fragment reads are done
@@ -534,7 +537,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
                 if (ELD_DBG(a) & 2) { buf ^= 1; continue; }      // (dev ablation: no fragment reads, no MFMAs)
                 const float* lb = ldsB + buf * B_WORDS;
                 if constexpr (STREAM) {
-                    x3_stage_blocks<RPW, NT>(acc,
+                    x3_stage_blocks<RPW, NT, STREAM == 2>(acc,
                         [&](int kx, int r, uint4 (&X)[3]) {
                             const float* p = ldsA + pb[r] + (ky * HWL + kx) * PX;
 #pragma unroll
@@ -718,10 +721,11 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
                 const bool rok = strip_row(vrel + wave * RPW + 2 * rp, dimg, y) && img0 + dimg < a.N;
                 img_p[rp] = img0 + dimg; y_p[rp] = rok ? y : a.H;
             }
-            pool_epilogue<RPW, NT, BN>(a, acc, img_p, nb, y_p, x0 + m, hi);
+            pool_epilogue<RPW, NT, BN, (WAVES == 8 && NT <= 2)>(a, acc, img_p, nb, y_p, x0 + m, hi);
         }
         if (t_next >= total_tiles) break;
         t = t_next;
+        after_epi = true;
     }
 }
 
@@ -996,7 +1000,7 @@ int launch_x3(ConvArgs a, hipStream_t st) {
     return 0;
 }
 
-template <int BN, int RPW, int WAVES, bool DB, bool STREAM = false>
+template <int BN, int RPW, int WAVES, bool DB, int STREAM = 0>
 int launch_x3d(ConvArgs a, hipStream_t st) {
     constexpr int TH = WAVES * RPW;
     conv_tile_shape(a.N, a.H, a.W, TH, a.pool_out != nullptr, a.tile_h, a.tile_w);
@@ -1116,10 +1120,17 @@ int launch_conv_x3(const ConvArgs& a_in, hipStream_t st) {
     if (bn == 32 && x3w_takes(a)) return launch_conv_x3w(a, st);      // specialised waves (conv_x3w.hip)
     if (bn == 32 && x3d_32_kernel(a.N, a.H, a.W)) return launch_x3d<32, 4, 8, false>(a, st);
     if (bn == 32) return (stream & 1) ? launch_x3<32, 4, false, true, true, true>(a, st) : launch_x3<32, 4, false, true, true>(a, st);      // pre-split slabs through registers (round 6)
-    if (bn == 128) return (stream & 4) ? launch_x3d<128, 2, 8, false, true>(a, st) : launch_x3d<128, 2, 8, false>(a, st);      // weights pre-split in slab layout: LDS-DMA kernel
+    // ELD_X3_WREUSE (bit mask: 2 = conv_x3d_kernel<64>, 4 = conv_x3d_kernel<128>; default both): the streamed blocks in the weight-reuse order (conv_x3_dev.h
+    // x3_stage_blocks) -- a third fewer LDS fragment reads; same box, interleaved: 2168 -> 2126 us (-1.9 %) / 2580 -> 2538 us (-1.6 %) per launch, step -0.9 %
+    static const int wreuse = [] { const char* e = getenv("ELD_X3_WREUSE"); return e ? atoi(e) : 6; }();
+    if (bn == 128) {                                                  // weights pre-split in slab layout: LDS-DMA kernel
+        if ((stream & 4) && (wreuse & 4)) return launch_x3d<128, 2, 8, false, 2>(a, st);
+        return (stream & 4) ? launch_x3d<128, 2, 8, false, 1>(a, st) : launch_x3d<128, 2, 8, false>(a, st);
+    }
     if (bn == 64) {
         if (waves != 8) return launch_x3d<64, 2, 4, false>(a, st);
-        return (stream & 2) ? launch_x3d<64, 2, 8, false, true>(a, st) : launch_x3d<64, 2, 8, false>(a, st);
+        if ((stream & 2) && (wreuse & 2)) return launch_x3d<64, 2, 8, false, 2>(a, st);
+        return (stream & 2) ? launch_x3d<64, 2, 8, false, 1>(a, st) : launch_x3d<64, 2, 8, false>(a, st);
     }
     // round 5: the next stage's slab loads are issued AHEAD of the halo loads (template BFIRST; -2.7 % per launch, same box); ELD_X3_BFIRST=0 restores the
     // round-4 order for A/B runs

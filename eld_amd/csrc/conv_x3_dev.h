@@ -43,7 +43,7 @@ __device__ __forceinline__ int stage_row(int r, int limit) {
 // (the epilogue adds bias and applies LeakyReLU in place before it stores), so this pools exactly what was stored; the even lanes write
 // [N, H/2, W/2, Nout].  H and W are even (checked by the launcher), so a window is never split by the image border.  Every lane of the wave runs
 // the exchange; only the stores are predicated.
-template <int RPW, int NT, int BN>
+template <int RPW, int NT, int BN, bool PCODES = (NT <= 2)>
 __device__ __forceinline__ void pool_epilogue(const ConvArgs& a, const f32x16 (&acc)[RPW][NT], const int (&img_p)[RPW / 2], int nb,
                                               const int (&y_p)[RPW / 2] /* first row of each of the lane's row pairs; >= H: none */, int x, int hi) {
     static_assert(RPW % 2 == 0, "row pairs per lane");
@@ -68,6 +68,27 @@ __device__ __forceinline__ void pool_epilogue(const ConvArgs& a, const f32x16 (&
 #pragma unroll
                 for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(dst + 8 * q) = pv[q];
             }
+            if constexpr (PCODES) if (a.pool_codes_out != nullptr) {      // (wave-uniform) argmax of every window, ConvArgs::pool_codes_out; the 32- / 64-channel tiles of full-size problems only, like the slope codes
+                // this lane's column of the window: S = the bottom value is STRICTLY greater (bit per element); against the partner lane's column maximum:
+                // G = the partner's is strictly greater, Q = equal
+                unsigned S = 0, G = 0, Q = 0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float top = acc[2 * rp][tt][i], bot = acc[2 * rp + 1][tt][i];
+                    const float me = fmax_raw(top, bot);
+                    const float pm = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(me), 0xB1, 0xF, 0xF, true));      // lane ^ 1
+                    S |= bot > top ? (1u << i) : 0u;
+                    G |= pm > me ? (1u << i) : 0u;
+                    Q |= pm == me ? (1u << i) : 0u;
+                }
+                const unsigned Sp = (unsigned)__builtin_amdgcn_update_dpp(0, (int)S, 0xB1, 0xF, 0xF, true);
+                // (even lanes = left column.)  The right column wins when its maximum is greater, or equal with the left winner in the bottom row and the right
+                // one in the top row (row-major order: top-left, top-right, bottom-left, bottom-right; the first maximum takes the gradient)
+                const unsigned Hb = G | (Q & S & ~Sp);
+                const unsigned Vb = (S & ~Hb) | (Sp & Hb);
+                if (x < a.W && !(x & 1))
+                    a.pool_codes_out[((((size_t)(img * Hp + (y >> 1)) * Wp + (x >> 1)) * (size_t)(a.Nout >> 5)) + (size_t)((nb * BN + tt * 32) >> 5)) * 2 + hi] = Vb | (Hb << 16);
+            }
         }
     }
 }
@@ -88,11 +109,37 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 // small double buffers while the predecessor's six MFMAs run, and __builtin_amdgcn_sched_barrier pins that order: 2 x (12 + 12) fragment registers
 // instead of 60 ... 72, no LDS latency in front of any MFMA but a stage's first.
 //   readX(kx, r, X[3]) / readW(kx, tt, W[3]): the three piece fragments of pixel row r / channel block tt at tap kx.
-template <int RPW, int NT, typename RX, typename RW>
+// WREUSE (NT > 1 only): the blocks of a tap run (channel block tt, pixel row r) with r fastest, every pixel row's fragments resident (one buffer per row)
+// and the weight fragments of a channel block used for all RPW rows before the next block's replace them: a stage then reads every pixel fragment once
+// per tap (as before) and every weight fragment once per tap instead of RPW times -- 3 (RPW + NT) fragment triples instead of 3 RPW (1 + NT): -33 % of a
+// 64-channel tile's LDS reads, -40 % of a 128-channel tile's, in the same 2 x (12 + 12) fragment registers at RPW = 2.  An accumulator still receives its
+// taps in the order 0, 1, 2 and its six products smallest first: the same bits.
+template <int RPW, int NT, bool WREUSE = false, typename RX, typename RW>
 __device__ __forceinline__ void x3_stage_blocks(f32x16 (&acc)[RPW][NT], RX&& readX, RW&& readW) {
     constexpr int NBLK = 3 * RPW * NT;
     constexpr int WI[6] = {0, 1, 2, 0, 1, 0};
     constexpr int XI[6] = {2, 1, 0, 1, 0, 0};
+    if constexpr (WREUSE && NT > 1) {
+        uint4 X[RPW][3], Wf[2][3];
+        readX(0, 0, X[0]);
+        readW(0, 0, Wf[0]);
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+            const int tt = (b / RPW) % NT, r = b % RPW;
+            const int wi = (b / RPW) & 1;
+            if (b + 1 < NBLK) {
+                const int kx1 = (b + 1) / (RPW * NT), tt1 = ((b + 1) / RPW) % NT, r1 = (b + 1) % RPW;
+                if (tt1 == 0) readX(kx1, r1, X[r1]);                   // (row r1's buffer: its last reader, block (kx1 - 1, NT - 1, r1), has been issued)
+                if (r1 == 0) readW(kx1, tt1, Wf[wi ^ 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                acc[r][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Wf[wi][WI[q]]), __builtin_bit_cast(bf16x8, X[r][XI[q]]), acc[r][tt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
     uint4 X[2][3], Wf[2][3];
     readX(0, 0, X[0]);
     readW(0, 0, Wf[0]);

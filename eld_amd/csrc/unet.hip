@@ -107,10 +107,11 @@ inline void take_amax(ConvArgs& a) { a.algo = g_algo; a.amax_in0 = g_am.in0; a.a
 inline void take_amax(WgradArgs& a) { a.algo = g_algo; a.amax_g = g_am.in0; a.amax_x0 = g_am.w; a.amax_x1 = g_am.in1; g_am = Amax(); }      // wgrad: in0 = G, w = X0, in1 = X1
 enum { S_W = 0, S_X = 23, S_EA = 24, S_EB = 29, S_UP = 34, S_DA = 38, S_DB = 42, S_GA = 46, S_GB = 47, S_SKIP = 48, S_COUNT = 64 };
 int conv_fwd(const float* in0, int C0, const float* in1, int C1, const float* wp, const float* bias, float* out, int N, int H, int W,
-             int Cout, int lrelu, hipStream_t st, float* pool_out = nullptr, unsigned* codes_out = nullptr) {
+             int Cout, int lrelu, hipStream_t st, float* pool_out = nullptr, unsigned* codes_out = nullptr, unsigned* pool_codes_out = nullptr) {
     ConvArgs a = {};
     a.pool_out = pool_out;
     a.codes_out = codes_out;
+    a.pool_codes_out = pool_codes_out;
     a.in0 = in0; a.in1 = in1; a.C0 = C0; a.C1 = C1; a.wp = wp; a.N = N; a.H = H; a.W = W; a.Nout = Cout;
     a.epi = EPI_FWD; a.bias = bias; a.lrelu = lrelu; a.out0 = out;
     a.kpart = g_kp.p; a.kpart_floats = g_kp.floats;
@@ -197,6 +198,8 @@ struct Plan {
     // (2 bits per element); written by the fp32 three-piece forward where `codes` is set (see make_plan) and, for ea[0] / da[0], by the bf16 forward
     // (unet_forward_bf16); read by the backward for the regions the last forward reports (FusedFwd::codes)
     size_t cd_ea[2], cd_da[2];
+    // round 6: slope codes of eb[0], eb[1] and argmax codes of pool[0], pool[1] (ConvArgs::pool_codes_out): what maxpool_bwd_codes_kernel reads instead of eb
+    size_t cd_eb[2], pc[2];
     bool codes;
     size_t total;     // floats
 };
@@ -277,6 +280,8 @@ int make_plan(Plan& P, int N, int H, int W, int in_ch, int out_ch) {
     for (int l = 0; l < 2; ++l) {
         P.cd_ea[l] = take(act(l, chan(l)) / 16 + 64);
         P.cd_da[l] = take(act(l, chan(l)) / 16 + 64);
+        P.cd_eb[l] = take(act(l, chan(l)) / 16 + 64);
+        P.pc[l] = take(act(l + 1, chan(l)) / 16 + 64);
     }
     P.amax = take(S_COUNT);
     P.total = off;
@@ -355,7 +360,7 @@ struct HeadLoss { const float* target; float* loss; int mse; float grad_scale; }
 struct FusedFwd { bool packed = false; const float* x = nullptr; unsigned codes = 0; };
 // FusedFwd::codes / the forwards' have_out: which slope-code regions the LAST forward on this workspace filled (it decides per launch: kernel choice,
 // fp32 scheme, debug mask) -- the backward reads a region only when its bit is set, whatever its own switches say
-enum { CODES_EA0 = 1, CODES_EA1 = 2, CODES_DA0 = 4, CODES_DA1 = 8, CODES_INFER = 256 };      // CODES_INFER: the forward was eld_unet_infer_ex -- nothing for a backward
+enum { CODES_EA0 = 1, CODES_EA1 = 2, CODES_DA0 = 4, CODES_DA1 = 8, CODES_EB0 = 16, CODES_EB1 = 32, CODES_INFER = 256 };      // CODES_EBl: slope codes of eb[l] AND argmax codes of pool[l]      // CODES_INFER: the forward was eld_unet_infer_ex -- nothing for a backward
 
 int unet_forward(const Plan& P, const float* x, const float* prm, float* out, float* ws, hipStream_t st, const HeadLoss* hl = nullptr, unsigned* have_out = nullptr,
                  bool infer = false) {
@@ -372,7 +377,8 @@ int unet_forward(const Plan& P, const float* x, const float* prm, float* out, fl
     const bool first_direct = P.in_ch <= 4;        // conv1_1 straight from the NCHW planes (conv_first.hip)
     const bool use_codes = !infer && P.codes && g_algo == 1 && !(debug_kernel_mask(-1) & 128);   // slope codes for the backward-data epilogues of levels 0 / 1 (Plan::codes)
     auto CD = [&](size_t off) -> unsigned* { return use_codes ? reinterpret_cast<unsigned*>(ws + off) : nullptr; };
-    if (have_out) *have_out = !use_codes ? 0u : ((!first_direct || conv_first_writes_codes(P.in_ch)) ? CODES_EA0 : 0u) | CODES_EA1 | CODES_DA0 | CODES_DA1;
+    const bool use_pcodes = use_codes && !(debug_kernel_mask(-1) & 256);      // argmax codes of the two full-size pools (bit 8 of the mask: A/B and bit-identity switch)
+    if (have_out) *have_out = !use_codes ? 0u : ((!first_direct || conv_first_writes_codes(P.in_ch)) ? CODES_EA0 : 0u) | CODES_EA1 | CODES_DA0 | CODES_DA1 | (use_pcodes ? (x3w_enabled() ? CODES_EB0 : 0u) | CODES_EB1 : 0u);
     if (first_direct && (hl || infer)) {
         // fused training forward: the backward reads the caller's x (include/eld_amd.h: it must stay valid and unchanged until that call);
         // inference (eld_unet_infer_ex): no backward follows
@@ -399,8 +405,9 @@ int unet_forward(const Plan& P, const float* x, const float* prm, float* out, fl
         AM(S_EA + l, -1, S_W + 2 * l + 1, S_EB + l);
         // three-piece scheme: the conv's epilogue also writes the pooled tensor (no second pass over eb[l])
         const bool fuse_pool = g_algo == 1 && l < NLEV - 1;
+        const bool pcodes = fuse_pool && l < 2 && use_pcodes && (l == 1 || x3w_enabled());      // level 0: conv_x3w_kernel writes them, conv_x3_kernel<32, 4> does not       // levels 0 / 1: the pool's backward then reads codes instead of eb[l]
         RC(conv_fwd(ws + P.ea[l], chan(l), nullptr, 0, ws + P.wp_fwd[2 * l + 1], prm + B.b_off, ws + P.eb[l], N, P.Hl[l], P.Wl[l], chan(l), 1, st,
-                    fuse_pool ? ws + P.pool[l] : nullptr));
+                    fuse_pool ? ws + P.pool[l] : nullptr, pcodes ? CD(P.cd_eb[l]) : nullptr, pcodes ? CD(P.pc[l]) : nullptr));
         if (l < NLEV - 1 && !fuse_pool) RC(launch_maxpool_fwd(ws + P.eb[l], ws + P.pool[l], N, P.Hl[l + 1], P.Wl[l + 1], chan(l), st));
     }
     for (int l = 3; l >= 0; --l) {
@@ -560,7 +567,10 @@ int unet_backward(const Plan& P, const float* dout, const float* prm, float* grd
         RC(fresh(gs(oth))); BD(gs(cur), S_W + ia, gs(oth), -1);
         RC(conv_bwd_data(cur, ws + P.wp_bwd[ia], oth, nullptr, Cp, nullptr, nullptr, N, H, W, Cp, C, st));      // d_pool (raw)
         { float* t = cur; cur = oth; oth = t; }
-        RC(launch_maxpool_bwd(ws + P.eb[l - 1], cur, ws + P.skip[l - 1], oth, N, H, W, Cp, st));
+        if (l - 1 < 2 && CD(P.cd_eb[l - 1], l - 1 ? CODES_EB1 : CODES_EB0) != nullptr)
+            RC(launch_maxpool_bwd_codes(CD(P.pc[l - 1], l - 1 ? CODES_EB1 : CODES_EB0), CD(P.cd_eb[l - 1], l - 1 ? CODES_EB1 : CODES_EB0), cur, ws + P.skip[l - 1], oth, N, H, W, Cp, st));
+        else
+            RC(launch_maxpool_bwd(ws + P.eb[l - 1], cur, ws + P.skip[l - 1], oth, N, H, W, Cp, st));
         if (h2) { RC(fresh(gs(oth))); RC(launch_absmax(oth, (size_t)N * 4 * H * W * Cp, am + gs(oth), st)); }
         { float* t = cur; cur = oth; oth = t; }
     }

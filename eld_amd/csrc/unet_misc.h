@@ -7,6 +7,8 @@ enum PackKind { PACK_CONV_FWD = 0, PACK_CONV_BWD = 1, PACK_CONVT_FWD = 2, PACK_C
 int launch_nchw_to_nhwc16(const float* x, float* y, int N, int C, int H, int W, hipStream_t st);
 int launch_maxpool_fwd(const float* in, float* out, int N, int Ho, int Wo, int C, hipStream_t st);
 int launch_maxpool_bwd(const float* act, const float* dp, const float* skip, float* g, int N, int Ho, int Wo, int C, hipStream_t st);
+int launch_maxpool_bwd_codes(const unsigned* pool_codes, const unsigned* slope_codes, const float* dp, const float* skip, float* g, int N, int Ho, int Wo, int C,
+                             hipStream_t st);
 int launch_head_fwd(const float* in, const float* w, const float* b, float* out, int N, int H, int W, int OC, hipStream_t st);
 size_t head_bwd_ws_floats();
 int launch_head_bwd(const float* dout, const float* act, const float* w, float* g, float* dw, float* db, float* part,

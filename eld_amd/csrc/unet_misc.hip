@@ -104,6 +104,56 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ act, const float* _
     }
 }
 
+// The same from CODES instead of the saved un-pooled tensor (round 6): the pool's backward needs two facts about it, which window element took the maximum and
+// each element's LeakyReLU slope class -- 2 bits per pooled element (ConvArgs::pool_codes_out) and 2 bits per element (ConvArgs::codes_out), written by the
+// forward epilogue that produced the tensor -- 0.31 bytes per element instead of 4: this kernel moves 9.3 B per element instead of 13 and is HBM-bound.
+// C % 32 == 0.  Same selections and slopes as maxpool_bwd_kernel, so the same bits.
+__global__ void maxpool_bwd_codes_kernel(const unsigned* __restrict__ pool_codes, const unsigned* __restrict__ slope_codes, const float* __restrict__ dp,
+                                         const float* __restrict__ skip, float* __restrict__ g, int N, int Ho, int Wo, int C) {
+    const int C4 = C / 4, CB = C >> 5;
+    const size_t total = (size_t)N * Ho * Wo * C4;
+    const int Wi = 2 * Wo;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const size_t pp = i / C4;                                      // pooled pixel (n, yo, xo)
+        size_t p = pp;
+        const int xo = (int)(p % Wo); p /= Wo;
+        const int yo = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        const int cb = 4 * c4, blk = cb >> 5, e0 = cb & 31;
+        const int q = e0 >> 3, hi = (e0 >> 2) & 1;                     // channels 8q + 4hi + j, j = 0..3 <-> code elements 4q + j
+        const unsigned pw = pool_codes[(pp * CB + blk) * 2 + hi] >> (4 * q);
+        const size_t pix0 = ((size_t)n * 2 * Ho + 2 * yo) * Wi + 2 * xo;
+        const size_t pixs[4] = {pix0, pix0 + 1, pix0 + Wi, pix0 + Wi + 1};
+        const float4 gp = reinterpret_cast<const float4*>(dp)[i];
+        const float gpv[4] = {gp.x, gp.y, gp.z, gp.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned sw = slope_codes[(pixs[k] * CB + blk) * 2 + hi] >> (8 * q);
+            float4 sk = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (skip) sk = reinterpret_cast<const float4*>(skip)[(pixs[k] * C) / 4 + c4];
+            const float skv[4] = {sk.x, sk.y, sk.z, sk.w};
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int sel = 2 * (int)((pw >> j) & 1u) + (int)((pw >> (16 + j)) & 1u);
+                o[j] = ((sel == k ? gpv[j] : 0.f) + skv[j]) * slope_of_code(sw, j);
+            }
+            reinterpret_cast<float4*>(g)[(pixs[k] * C) / 4 + c4] = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+int launch_maxpool_bwd_codes(const unsigned* pool_codes, const unsigned* slope_codes, const float* dp, const float* skip, float* g, int N, int Ho, int Wo, int C,
+                             hipStream_t st) {
+    if (C % 32) return ELD_EINVAL;
+    const size_t total = (size_t)N * Ho * Wo * (C / 4);
+    if (!total) return 0;
+    ELD_LAUNCH(maxpool_bwd_codes_kernel, dim3((unsigned)min((total + 255) / 256, (size_t)32768)), dim3(256), 0, st, pool_codes, slope_codes, dp, skip, g, N, Ho, Wo, C);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_maxpool_bwd(const float* act, const float* dp, const float* skip, float* g, int N, int Ho, int Wo, int C, hipStream_t st) {
     const size_t total = (size_t)N * Ho * Wo * (C / 4);
     if (!total) return 0;

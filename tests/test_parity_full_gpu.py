@@ -23,8 +23,8 @@ pass), so every tensor must ALSO meet a RELATIVE criterion:
 test_zeroed_deep_gradient_fails_the_check is the negative control: conv5_1's weight gradient zeroed after the backward must fail.
 Round 3 adds the bench's own shape (8 x 4 x 1424 x 2128: batch gradients == mean of the eight single-frame gradients, each of which
 is oracle-pinned by the full-frame case) and BASELINE configs[2] (bf16 engine against the float64 oracle at frame size).
-Every measured number lands in gpurun_out/r05_parity_<case>.json; tools/parity_report.py turns those into
-profiles/r05_parity.md.
+Every measured number lands in gpurun_out/r06_parity_<case>.json; tools/parity_report.py turns those into
+profiles/r06_parity.md.
 """
 import json
 import os
@@ -151,7 +151,7 @@ def compare(tag, lib, shape, algo, want_f64=True, zero=None):
         return fails
     try:
         os.makedirs(OUT, exist_ok=True)
-        with open(os.path.join(OUT, 'r05_parity_%s.json' % tag), 'w') as f:
+        with open(os.path.join(OUT, 'r06_parity_%s.json' % tag), 'w') as f:
             json.dump(rec, f, indent=1)
     except OSError:
         pass
@@ -202,7 +202,7 @@ def test_full_frame_batch_is_image_independent(lib):
 def _dump(tag, rec):
     try:
         os.makedirs(OUT, exist_ok=True)
-        with open(os.path.join(OUT, 'r05_parity_%s.json' % tag), 'w') as f:
+        with open(os.path.join(OUT, 'r06_parity_%s.json' % tag), 'w') as f:
             json.dump(rec, f, indent=1)
     except OSError:
         pass

@@ -709,6 +709,37 @@ def test_slope_codes_give_the_gradients_of_the_saved_activations_bit_for_bit(lib
     assert torch.equal(g1, g0), int((g1 != g0).sum())
 
 
+@pytest.mark.parametrize('prec,shape', [('fp32', (1, 4, 528, 1072)), ('fp32', (2, 4, 144, 208)), ('bf16', (1, 4, 256, 512)), ('bf16', (2, 4, 272, 560))])
+def test_pool_codes_route_ties_like_the_saved_activations(lib, prec, shape):
+    """Round 6: the forward epilogues of conv1_2 / conv2_2 also write the ARGMAX of every 2x2 pooling window (2 bits per pooled element,
+    ConvArgs::pool_codes_out) and their own slope codes, and the pools' backward reads those instead of the saved un-pooled tensors.  The
+    winner of a window with equal maxima is the FIRST in row-major order (torch's CPU max_pool2d backward; unet_misc.hip POOL_BWD_1), which random
+    inputs never exercise -- so this input is piecewise constant on 6 x 10 blocks (offset against the 2 x 2 windows): inside a block all four
+    window elements of conv1_2's output are the same bits, across a block edge two of them are.  eld_debug_kernel_mask bit 8 switches the pool
+    codes off (bit 7: all codes): every gradient must agree to the last bit."""
+    net, x, junk, dout = _codes_case(prec, shape, seed=13)
+    N, C, H, W = shape
+    g = torch.Generator(device='cuda').manual_seed(21)
+    coarse = torch.rand(N, C, (H + 5) // 6 + 1, (W + 9) // 10 + 1, device='cuda', generator=g)
+    x = coarse.repeat_interleave(6, 2).repeat_interleave(10, 3)[:, :, 1:H + 1, 3:W + 3].contiguous()
+    assert x.shape == shape
+    bf16 = prec == 'bf16'
+    _, key, _ = net._engine_forward(x, save=True, bf16=bf16)
+    g1 = net._engine_backward(dout, key, shape).clone()
+    res = []
+    for mask in (256, 128):
+        old = lib.eld_debug_kernel_mask(mask)
+        try:
+            _, key, _ = net._engine_forward(x, save=True, bf16=bf16)
+            res.append(net._engine_backward(dout, key, shape).clone())
+        finally:
+            lib.eld_debug_kernel_mask(old)
+    torch.cuda.synchronize()
+    for g0 in res:
+        assert torch.isfinite(g0).all() and float(g0.abs().max()) > 0
+        assert torch.equal(g1, g0), int((g1 != g0).sum())
+
+
 @pytest.mark.parametrize('prec', ['fp32', 'bf16'])
 def test_backward_reads_slope_codes_only_from_the_forward_that_wrote_them(lib, prec):
     """Which code regions are valid is a property of the LAST forward on a workspace (its fp32 scheme, its kernels), not of the backward's own

@@ -1,7 +1,7 @@
 # evidence run of a round (usage: gpurun --timeout 3600 -- "bash tools/gpu_round_evidence.sh <tag>"): full test suite, profile set, parity tables, end-metric training parity, eval sweep, unmodified train_syn.py
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-T=${1:-r05f}
+T=${1:-r06f}
 mkdir -p gpurun_out/$T
 ( time timeout 900 python -m pytest tests -m gpu -q ) > gpurun_out/$T/pytest.log 2>&1; grep -n "passed\|failed" gpurun_out/$T/pytest.log | tail -2
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/$T/smoke.log 2>&1; tail -1 gpurun_out/$T/smoke.log

@@ -8,7 +8,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def main(tag='r05'):
+def main(tag='r06'):
     files = sorted(glob.glob(os.path.join(ROOT, 'gpurun_out', '%s_parity_*.json' % tag)))
     if not files:
         raise SystemExit('no parity records under gpurun_out/')
