@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
         constexpr int NPC = X3 ? 3 : (H2 ? 2 : 1);
         constexpr int KSB = PW / 16;
         const int gi = lane & 15, gg = lane >> 4;                   // lane inside its 16-lane group, group: channels 16(gg&1).., k-half gg>>1 (= hi)
-        const int lq0 = wpix * PW + 8 * hi + (gi >> 2);             // pixel row this lane ADDRESSES in k-step 0 (first 4-pixel block)
+    const int lq0 = wpix * PW + 8 * hi + (gi >> 2);             // pixel row this lane ADDRESSES in k-step 0 (first 4-pixel block)
         const int pyq = lq0 / TW, pxq = lq0 - pyq * TW;
         const bf16_t* gq = reinterpret_cast<const bf16_t*>(ldsG) + (wco * GROWS + lq0) * 32 + (gg & 1) * 16 + (gi & 3) * 4;
         const bf16_t* xq = reinterpret_cast<const bf16_t*>(ldsX) + (MODE == CONV_3X3 ? (pyq * (TW + 2) + pxq) : lq0) * JB + (gg & 1) * 16 + (gi & 3) * 4;
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
 // fragment offsets below stay compile-time for all three) over the VIRTUAL-ROW strip of the batch (conv.h vrow_*).  Pixels are the K dimension
 // of this GEMM, so every padding pixel of a ragged level is a wasted MFMA column: 8-wide tiles bring 89 x 133 from 1.30x (2 x 32 tiles) to 1.03x,
 // and their 3x3 halo is smaller too (10 x 10 against 4 x 34 pixels of X per 64 pixels of G).
-template <typename T, int WCO, int WCI, int WPIX, int TH, int TWT, bool STREAM = false>      // T = float (three bf16 pieces per operand, six products) or bf16_t (the tiles as they are, one product)
+template <typename T, int WCO, int WCI, int WPIX, int TH, int TWT, int STREAM = 0>      // T = float (three bf16 pieces per operand, six products) or bf16_t (the tiles as they are, one product); STREAM: 1 = streamed blocks, 2 = row-shared X fragments (below)
 __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradArgs a) {
     constexpr int ES = sizeof(T), EPU = 16 / ES, NPC = ES == 4 ? 3 : 1, XQ = 32 / EPU;      // element size, elements per 16-byte unit, pieces, units per 32-channel pixel
     static_assert(WCO * WCI * WPIX == 8, "8 waves");
@@ -566,7 +566,14 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradArgs a) {
 
     // fragment addresses (see wgrad_kernel): a 16-lane group reads a [4 pixels][16 channels] block per ds_read_b64_tr_b16
     const int gi = lane & 15, gg = lane >> 4;
-    const int lq0 = wpix * PW + 8 * hi + (gi >> 2);
+    // Row-shared X fragments (round 6, STREAM == 2; 8-pixel-wide tiles owned by one pixel slice): a 16-pixel k-step is two tile ROWS, and with the rows paired as
+    // (s, s + TH/2) instead of (2s, 2s + 1) the X operand of tap (ky, kx) at k-step s is rows (s + ky, s + ky + TH/2) of the halo tile -- a function of a = s + ky
+    // alone.  One fragment triple F(a, kx) then serves up to three (k-step, kernel row) pairs: (TH/2 + 2) x 3 X triples per tile instead of TH/2 x 9 (TH = 8: 18
+    // instead of 36; with the G triples 22 instead of 40 LDS fragment triples per 216 MFMAs).  The lane halves (hi) simply read rows TH/2 apart.
+    constexpr bool ROWSHARE = STREAM == 2;
+    static_assert(!ROWSHARE || (NPC == 3 && TWT == 8 && WPIX == 1 && TH % 2 == 0), "row-shared fragments: fp32, 8-pixel-wide tiles, one pixel slice");
+    constexpr int HS = TH / 2;
+    const int lq0 = ROWSHARE ? HS * TWT * hi + (gi >> 2) : wpix * PW + 8 * hi + (gi >> 2);
     const int pyq = lq0 / TWT, pxq = lq0 - pyq * TWT;                 // (the +4 pixels of tr8's second read and the k-step offsets below never leave the row)
     const bf16_t* gq = ldsG + wco * GBLK + lq0 * 32 + (gg & 1) * 16 + (gi & 3) * 4;
     const bf16_t* xq = ldsX + (wci * X_PIX + pyq * (TWT + 2) + pxq) * 32 + (gg & 1) * 16 + (gi & 3) * 4;
@@ -582,7 +589,46 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradArgs a) {
         store_tile();
         __syncthreads();
         if (tile + a.psplit < ntiles) load_tile(tile + a.psplit);
-        if constexpr (NPC == 3 && STREAM) {
+        if constexpr (ROWSHARE) {
+            // unit u = (a, kx): F(a, kx) feeds the blocks (ky, s = a - ky), 0 <= s < HS, six piece products each on acc[3 ky + kx]; an accumulator receives its
+            // k-steps in ascending order.  G(s) lives in a ring of three (used at a = s, s + 1, s + 2): G(a + 1) is read in unit (a, 2) AFTER that unit's
+            // ky = 2 block, the last reader of the slot's previous tenant G(a - 2).  F is double-buffered: the next unit's triple is read while this unit runs.
+            constexpr int GI[6] = {0, 1, 2, 0, 1, 0};
+            constexpr int XI[6] = {2, 1, 0, 1, 0, 0};
+            constexpr int NU = (HS + 2) * 3;
+            bf16x8 gr[3][3], xf[2][3];
+            auto readG = [&](int s_, bf16x8 (&g3)[3]) {
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) g3[pc] = tr8(gq + pc * GPL + s_ * TWT * 32);
+            };
+            auto readF = [&](int a_, int kx, bf16x8 (&x3)[3]) {
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) x3[pc] = tr8(xq + pc * XPL + (a_ * (TWT + 2) + kx) * 32);
+            };
+            readG(0, gr[0]);
+            readF(0, 0, xf[0]);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int a_ = u / 3, kx = u % 3;
+                if (u + 1 < NU) readF((u + 1) / 3, (u + 1) % 3, xf[(u + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ky = 2; ky >= 0; --ky) {
+                    const int s_ = a_ - ky;
+                    if (s_ >= 0 && s_ < HS) {
+#pragma unroll
+                        for (int q = 0; q < 6; ++q)
+                            acc[3 * ky + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gr[s_ % 3][GI[q]], xf[u & 1][XI[q]], acc[3 * ky + kx], 0, 0, 0);
+                    }
+                    if (ky == 2 && kx == 2 && a_ + 1 < HS) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        readG(a_ + 1, gr[(a_ + 1) % 3]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
+        if constexpr (NPC == 3 && STREAM == 1) {
             // Streamed fragment blocks (round 6, as conv_x3.hip x3_stage_blocks): block b = (k-step ks, tap t) is six piece products on acc[t]; the
             // fragments the NEXT block needs (its tap's three X pieces; at a k-step's last tap also the next k-step's three G pieces) are read into the
             // other half of two double buffers while the block's MFMAs run.  Per-accumulator product order as below: the same bits.
@@ -960,7 +1006,7 @@ int wgrad8_ntiles(int CA, int CBp, int N, int H, int W, bool bf16) {
     return ((W + TWo - 1) / TWo) * ((vrow_extent(N, H, VP) + TH - 1) / TH);
 }
 
-template <typename T, int WCO, int WCI, int WPIX, int TH, int TWT, bool STREAM = false>
+template <typename T, int WCO, int WCI, int WPIX, int TH, int TWT, int STREAM = 0>
 static int launch_w8(WgradArgs a, hipStream_t st) {
     constexpr int COB = 32 * WCO, JBK = 32 * WCI;
     a.vp = vrow_pitch(a.N, a.H, TH);
@@ -1023,12 +1069,17 @@ static int launch_wgrad8(const WgradArgs& a, hipStream_t st) {
     // same-box against the round-5 loop: 128 x 64 blocks 1997 -> 2005 us (+0.4 %), 64 x 64 2872 -> 2860 (-0.4 %), 32 x 32 2456 -> 2482 (+1.0 %): this loop's
     // eighteen-read bursts per kernel row were already covered by the SIMD's other wave.  Default: the round-5 loop.
     static const int stream = [] { const char* e = getenv("ELD_WG8_STREAM"); return e ? atoi(e) : 0; }();
-    if (COB == 128) return (stream & 1) ? launch_w8<float, 4, 2, 1, 8, 8, true>(a, st) : launch_w8<float, 4, 2, 1, 8, 8>(a, st);
+    // ELD_WG8_ROWSHARE (opt-in): the 128 x 64 blocks pair a k-step's tile rows TH/2 apart and share X fragments between kernel rows (wgrad8_kernel, STREAM == 2).
+    // Measured same-box (profiles/r06_ab_notes.md): 45 % fewer LDS fragment reads, 1979 -> 2008 us per launch (+1.5 %), step unchanged: this kernel is not held by
+    // its LDS reads, and the units at the tile's first and last row pair feed only six MFMAs per fragment triple.
+    static const int rowshare = [] { const char* e = getenv("ELD_WG8_ROWSHARE"); return e ? atoi(e) : 0; }();
+    if (COB == 128 && rowshare) return launch_w8<float, 4, 2, 1, 8, 8, 2>(a, st);
+    if (COB == 128) return (stream & 1) ? launch_w8<float, 4, 2, 1, 8, 8, 1>(a, st) : launch_w8<float, 4, 2, 1, 8, 8>(a, st);
     if (stream & 2) {
-        if (COB == 64 && JBK == 64) return launch_w8<float, 2, 2, 2, 2, 32, true>(a, st);
-        if (COB == 64) return launch_w8<float, 2, 1, 4, 4, 32, true>(a, st);
-        if (JBK == 64) return launch_w8<float, 1, 2, 4, 4, 32, true>(a, st);
-        return launch_w8<float, 1, 1, 8, 4, 32, true>(a, st);
+        if (COB == 64 && JBK == 64) return launch_w8<float, 2, 2, 2, 2, 32, 1>(a, st);
+        if (COB == 64) return launch_w8<float, 2, 1, 4, 4, 32, 1>(a, st);
+        if (JBK == 64) return launch_w8<float, 1, 2, 4, 4, 32, 1>(a, st);
+        return launch_w8<float, 1, 1, 8, 4, 32, 1>(a, st);
     }
     if (COB == 64 && JBK == 64) return launch_w8<float, 2, 2, 2, 2, 32>(a, st);
     if (COB == 64) return launch_w8<float, 2, 1, 4, 4, 32>(a, st);

@@ -69,25 +69,21 @@ __device__ __forceinline__ void pool_epilogue(const ConvArgs& a, const f32x16 (&
                 for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(dst + 8 * q) = pv[q];
             }
             if constexpr (PCODES) if (a.pool_codes_out != nullptr) {      // (wave-uniform) argmax of every window, ConvArgs::pool_codes_out; the 32- / 64-channel tiles of full-size problems only, like the slope codes
-                // this lane's column of the window: S = the bottom value is STRICTLY greater (bit per element); against the partner lane's column maximum:
-                // G = the partner's is strictly greater, Q = equal
-                unsigned S = 0, G = 0, Q = 0;
+                // The winner is the first element EQUAL to the window maximum in the order top-left, top-right, bottom-left, bottom-right (unet_misc.hip
+                // POOL_BWD_1).  Et / Eb: this lane's top / bottom value equals the maximum (one bit per element, built as E = 2 E + (v == max) from element
+                // 15 down: v_cmp + v_addc, two instructions per bit and two live registers -- the first form of this epilogue compared the four values with
+                // each other, three masks and ~13 instructions per element, and cost conv_x3w_kernel four spilled registers).
+                unsigned Et = 0, Eb = 0;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float top = acc[2 * rp][tt][i], bot = acc[2 * rp + 1][tt][i];
-                    const float me = fmax_raw(top, bot);
-                    const float pm = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(me), 0xB1, 0xF, 0xF, true));      // lane ^ 1
-                    S |= bot > top ? (1u << i) : 0u;
-                    G |= pm > me ? (1u << i) : 0u;
-                    Q |= pm == me ? (1u << i) : 0u;
+                for (int i = 15; i >= 0; --i) {
+                    const float mx = i % 4 == 0 ? pv[i / 4].x : (i % 4 == 1 ? pv[i / 4].y : (i % 4 == 2 ? pv[i / 4].z : pv[i / 4].w));
+                    asm("v_cmp_eq_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(Et) : "v"(acc[2 * rp][tt][i]), "v"(mx) : "vcc");
+                    asm("v_cmp_eq_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(Eb) : "v"(acc[2 * rp + 1][tt][i]), "v"(mx) : "vcc");
                 }
-                const unsigned Sp = (unsigned)__builtin_amdgcn_update_dpp(0, (int)S, 0xB1, 0xF, 0xF, true);
-                // (even lanes = left column.)  The right column wins when its maximum is greater, or equal with the left winner in the bottom row and the right
-                // one in the top row (row-major order: top-left, top-right, bottom-left, bottom-right; the first maximum takes the gradient)
-                const unsigned Hb = G | (Q & S & ~Sp);
-                const unsigned Vb = (S & ~Hb) | (Sp & Hb);
+                const unsigned Etr = (unsigned)__builtin_amdgcn_update_dpp(0, (int)Et, 0xB1, 0xF, 0xF, true);      // lane ^ 1: the right column's top (even lanes = left column)
+                const unsigned Vb = ~(Et | Etr), Hb = ~Et & (Etr | ~Eb);                                            // bottom row / right column
                 if (x < a.W && !(x & 1))
-                    a.pool_codes_out[((((size_t)(img * Hp + (y >> 1)) * Wp + (x >> 1)) * (size_t)(a.Nout >> 5)) + (size_t)((nb * BN + tt * 32) >> 5)) * 2 + hi] = Vb | (Hb << 16);
+                    a.pool_codes_out[((((size_t)(img * Hp + (y >> 1)) * Wp + (x >> 1)) * (size_t)(a.Nout >> 5)) + (size_t)((nb * BN + tt * 32) >> 5)) * 2 + hi] = (Vb & 0xFFFFu) | (Hb << 16);
             }
         }
     }

@@ -45,9 +45,10 @@ constexpr int W_AUNITS = W_APIX * 4;
 
 // SLABW: the last producer wave moves the weight slabs and the other three stage the halo (13 units per thread and chunk: 216 VGPRs, so only with two waves per
 // SIMD = 4 consumer waves); else all four producer waves stage the halo (10 units) AND move the slabs, with a counted wait for their pieces.
-template <int W_CW, int W_RPW, bool SLABW, bool PRIO, int W_PW = 4>
+template <int W_CW, int W_RPW, bool SLABW, bool PRIO, int W_PW = 4, bool PAIR = false>
 __global__ __launch_bounds__(64 * (W_CW + W_PW), (W_CW + W_PW) / 4) void conv_x3w_kernel(const ConvArgs a) {
     static_assert(W_CW * W_RPW == W_TH, "tile rows");
+    static_assert(!PAIR || SLABW, "paired halo loads: the halo waves wait for nothing but their own loads");
     constexpr int W_HW = SLABW ? W_PW - 1 : W_PW;                     // producer waves that stage the halo
     constexpr int W_PTHREADS = 64 * W_HW;
     constexpr int W_AIT = (W_AUNITS + W_PTHREADS - 1) / W_PTHREADS;   // sixteen-byte units per halo thread and chunk: 13 / 10
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(64 * (W_CW + W_PW), (W_CW + W_PW) / 4) void conv_x3
         load_part(I0_{}, I0_{}, IE_{}, 0);
         load_part(I1_{}, I0_{}, IE_{}, 1);
         cut_part(I0_{}, I0_{}, IE_{});
-        load_part(I0_{}, I0_{}, IE_{}, 2);
+        if constexpr (!PAIR) load_part(I0_{}, I0_{}, IE_{}, 2);
         __syncthreads();
         int g = 0, sb = 0;
         for (int k = 0; k < my_tiles; ++k) {
@@ -203,6 +204,26 @@ __global__ __launch_bounds__(64 * (W_CW + W_PW), (W_CW + W_PW) / 4) void conv_x3
                         }
                         // chunk g + 1: this stage's third of its units into LDS, then the same third of chunk g + 3 into the freed registers
                         prof(10);
+                        if constexpr (PAIR) {
+                            // Paired loads: chunks 2j and 2j + 1 of a tile are the two 64-byte halves of the same 128-byte pixel records (32 channels x 4 B), and
+                            // the L2 fetches whole lines.  Issued a chunk period apart (the schedule below), the second half finds its line evicted again
+                            // (FETCH_SIZE: 5.72 GB read per launch against 4.07 GB of halo tiles).  Here BOTH halves of a third's pixels are
+                            // requested back to back, in the stages of the EVEN chunk: the odd chunk g + 3 into the registers the cut of chunk g + 1 has just
+                            // freed, the even chunk g + 2 into the other set (free since chunk g was cut); the odd chunk's stages only cut.  An even chunk's
+                            // units are cut three stages after their loads were issued, an odd chunk's six.  Measured (profiles/r06_ab_notes.md): 4.09 GB per launch,
+                            // but the launch takes 2.7 % longer (all of a pair's loads in three stages instead of six) and the step is unchanged: opt-in (ELD_X3W=7).
+                            constexpr bool even = decltype(SN)::value == 1;          // (the set being cut holds an odd chunk <=> the chunk being consumed is even)
+                            using SO = std::integral_constant<int, 1 - decltype(SN)::value>;
+                            if (g + 1 < n_chunks) {
+                                if (ky == 0) cut_part(SN, I0_{}, IA_{}); else if (ky == 1) cut_part(SN, IA_{}, IB_{}); else cut_part(SN, IB_{}, IE_{});
+                            }
+                            prof(11);
+                            if constexpr (even) {
+                                if (ky == 0) { load_part(SO{}, I0_{}, IA_{}, g + 2); load_part(SN, I0_{}, IA_{}, g + 3); }
+                                else if (ky == 1) { load_part(SO{}, IA_{}, IB_{}, g + 2); load_part(SN, IA_{}, IB_{}, g + 3); }
+                                else { load_part(SO{}, IB_{}, IE_{}, g + 2); load_part(SN, IB_{}, IE_{}, g + 3); }
+                            }
+                        } else
                         if (g + 1 < n_chunks) {
                             if (ky == 0) { cut_part(SN, I0_{}, IA_{}); prof(11); load_part(SN, I0_{}, IA_{}, g + 3); }
                             else if (ky == 1) { cut_part(SN, IA_{}, IB_{}); prof(11); load_part(SN, IA_{}, IB_{}, g + 3); }
@@ -350,7 +371,7 @@ __global__ __launch_bounds__(64 * (W_CW + W_PW), (W_CW + W_PW) / 4) void conv_x3
 // 32-channel tensors), a single 32-channel output tensor, on a tile domain that gives every CU a tile; weights in conv_x3d_kernel's slab layout at BN = 32.
 // ELD_X3W=0 keeps these layers on conv_x3_kernel<32, 4>.
 // ELD_X3W: 0 = off (conv_x3_kernel<32, 4>), 1 = 4 consumer waves x 4 rows + 3 halo waves + 1 slab wave, 2 = 8 consumer waves x 2 rows + 4 producer waves (two MFMA
-// waves per SIMD cover each other's fragment-read latency), 3 = as 2 with the producers at s_setprio 3, 4 = 8 consumer + 8 producer waves (four waves per SIMD), 5 = as 4 with one of the producer waves moving the slabs and nothing else (the default)
+// waves per SIMD cover each other's fragment-read latency), 3 = as 2 with the producers at s_setprio 3, 4 = 8 consumer + 8 producer waves (four waves per SIMD), 5 = as 4 with one of the producer waves moving the slabs and nothing else (the default), 7 = as 5 with the halo loads of a chunk pair issued together (opt-in: -28 % of the launch's HBM reads, +2.7 % of its time)
 static int x3w_mode() {
     static const int on = [] { const char* e = getenv("ELD_X3W"); return e ? atoi(e) : 5; }();
     return on;
@@ -381,7 +402,11 @@ int launch_conv_x3w(const ConvArgs& a_in, hipStream_t st) {
     long long grid = (long long)eld_num_cus();
     if (grid > tiles) grid = tiles;
     const int mode = x3w_mode();
-    if (mode == 5) {
+    if (mode == 7) {
+        static EldAttrOnce once;
+        { const int rc = once.ensure(conv_x3w_kernel<8, 2, true, false, 8, true>, lds_bytes); if (rc) return rc; }
+        ELD_LAUNCH((conv_x3w_kernel<8, 2, true, false, 8, true>), dim3((unsigned)grid), dim3(1024), lds_bytes, st, a);
+    } else if (mode == 5) {
         static EldAttrOnce once;
         { const int rc = once.ensure(conv_x3w_kernel<8, 2, true, false, 8>, lds_bytes); if (rc) return rc; }
         ELD_LAUNCH((conv_x3w_kernel<8, 2, true, false, 8>), dim3((unsigned)grid), dim3(1024), lds_bytes, st, a);
