@@ -31,6 +31,7 @@ struct ConvArgs {
     int lrelu;          // EPI_FWD: apply max(0.2v, v)
     void* out0;         // EPI_FWD/CONVT: destination.  EPI_GRAD: channels [0, split)
     void* out1;         // EPI_GRAD: channels [split, Nout)
+    int xcd;            // != 0: workgroup ids are remapped so that every XCD takes a CONTIGUOUS range of the launch's work items (xcd_block below)
     int ksplit;         // conv_x3d_kernel, small problems: > 1 = split the K (input-channel chunk) range of every tile over this many workgroups; the
     float* kpart;       //   partial sums go to kpart[ksplit][N][H][W][Nout] (fp32) and x3_splitk_finish_kernel adds them in a fixed order and runs the
     size_t kpart_floats;//   epilogue.  kpart_floats = capacity of kpart (0: no split).  Set by the U-Net orchestration only.
@@ -370,6 +371,22 @@ int bfg_slab_bn(bool gather, int Nout, int Cs, int Cout_t, int N, int H, int W);
 __host__ __device__ inline size_t bfg_slab_bytes(int BN) { return (size_t)BN * 64; }
 int launch_conv_bfg(const ConvArgs& a, int mode, hipStream_t st);
 
+// XCD-aware work-item ids (round 6).  The dispatcher places block b on XCD b % 8 (observed, not promised: MI355X_MICROARCH.md, workgroup dispatch), and every XCD
+// has its own 4 MiB L2.  The kernels number their work items so that NEIGHBOURS share operands (the column blocks of one pixel tile, the (out, in) channel
+// blocks of one pixel slice of a weight gradient): with the identity map those neighbours sit on eight different XCDs and every one of the eight L2s fetches the
+// shared tile from the fabric.  xcd_block() hands XCD x the x-th CONTIGUOUS eighth of the ids instead (bijective for any grid size) -- a pure speed choice:
+// nothing depends on where a block runs.  eld_xcd_mask(): env ELD_XCD, one bit per kernel family (see launchers), for same-box A/B runs.
+#ifdef __HIPCC__
+__device__ __forceinline__ int xcd_block(int on) {
+    const int b = (int)blockIdx.x;
+    if (!on) return b;
+    const int n = (int)gridDim.x, q = n >> 3, r = n & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+#endif
+enum { XCD_GEMM = 1, XCD_WGRAD8 = 2, XCD_WGRAD = 4, XCD_X3D = 8, XCD_X3W = 16, XCD_BF16 = 32, XCD_IGEMM = 64 };
+int eld_xcd_mask();
+
 // dW-type reduction:  P[tap][i][j] = sum_pixels G[pixel][i] * X[pixel (+) tap][j]
 struct WgradArgs {
     const void* g;       // NHWC, CA channels, unshifted (the A operand); element type = dtype
@@ -389,6 +406,7 @@ struct WgradArgs {
     int dtype;           // DT_F32 / DT_BF16 inputs (partials and accumulation are always fp32)
     int algo;            // as ConvArgs::algo
     int wgrad8;          // partials were sized for wgrad8_kernel's block shape (wgrad8_shape): use it
+    int xcd;             // as ConvArgs::xcd
     const float* amax_g; const float* amax_x0; const float* amax_x1;     // algo 2 only: see ConvArgs
 };
 

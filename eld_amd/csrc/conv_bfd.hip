@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
     const char* ldsA = lds + NBB * B_BYTES;
     const char* ldsB = lds;
 
-    int t = blockIdx.x;
+    int t = xcd_block(a.xcd);
     if (t >= total_tiles) return;
     // bias -> LDS once per workgroup: a global load inside the tile loop's epilogue would be waited for with a vmcnt that also drains every
     // LDS-DMA piece in flight (the queue retires in order)
@@ -392,6 +392,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfd_kernel(const ConvArgs a) 
 
 template <int BN, int RPW, int WAVES>
 int launch_bfd(ConvArgs a, hipStream_t st) {
+    a.xcd = eld_xcd_mask() & XCD_BF16;
     constexpr int TH = WAVES * RPW;
     conv_tile_shape(a.N, a.H, a.W, TH, a.pool_out != nullptr, a.tile_h, a.tile_w);
     a.vp = vrow_pitch(a.N, a.H, a.tile_h);

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64 * BFG_WAVES) void conv_bfg_kernel(const ConvArgs
     const i32x4 rsrc_w = {(int)(unsigned)wbase, (int)((unsigned)(wbase >> 32) & 0xFFFFu), (int)((size_t)KC * NB * B_BYTES), 0x00020000};
     constexpr unsigned OOB = 0xFFFFFFF0u;
 
-    const int first = blockIdx.x, stride = gridDim.x;
+    const int first = xcd_block(a.xcd), stride = gridDim.x;
     if (first >= total_tiles) return;
     if (!GATHER) {                               // bias -> LDS once (a global load in the loop's epilogue would drain the DMA queue: vmcnt retires in order)
         for (int i = tid; i < a.Cout_t; i += 64 * WAVES) lds_bias[i] = a.bias[i];
@@ -225,6 +225,7 @@ __global__ __launch_bounds__(64 * BFG_WAVES) void conv_bfg_kernel(const ConvArgs
 
 template <int BN, bool GATHER>
 int launch_bfg(ConvArgs a, hipStream_t st) {
+    a.xcd = eld_xcd_mask() & XCD_BF16;
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + BFG_TH - 1) / BFG_TH;
     const size_t lds_bytes = (size_t)BFG_NAB * (BFG_A_BYTES + BN * 64) + BFG_BIAS_BYTES;

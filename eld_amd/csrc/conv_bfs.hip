@@ -105,7 +105,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfs_kernel(const ConvArgs a) 
             a_voff[it] = ok ? (unsigned)(gy * a.W + gx) * (unsigned)(Cs0 * 2) + a_oct[it] : OOB;
         }
     };
-    const int first = blockIdx.x, stride = gridDim.x;
+    const int first = xcd_block(a.xcd), stride = gridDim.x;
     if (first >= total_tiles) return;
     const int my_tiles = (total_tiles - first + stride - 1) / stride;
     const int n_items = my_tiles * NCH;
@@ -311,6 +311,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfs_kernel(const ConvArgs a) 
 
 template <int RPW, int WAVES, int ACT>
 int launch_bfs(ConvArgs a, hipStream_t st) {
+    a.xcd = eld_xcd_mask() & XCD_BF16;
     constexpr int TH = WAVES * RPW;
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + TH - 1) / TH;

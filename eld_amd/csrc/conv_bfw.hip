@@ -108,7 +108,7 @@ __global__ __launch_bounds__(512) void conv_bfw_kernel(const ConvArgs a) {
             a_voff[it] = ok ? (unsigned)(gy * a.W + gx) * (unsigned)(Cs0 * 2) + a_oct[it] : OOB;
         }
     };
-    const int first = blockIdx.x, stride = gridDim.x;
+    const int first = xcd_block(a.xcd), stride = gridDim.x;
     if (first >= total_tiles) return;
     const int my_tiles = (total_tiles - first + stride - 1) / stride;
     const int n_items = my_tiles * NI;
@@ -338,6 +338,7 @@ __global__ __launch_bounds__(512) void conv_bfw_kernel(const ConvArgs a) {
 
 template <bool ACT>
 int launch_bfw(ConvArgs a, hipStream_t st) {
+    a.xcd = eld_xcd_mask() & XCD_BF16;
     constexpr int TH = 16;
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + TH - 1) / TH;

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
         }
     };
 
-    int t = blockIdx.x;
+    int t = xcd_block(a.xcd);
     if (t >= total_tiles) return;
     setup_load(t);
     load_chunk(0);
@@ -384,6 +384,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
 
 template <typename T, int MODE, int BN, int RPW, bool H2 = false>
 static int launch_t(ConvArgs a, hipStream_t st) {
+    a.xcd = eld_xcd_mask() & XCD_IGEMM;
     using G = Geo<MODE, RPW>;
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + G::TH - 1) / G::TH;

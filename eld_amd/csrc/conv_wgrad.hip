@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     const int m = lane & 31, hi = lane >> 5;
     const int wco = wave % WCO, wpix = wave / WCO;
     const int IB = a.CA / COB, JBn = a.CBp / JB;
-    int bid = blockIdx.x;
+    int bid = xcd_block(a.xcd);
     const int jb = bid % JBn; bid /= JBn;
     const int ib = bid % IB;
     const int ps = bid / IB;
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradArgs a) {
     const int m = lane & 31, hi = lane >> 5;
     const int wco = wave % WCO, wci = (wave / WCO) % WCI, wpix = wave / (WCO * WCI);
     const int IB = a.CA / COB, JBn = a.CBp / JBK;
-    int bid = blockIdx.x;
+    int bid = xcd_block(a.xcd);
     const int jb = bid % JBn; bid /= JBn;
     const int ib = bid % IB;
     const int ps = bid / IB;
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(512, 2) void wgrad8d_kernel(const WgradArgs a) {
     const int m = lane & 31, hi = lane >> 5;
     const int wco = wave % WCO, wci = (wave / WCO) % WCI, wpix = wave / (WCO * WCI);
     const int IB = a.CA / COB, JBn = a.CBp / JBK;
-    int bid = blockIdx.x;
+    int bid = xcd_block(a.xcd);
     const int jb = bid % JBn; bid /= JBn;
     const int ib = bid % IB;
     const int ps = bid / IB;
@@ -1008,6 +1008,7 @@ int wgrad8_ntiles(int CA, int CBp, int N, int H, int W, bool bf16) {
 
 template <typename T, int WCO, int WCI, int WPIX, int TH, int TWT, int STREAM = 0>
 static int launch_w8(WgradArgs a, hipStream_t st) {
+    a.xcd = eld_xcd_mask() & XCD_WGRAD8;
     constexpr int COB = 32 * WCO, JBK = 32 * WCI;
     a.vp = vrow_pitch(a.N, a.H, TH);
     a.tiles_x = (a.W + TWT - 1) / TWT;
@@ -1027,6 +1028,7 @@ static int launch_w8(WgradArgs a, hipStream_t st) {
 
 template <int WCO, int WCI, int WPIX, int TH, int TWT>
 static int launch_w8d(WgradArgs a, hipStream_t st) {
+    a.xcd = eld_xcd_mask() & XCD_WGRAD8;
     constexpr int COB = 32 * WCO, JBK = 32 * WCI;
     a.vp = vrow_pitch(a.N, a.H, TH);
     a.tiles_x = (a.W + TWT - 1) / TWT;
@@ -1089,6 +1091,7 @@ static int launch_wgrad8(const WgradArgs& a, hipStream_t st) {
 
 template <typename T, int MODE, int WCO, int TH, int ALG = ALG_F32>
 static int launch_w(WgradArgs a, hipStream_t st) {
+    a.xcd = eld_xcd_mask() & XCD_WGRAD;
     constexpr int COB = 32 * WCO;
     constexpr int X_PIX = MODE == CONV_3X3 ? (TH + 2) * (TW + 2) : 4 * TH * TW;
     a.tiles_x = (a.W + TW - 1) / TW;

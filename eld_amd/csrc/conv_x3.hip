@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
         }
     };
 
-    int t = blockIdx.x;
+    int t = xcd_block(a.xcd);
     if (t >= total_tiles) return;
     if ((ELD_DBG(a) & 256) && blockIdx.x >= (gridDim.x >> 1)) {      // (dev probe 256: the second workgroup of a CU starts half a tile period late)
         for (int i = 0; i < 4; ++i) __builtin_amdgcn_s_sleep(127);
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 && BN <= 64) ? 2 : (WAVES =
     }
     auto chunk_begin = [&](int t) { return ((t % KS) * NCH) / KS; };
     auto chunk_end = [&](int t) { return ((t % KS + 1) * NCH) / KS; };
-    int t = blockIdx.x;
+    int t = xcd_block(a.xcd);
     if (t >= total_tiles) return;
     setup_load(t / KS);
     load_A(chunk_begin(t) * CK);
@@ -814,7 +814,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv_x3_gemm_k
         }
     };
 
-    int t = blockIdx.x;
+    int t = xcd_block(a.xcd);
     if (t >= total_tiles) return;
     setup_load(t);
     load_stage(t % NB, 0);
@@ -980,6 +980,7 @@ int launch_x3_splitk_finish(const ConvArgs& a, hipStream_t st) {
 
 template <int BN, int RPW, bool DB, bool BFIRST = false, bool BSLAB = false, bool STREAM = false>
 int launch_x3(ConvArgs a, hipStream_t st) {
+    a.xcd = eld_xcd_mask() & XCD_X3W;
     constexpr int TH = 4 * RPW;
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + TH - 1) / TH;
@@ -1002,6 +1003,7 @@ int launch_x3(ConvArgs a, hipStream_t st) {
 
 template <int BN, int RPW, int WAVES, bool DB, int STREAM = 0>
 int launch_x3d(ConvArgs a, hipStream_t st) {
+    a.xcd = eld_xcd_mask() & XCD_X3D;
     constexpr int TH = WAVES * RPW;
     conv_tile_shape(a.N, a.H, a.W, TH, a.pool_out != nullptr, a.tile_h, a.tile_w);
     a.vp = vrow_pitch(a.N, a.H, a.tile_h);
@@ -1043,6 +1045,7 @@ int launch_x3d(ConvArgs a, hipStream_t st) {
 
 template <int MODE, int BN, int WAVES>
 int launch_x3_gemm(ConvArgs a, hipStream_t st) {
+    a.xcd = eld_xcd_mask() & XCD_GEMM;
     constexpr int TH = 2 * WAVES;
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + TH - 1) / TH;
@@ -1101,6 +1104,12 @@ int x3_slab_bn(int Nout, int N, int H, int W, int* waves) {
     if (waves && px_tiles * (Nout / 64) < cus) *waves = 4;
     // (round 5: the 4-wave kernel for the 64-channel layers of big problems too -- 8-row tiles, two 81 KB workgroups per CU -- measured -0.2 %: not kept)
     return 64;
+}
+
+// XCD-aware work-item ids (conv.h xcd_block): one bit per kernel family, env ELD_XCD for same-box A/B runs
+int eld_xcd_mask() {
+    static const int m = [] { const char* e = getenv("ELD_XCD"); return e ? atoi(e) : 127; }();
+    return m;
 }
 
 // a: fp32 CONV_3X3 arguments already validated by launch_conv

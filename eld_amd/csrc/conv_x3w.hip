@@ -63,7 +63,7 @@ __global__ __launch_bounds__(64 * (W_CW + W_PW), (W_CW + W_PW) / 4) void conv_x3
     const int Cin = a.C0 + a.C1, NCH = Cin / W_CK;                    // 2 or 4 chunks per tile (launcher: NCH even, C0 % 32 == 0)
     const int tiles_img = a.tiles_x * a.tiles_y;
     const int total_tiles = tiles_img * a.N;
-    const int first = blockIdx.x, stride = gridDim.x;
+    const int first = xcd_block(a.xcd), stride = gridDim.x;
     if (first >= total_tiles) return;
     const int my_tiles = (total_tiles - first + stride - 1) / stride;
     const int n_chunks = my_tiles * NCH;                              // the workgroup's chunk sequence g = 0 .. n_chunks - 1: tile first + (g / NCH) * stride, chunk g % NCH
@@ -392,6 +392,7 @@ void conv_x3_set_prof(unsigned long long* buf) { g_x3w_prof = buf; }      // dev
 
 int launch_conv_x3w(const ConvArgs& a_in, hipStream_t st) {
     ConvArgs a = a_in;
+    a.xcd = eld_xcd_mask() & XCD_X3W;
     a.prof = ELD_DEV_TOOLS ? g_x3w_prof : nullptr;
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + W_TH - 1) / W_TH;
