@@ -42,6 +42,13 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def ranks_share_device():
+    """True when the job has more ranks than this node has GPUs (the one-GPU gloo smoke runs of the N > 1 path): two processes then time-slice ONE
+    device, and a process that keeps a second stream busy beside its compute stream (ELDModel.prefetch_input) was measured 24x slower in that setting
+    (424 against 17.7 ms per 512 x 512 step, profiles/r06_ab_notes.md) -- callers switch the lookahead off."""
+    return world_size() > 1 and torch.cuda.is_available() and world_size() > torch.cuda.device_count()
+
+
 def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 

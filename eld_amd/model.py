@@ -193,6 +193,8 @@ class ELDModel:
         the synthesis stream first waits for everything the current stream holds at this point (the previous iteration), so host-side draws
         (_sample_params, sample ids) and device results are exactly those of the serial order.  set_input(data) with the same dict picks the
         tensors up; any other set_input() discards the prefetch."""
+        if D.ranks_share_device():                   # several ranks time-slice this GPU (one-GPU smoke runs of the N > 1 path): no second stream, set_input() does the work
+            return
         if self._synth_stream is None:
             self._synth_stream = torch.cuda.Stream(self.device)
         s = self._synth_stream
