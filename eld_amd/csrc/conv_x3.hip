@@ -922,221 +922,6 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 4 ? 2 : 1) void conv_x3_gemm_k
     }
 }
 
-// ---- the same pixel GEMM, software-pipelined (round 6) -------------------------------------------------------------------------
-// conv_x3_gemm_kernel runs a stage as barrier / cut + LDS stores / barrier / loads / MFMAs on ONE LDS buffer: every wave of the workgroup cuts at the same
-// time, then every wave multiplies, and the single-layer ablation (tools/convt_ablate.py) shows the launch time to be the SUM of its staging side and its
-// matrix side (upv6 forward: 0.35 + 0.55 ms of 0.90), two workgroups per CU notwithstanding.  Here a stage is 16 k-values, the stage buffer is doubled
-// (2 x 35.8 KB: the same 71.7 KB, still two workgroups per CU) and a wave cuts stage s + 1 into the OTHER buffer between the MFMAs of stage s -- the VALU /
-// LDS-write work of the cut issues in the shadow of the wave's own matrix instructions (sched_group_barrier pins the interleave), one barrier per stage.
-// Loads run two stages ahead of the cut in two register sets (the workgroup's tiles form ONE stage sequence: the next tile's first stages are in flight
-// during a tile's epilogue).  Same operands, same per-accumulator order of the k blocks as conv_x3_gemm_kernel: the same bits.
-template <int MODE, int BN, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 2) void conv_x3_gemmp_kernel(const ConvArgs a) {
-    constexpr int THREADS = 64 * WAVES, RPW = 2, TH = WAVES * RPW, NT = BN / 32;
-    constexpr int TPIX = TH * TW;
-    constexpr int A_WORDS = TPIX * PX, BUF_WORDS = (TPIX + BN) * PX;
-    extern __shared__ __attribute__((aligned(16))) float lds[];      // [2][A rows: TPIX pixels | B rows: BN columns][PX]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m = lane & 31, hi = lane >> 5;
-    const int NB = a.Nout / BN;
-    const int C0 = a.C0;
-    const int Ktot = MODE == CONV_1X1 ? C0 : 4 * C0;
-    const int SPT = Ktot / 16;                                        // stages per tile
-    const int Ws = MODE == CONV_GATHER2X2 ? 2 * a.W : a.W, Hs = MODE == CONV_GATHER2X2 ? 2 * a.H : a.H;
-    const int total_tiles = a.tiles_x * a.tiles_y * a.N * NB;
-    const int first = xcd_block(a.xcd), stride = gridDim.x;
-    if (first >= total_tiles) return;
-    const int my_tiles = (total_tiles - first + stride - 1) / stride;
-    const int S = my_tiles * SPT;                                     // the workgroup's stage sequence: stage s = tile first + (s / SPT) * stride, k0 = (s % SPT) * 16
-
-    constexpr int A_IT = TPIX * 4 / THREADS, B_IT = BN * 4 / THREADS;
-    static_assert(TPIX * 4 % THREADS == 0 && BN * 4 % THREADS == 0, "whole staging passes");
-    float4 ra[2][A_IT], rb[2][B_IT];
-    unsigned a_voff[2][A_IT], b_voff[B_IT];
-    int s_img[2] = {0, 0}, s_tile[2] = {-1, -1}, s_nb[2] = {0, 0};
-    constexpr unsigned OOB = 0xFFFFFFF0u;
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (int)((size_t)(MODE == CONV_1X1 ? 1 : 4) * a.Nout * C0 * 4), 0x00020000);
-#pragma unroll
-    for (int it = 0; it < B_IT; ++it) {
-        const int u = tid + it * THREADS;                              // (n, part)
-        b_voff[it] = (unsigned)(stage_row(u >> 2, BN) * C0 * 4 + (u & 3) * 16);
-    }
-    auto decode = [&](int t, int& nb, int& img, int& y0, int& x0) {
-        nb = t % NB;
-        int r = t / NB;
-        const int tx = r % a.tiles_x;
-        r /= a.tiles_x;
-        const int ty = r % a.tiles_y;
-        img = r / a.tiles_y;
-        y0 = ty * TH; x0 = tx * TW;
-    };
-    using I0_ = std::integral_constant<int, 0>;
-    using I1_ = std::integral_constant<int, 1>;
-    auto setup_set = [&](auto SI, int t) {
-        constexpr int si = decltype(SI)::value;
-        int y0, x0;
-        decode(t, s_nb[si], s_img[si], y0, x0);
-        s_tile[si] = t;
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const int u = tid + it * THREADS;                          // (pixel, part)
-            const int lp = stage_row(u >> 2, TPIX);
-            const int gy = y0 + lp / TW, gx = x0 + lp % TW;
-            const bool ok = gy < a.H && gx < a.W;
-            const unsigned pix = MODE == CONV_GATHER2X2 ? (unsigned)(2 * gy * Ws + 2 * gx) : (unsigned)(gy * Ws + gx);
-            a_voff[si][it] = ok ? pix * (unsigned)(C0 * 4) + (unsigned)((u & 3) * 16) : OOB;
-        }
-    };
-    // loads of stage s into register set SI (no-op past the end of the sequence)
-    auto load_stage = [&](auto SI, int s_) {
-        constexpr int si = decltype(SI)::value;
-        if (s_ >= S) return;
-        const int k = s_ / SPT, k0 = (s_ - k * SPT) * 16;
-        const int t = first + k * stride;
-        if (t != s_tile[si]) setup_set(SI, t);
-        const int tap = MODE == CONV_GATHER2X2 ? k0 / C0 : 0;
-        const int cs = k0 - tap * C0;
-        const size_t img_bytes = (size_t)Hs * Ws * C0 * 4;
-        const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(static_cast<const char*>(a.in0) + (size_t)s_img[si] * img_bytes), 0, (int)img_bytes, 0x00020000);
-        const int asoff = (((tap >> 1) * Ws + (tap & 1)) * C0 + cs) * 4;
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it)
-            ra[si][it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)a_voff[si][it], asoff, 0));
-        const int wsoff = ((tap * a.Nout + s_nb[si] * BN) * C0 + cs) * 4;
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it)
-            rb[si][it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)b_voff[it], wsoff, 0));
-    };
-    // cut register set SI into stage buffer SI (a stage's set and buffer have the stage's parity)
-    auto cut_stage = [&](auto SI) {
-        constexpr int si = decltype(SI)::value;
-        float* bufp = lds + si * BUF_WORDS;
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const int u = tid + it * THREADS;
-            split_store(bufp + stage_row(u >> 2, TPIX) * PX + (u & 3) * 2, ra[si][it]);
-        }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            const int u = tid + it * THREADS;
-            split_store(bufp + A_WORDS + stage_row(u >> 2, BN) * PX + (u & 3) * 2, rb[si][it]);
-        }
-    };
-
-    f32x16 acc[RPW][NT];
-    int kk = 0, tk = 0;                                               // stage within the tile, tile counter
-    // one stage: MFMAs of stage s from buffer SB, the cut of stage s + 1 (register set / buffer 1 - SB) between them, then the loads of stage s + 3 into the freed set
-    auto stage = [&](auto SB, int s_) {
-        constexpr int sb = decltype(SB)::value;
-        using SN = std::integral_constant<int, 1 - sb>;
-        if (kk == 0) {
-#pragma unroll
-            for (int r = 0; r < RPW; ++r)
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[r][tt][i] = 0.f;
-        }
-        {
-            const float* bufp = lds + sb * BUF_WORDS;
-            uint4 fx[3][RPW], fw[3][NT];
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                const float* p = bufp + ((wave * RPW + r) * TW + m) * PX + hi * 4;
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc) fx[pc][r] = *reinterpret_cast<const uint4*>(p + pc * 8);
-            }
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt) {
-                const float* p = bufp + A_WORDS + (tt * 32 + m) * PX + hi * 4;
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc) fw[pc][tt] = *reinterpret_cast<const uint4*>(p + pc * 8);
-            }
-            cut_stage(SN{});                                           // (past the end of the sequence: stale registers into a buffer nobody reads)
-            constexpr int WI[6] = {0, 1, 2, 0, 1, 0};
-            constexpr int XI[6] = {2, 1, 0, 1, 0, 0};
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-#pragma unroll
-                for (int r = 0; r < RPW; ++r)
-#pragma unroll
-                    for (int tt = 0; tt < NT; ++tt)
-                        acc[r][tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[WI[q]][tt]), __builtin_bit_cast(bf16x8, fx[XI[q]][r]), acc[r][tt], 0, 0, 0);
-            // the interleave: one MFMA, then a slice of the cut (per stage and thread: (A_IT + B_IT) x (18 VALU + 3 ds_write_b64))
-#pragma unroll
-            for (int i = 0; i < 6 * RPW * NT; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-            }
-        }
-        load_stage(SN{}, s_ + 3);
-        if (kk == SPT - 1) {
-            // epilogue of tile tk (conv_x3_gemm_kernel's): lane (m, hi) holds channels 8q + 4hi .. + 3 of pixel x0 + m in each 32-block
-            const int t = first + tk * stride;
-            int nb, img, y0, x0;
-            decode(t, nb, img, y0, x0);
-            const int x = x0 + m;
-            const bool xok = x < a.W;
-#pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                const int y = y0 + wave * RPW + r;
-                const bool yok = y < a.H;
-                const int yc = yok ? y : 0;
-                const size_t pix = (size_t)(img * a.H + yc) * a.W + (xok ? x : 0);
-#pragma unroll
-                for (int tt = 0; tt < NT; ++tt) {
-                    const int nb32 = nb * BN + tt * 32, nbase = nb32 + 4 * hi;
-                    float4 v[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = make_float4(acc[r][tt][4 * q], acc[r][tt][4 * q + 1], acc[r][tt][4 * q + 2], acc[r][tt][4 * q + 3]);
-                    float* blk;
-                    size_t pstride;
-                    if (MODE == CONV_1X1) {
-                        const int tap = nb32 / a.Cout_t, co0 = nb32 - tap * a.Cout_t;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float4 bq = *reinterpret_cast<const float4*>(a.bias + co0 + 4 * hi + 8 * q);
-                            v[q].x += bq.x; v[q].y += bq.y; v[q].z += bq.z; v[q].w += bq.w;
-                        }
-                        blk = static_cast<float*>(a.out0) + ((size_t)(img * 2 * a.H + 2 * yc + (tap >> 1)) * (2 * a.W) + 2 * x0 + (tap & 1)) * a.Cout_t + co0;
-                        pstride = (size_t)2 * a.Cout_t;
-                    } else {
-                        blk = static_cast<float*>(a.out0) + ((size_t)(img * a.H + yc) * a.W + x0) * a.Nout + nb32;
-                        pstride = (size_t)a.Nout;
-                        const float* act = static_cast<const float*>(a.act0);
-                        if (act) {
-                            float4 sl[4];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) sl[q] = *reinterpret_cast<const float4*>(act + pix * a.Nout + nbase + 8 * q);
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                v[q].x *= lrelu_slope(sl[q].x); v[q].y *= lrelu_slope(sl[q].y);
-                                v[q].z *= lrelu_slope(sl[q].z); v[q].w *= lrelu_slope(sl[q].w);
-                            }
-                        }
-                    }
-                    f32_line_store(v, blk, pstride, lane, yok, a.W - x0);
-                }
-            }
-            kk = 0; ++tk;
-        } else ++kk;
-        __syncthreads();                                              // stage s + 1 is in its buffer; everybody is done reading stage s
-    };
-
-    // prologue: stage 0 cut into buffer 0; stages 1 and 2 in flight
-    load_stage(I0_{}, 0);
-    load_stage(I1_{}, 1);
-    cut_stage(I0_{});
-    load_stage(I0_{}, 2);
-    __syncthreads();
-    for (int s_ = 0; s_ < S; s_ += 2) {
-        stage(I0_{}, s_);
-        if (s_ + 1 >= S) break;
-        stage(I1_{}, s_ + 1);
-    }
-}
-
 // ---- split-K finish: out = epilogue(sum over the K parts, in a fixed order) ---------------------------------------------------------
 // One thread per (pixel or 2x2 pixel block, channel quad).  The epilogues are those of the conv kernels: EPI_FWD bias + LeakyReLU (+ the fused
 // 2x2 max-pool when pool_out is set: the thread then owns a whole pooling window), EPI_GRAD LeakyReLU slope of the saved activation and the
@@ -1276,16 +1061,8 @@ int launch_x3_gemm(ConvArgs a, hipStream_t st) {
     if (per_cu > 2) per_cu = 2;
     long long grid = (long long)eld_num_cus() * per_cu;
     if (grid > tiles) grid = tiles;
-    // ELD_GEMM_PIPE (default 1): the software-pipelined kernel (cut of stage s + 1 between the MFMAs of stage s); 0 = conv_x3_gemm_kernel
-    static const int pipe = [] { const char* e = getenv("ELD_GEMM_PIPE"); return e ? atoi(e) : 1; }();
-    if (pipe && WAVES == 4 && BN == 64) {
-        auto kp = conv_x3_gemmp_kernel<MODE, 64, 4>;
-        static EldAttrOnce oncep;
-        { const int rc = oncep.ensure(kp, lds_bytes); if (rc) return rc; }
-        ELD_LAUNCH(kp, dim3((unsigned)grid), dim3(256), lds_bytes, st, a);
-        ELD_LAUNCH_CHECK();
-        return 0;
-    }
+    // (round 6: a software-pipelined variant -- 16-k stages, doubled stage buffer, the cut of stage s + 1 between the MFMAs of stage s -- measured +26 % per launch:
+    // these launches are bound by the bytes a workgroup keeps in flight, not by the cut; commit 7f24c6e, profiles/r06_ab_notes.md section 9)
     auto kern = conv_x3_gemm_kernel<MODE, BN, WAVES>;
     static EldAttrOnce once;
     { const int rc = once.ensure(kern, lds_bytes); if (rc) return rc; }
