@@ -31,6 +31,7 @@ struct ConvArgs {
     int lrelu;          // EPI_FWD: apply max(0.2v, v)
     void* out0;         // EPI_FWD/CONVT: destination.  EPI_GRAD: channels [0, split)
     void* out1;         // EPI_GRAD: channels [split, Nout)
+    int band;           // > 1: tile ids run in bands of `band` tile rows, column-major inside a band (band_tile below)
     int xcd;            // != 0: workgroup ids are remapped so that every XCD takes a CONTIGUOUS range of the launch's work items (xcd_block below)
     int ksplit;         // conv_x3d_kernel, small problems: > 1 = split the K (input-channel chunk) range of every tile over this many workgroups; the
     float* kpart;       //   partial sums go to kpart[ksplit][N][H][W][Nout] (fp32) and x3_splitk_finish_kernel adds them in a fixed order and runs the
@@ -384,6 +385,18 @@ __device__ __forceinline__ int xcd_block(int on) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
 }
 #endif
+// Tile id -> (tile row, tile column) in BANDS of BH tile rows, column-major inside a band: 32 consecutive ids (what an XCD takes per round under xcd_block) are then an
+// 8-column x 4-row block of tiles instead of half a tile row, and the halo rows / columns neighbouring tiles share are fetched once per XCD (the level-0 weight
+// gradient reads 6 x 34 pixels of X per 4 x 32 pixels of G).  BH <= 1: row-major.  Bijective for any tiles_x x tiles_y (the last band is shorter).
+__host__ __device__ inline void band_tile(int id, int tiles_x, int tiles_y, int BH, int& ty, int& tx) {
+    if (BH <= 1) { ty = id / tiles_x; tx = id - ty * tiles_x; return; }
+    const int full = tiles_x * BH, band = id / full, off = id - band * full;
+    int bh = tiles_y - band * BH;
+    if (bh > BH) bh = BH;
+    tx = off / bh;
+    ty = band * BH + (off - tx * bh);
+}
+int eld_tile_band();      // env ELD_TILE_BAND (default 4; 1 = row-major)
 enum { XCD_GEMM = 1, XCD_WGRAD8 = 2, XCD_WGRAD = 4, XCD_X3D = 8, XCD_X3W = 16, XCD_BF16 = 32, XCD_IGEMM = 64 };
 int eld_xcd_mask();
 
@@ -407,6 +420,7 @@ struct WgradArgs {
     int algo;            // as ConvArgs::algo
     int wgrad8;          // partials were sized for wgrad8_kernel's block shape (wgrad8_shape): use it
     int xcd;             // as ConvArgs::xcd
+    int band;            // as ConvArgs::band
     const float* amax_g; const float* amax_x0; const float* amax_x1;     // algo 2 only: see ConvArgs
 };
 

@@ -91,7 +91,8 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfs_kernel(const ConvArgs a) 
     auto decode = [&](int t, int& img, int& y0, int& x0) {
         img = t / tiles_img;
         const int r = t - img * tiles_img;
-        const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+        int ty, tx;
+        band_tile(r, a.tiles_x, a.tiles_y, a.band, ty, tx);
         y0 = ty * TH; x0 = tx * TW;
     };
     auto setup_load = [&](int t) {
@@ -312,6 +313,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_bfs_kernel(const ConvArgs a) 
 template <int RPW, int WAVES, int ACT>
 int launch_bfs(ConvArgs a, hipStream_t st) {
     a.xcd = eld_xcd_mask() & XCD_BF16;
+    a.band = eld_tile_band();
     constexpr int TH = WAVES * RPW;
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + TH - 1) / TH;

@@ -471,7 +471,8 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const WgradArgs a) {
     // image and columns outside the image read as zeros -- the convolution's padding for X and "no pixel" for G.
     const unsigned g_rowc = (unsigned)(g_py0 * a.W * a.CA) * (unsigned)ES;      // this thread's row part of the G offset
     auto load_tile = [&](int tile) {
-        const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+        int ty, tx;
+        band_tile(tile, a.tiles_x, a.tiles_y, a.band, ty, tx);
         const int v0 = ty * TH, x0 = tx * TWT;
         const int img0 = v0 / VP, vrel = v0 - img0 * VP;
         const int wrem = a.W - x0;
@@ -834,7 +835,8 @@ __global__ __launch_bounds__(512, 2) void wgrad8d_kernel(const WgradArgs a) {
 
     // DMA of one tile into buffer `buf` (see wgrad8_kernel::load_tile for the strip / seam rules)
     auto issue = [&](int tile, int buf) {
-        const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+        int ty, tx;
+        band_tile(tile, a.tiles_x, a.tiles_y, a.band, ty, tx);
         const int v0 = ty * TH, x0 = tx * TWT;
         const int img0 = v0 / VP, vrel = v0 - img0 * VP;
         const int wrem = a.W - x0;
@@ -1009,6 +1011,7 @@ int wgrad8_ntiles(int CA, int CBp, int N, int H, int W, bool bf16) {
 template <typename T, int WCO, int WCI, int WPIX, int TH, int TWT, int STREAM = 0>
 static int launch_w8(WgradArgs a, hipStream_t st) {
     a.xcd = eld_xcd_mask() & XCD_WGRAD8;
+    a.band = eld_tile_band();
     constexpr int COB = 32 * WCO, JBK = 32 * WCI;
     a.vp = vrow_pitch(a.N, a.H, TH);
     a.tiles_x = (a.W + TWT - 1) / TWT;
@@ -1029,6 +1032,7 @@ static int launch_w8(WgradArgs a, hipStream_t st) {
 template <int WCO, int WCI, int WPIX, int TH, int TWT>
 static int launch_w8d(WgradArgs a, hipStream_t st) {
     a.xcd = eld_xcd_mask() & XCD_WGRAD8;
+    a.band = eld_tile_band();
     constexpr int COB = 32 * WCO, JBK = 32 * WCI;
     a.vp = vrow_pitch(a.N, a.H, TH);
     a.tiles_x = (a.W + TWT - 1) / TWT;

@@ -1118,6 +1118,11 @@ int eld_xcd_mask() {
     return m;
 }
 
+int eld_tile_band() {
+    static const int b = [] { const char* e = getenv("ELD_TILE_BAND"); return e ? atoi(e) : 4; }();
+    return b;
+}
+
 // a: fp32 CONV_3X3 arguments already validated by launch_conv
 int launch_conv_x3(const ConvArgs& a_in, hipStream_t st) {
     ConvArgs a = a_in;

@@ -71,7 +71,8 @@ __global__ __launch_bounds__(64 * (W_CW + W_PW), (W_CW + W_PW) / 4) void conv_x3
     auto decode = [&](int t, int& img, int& y0, int& x0) {
         img = t / tiles_img;
         const int r = t - img * tiles_img;
-        const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
+        int ty, tx;
+        band_tile(r, a.tiles_x, a.tiles_y, a.band, ty, tx);
         y0 = ty * W_TH; x0 = tx * TW;
     };
 
@@ -393,6 +394,7 @@ void conv_x3_set_prof(unsigned long long* buf) { g_x3w_prof = buf; }      // dev
 int launch_conv_x3w(const ConvArgs& a_in, hipStream_t st) {
     ConvArgs a = a_in;
     a.xcd = eld_xcd_mask() & XCD_X3W;
+    a.band = eld_tile_band();
     a.prof = ELD_DEV_TOOLS ? g_x3w_prof : nullptr;
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + W_TH - 1) / W_TH;

@@ -268,7 +268,8 @@ void eld_debug_conv_prof(void* buf);
  * BIT-IDENTICAL results from the two kernel families on the same inputs (same k order, same MFMA): mask bit 0 = conv_bfs_kernel (32-output-channel
  * 3x3 layers) off, bit 1 = conv_bfg_kernel (transposed convolutions) off, bit 2 = conv_bfd_kernel (the other bf16 3x3 layers) off, bit 3 = conv_bfw_kernel off (the 64-output-channel layers with K <= 64 then run on conv_bfd_kernel<64>; conv_bfw sums K in another order, so it equals the others up to fp32 summation order, not bit for bit), bit 4 = wgrad8d_kernel off (the bf16 weight gradient of the 128 x 64 blocks then runs the register-staged wgrad8_kernel<bf16>: other tile shape, so equal up to the fp32 summation order over pixels); bit 5 = eld_quality_assess with one window column per lane instead of two, bit 6 = eld_quality_assess on the round-2 tile kernels (three
  * implementations of the same sums: tests/test_model_gpu.py runs the oracle comparison under each); bit 7 = the U-Net forwards write no slope codes (the backward-data
- * epilogues of levels 0 / 1 then read the saved activations, as before round 5: same slopes, bit-identical gradients).  Returns the previous mask.  Process-wide; production never calls it. */
+ * epilogues of levels 0 / 1 then read the saved activations, as before round 5: same slopes, bit-identical gradients); bit 8 = no pool-argmax codes
+ * (the backward of the two full-size pools then reads the saved un-pooled tensors: same winners, bit-identical gradients).  Returns the previous mask.  Process-wide; production never calls it. */
 int eld_debug_kernel_mask(int mask);
 /* Test hook: live entries of the per-workspace host bookkeeping (which forward last filled a workspace: fused head, slope codes); bounded, evicted
  * one least-recently-touched entry at a time. */
