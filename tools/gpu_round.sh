@@ -9,6 +9,10 @@
 #   ablib <prec> <kernel,patterns> <lib>...  same-box A/B of library builds (tools/gpu_ab.sh; tools/build_variant.sh makes them)
 #   ablate [dbg,list]                        tools/conv_ablate.py on the dev library (tools/build_dev.sh first)
 #   x3wprof                                  tools/x3w_prof.py on the dev library: stage timeline of conv_x3w_kernel
+#   ablatet [dbg,list]                       tools/convt_ablate.py on the dev library: the transposed convolutions
+#   clock <env>...                           effective shader clock per kernel under environment settings (tools/gpu_clock_env.sh)
+#   switches                                 the U-Net / parity tests under every A/B switch (tools/gpu_switch_matrix.sh)
+#   evidence                                 the round's evidence set (tools/gpu_round_evidence.sh <tag>; then tools/profile_collect.sh <tag> <round>)
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 T=$1; STEP=$2; shift 2
@@ -23,5 +27,9 @@ import json; r = json.load(open('$O/bench.json')); print(r['value'], r['ms_per_s
   ablib) K=$2; P=$1; shift 2; bash tools/gpu_ab.sh $T $K $P "$@" | tee $O/ablib.txt ;;
   ablate) ABLATE_DBGS=${1:-0,64,1,2,3,4,16,8,5,18} ELD_AMD_LIB=$GRAFT_REPO_ROOT/tools/probe/libeld_dev.so timeout 1500 python tools/conv_ablate.py 8 2>&1 | tee $O/ablate.txt ;;
   x3wprof) ELD_AMD_LIB=$GRAFT_REPO_ROOT/tools/probe/libeld_dev.so timeout 600 python tools/x3w_prof.py 2>&1 | tee $O/x3wprof.txt ;;
+  ablatet) ABLATE_DBGS=${1:-0,1,2,3,4,16,18,20,22} ELD_AMD_LIB=$GRAFT_REPO_ROOT/tools/probe/libeld_dev.so timeout 900 python tools/convt_ablate.py 8 2>&1 | tee $O/ablatet.txt ;;
+  clock) bash tools/gpu_clock_env.sh $T "$@" | tee $O/clock.txt ;;
+  switches) bash tools/gpu_switch_matrix.sh | tee $O/switches.txt ;;
+  evidence) bash tools/gpu_round_evidence.sh $T ;;
   *) echo "unknown step $STEP"; exit 2 ;;
 esac
