@@ -1,6 +1,6 @@
 #!/bin/bash
 # The ONE parametrised GPU driver of the dev loop (rounds 4-6 each left a dozen one-off gpu_rNx.sh scripts: they are in git history, this replaces them).
-#   gpurun --timeout 3600 -- "bash tools/gpu_round.sh <tag> <step> [args...]"      steps may be chained with '+': tests+abenv ...
+#   gpurun --timeout 3600 -- "bash tools/gpu_round.sh <tag> <step> [args...]"
 # steps:
 #   tests [pytest args]                      pytest -m gpu -q -x (default: the whole suite)
 #   bench                                    the driver's command (python bench.py) -> gpurun_out/<tag>/bench.json, headline printed
