@@ -430,6 +430,9 @@ int launch_wgrad(const WgradArgs& a, int mode, hipStream_t st);
 bool wgrad8_shape(int CA, int CBp, int& COB, int& JB, int& TH, int& TWo, bool bf16 = false);
 // spatial tiles wgrad8_kernel walks for a layer (TH x TWo tiles over the virtual-row strip of the batch); 0 if the layer is not on wgrad8_kernel
 int wgrad8_ntiles(int CA, int CBp, int N, int H, int W, bool bf16);
+// transposed convs' weight gradient on the 8-wave kernel (wgradt8_kernel: fp32 three-piece scheme, 128 x 64 blocks, 8 x 8-pixel tiles per image)
+bool wgradt8_takes(int CA, int CB);
+int wgradt8_ntiles(int N, int H, int W);
 // out[(i*CBr + j)*T + tap] = sum_s part[s][tap][i][j]   (OIHW / (Cin,Cout,2,2) layouts);  bgrad[i] = sum_s bpart[s][i]
 int launch_wgrad_reduce(const float* part, const float* bpart, float* wgrad, float* bgrad, int psplit, int T, int CA,
                         int CBp, int CBr, hipStream_t st, int bias_n = 0);      // bias_n > 0: bpart is [psplit][bias_n] (default [psplit][CA])

@@ -984,6 +984,187 @@ static int wgrad8_dma() {
     static const int on = [] { const char* e = getenv("ELD_WGRAD_DMA"); return e ? (int)(atoi(e) != 0) : 1; }();
     return on && !(debug_kernel_mask(-1) & 16);      // test hook (eld_debug_kernel_mask bit 4): back on the register-staged kernel
 }
+// =============================================================================================================================
+// wgradt8_kernel (round 6) -- the transposed convolutions' weight gradient, dW[ci][tap][co] = sum_p in[p][ci] * dout[2p + tap][co] (fp32 inputs, three-piece
+// scheme), re-blocked like wgrad8_kernel: ONE 8-wave workgroup per CU, output block 128 (ci) x 64 (co) x 4 taps, a wave owns a 32 x 32 tile of all four taps
+// (64 accumulator registers) and walks the 8 x 8-pixel tiles of its pixel slice.  Against wgrad_kernel<float, CONV_GATHER2X2, 2, 2, ALG_X3> (64 x 32 blocks,
+// 4 waves): a staged value feeds twice the MFMAs (12 operand cuts per thread per 96 MFMAs instead of per 48), one workgroup per CU instead of two.
+// dout has no halo here: every dout pixel belongs to exactly one (pixel, tap), so the X tile is four tap planes of the tile's 64 pixels, [piece][32-ch block][tap]
+// [pixel][32] -- each plane reads exactly like the G tile.  Tiles never straddle images.  Partials / bias column sums / reduction as wgrad_kernel's.
+// C0 % 64 == 0 (no channel padding), CA % 128 == 0.
+template <int DUMMY>
+__global__ __launch_bounds__(512, 2) void wgradt8_kernel(const WgradArgs a) {
+    constexpr int WCO = 4, WCI = 2, TH = 8, TWT = 8, TPIX = TH * TWT, THREADS = 512, TAPS = 4, NPC = 3;
+    constexpr int COB = 32 * WCO, JBK = 32 * WCI, KSB = TPIX / 16;
+    constexpr int GBLK = TPIX * 32 + 32;                              // one pad row per 32-channel block of G (see wgrad8_kernel)
+    constexpr int GPL = GBLK * WCO, X_PIX = TAPS * TPIX, XPL = X_PIX * JBK;
+    constexpr int G_IT = TPIX * (COB / 4) / THREADS, X_IT = X_PIX * 8 / THREADS;      // 4 and 4 (per 32-channel block of X)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    bf16_t* ldsG = reinterpret_cast<bf16_t*>(lds);                    // [3][WCO][GBLK]
+    bf16_t* ldsX = ldsG + NPC * GPL;                                  // [3][WCI][X_PIX][32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 31, hi = lane >> 5;
+    const int wco = wave % WCO, wci = wave / WCO;
+    const int IB = a.CA / COB, JBn = a.CBp / JBK;
+    int bid = xcd_block(a.xcd);
+    const int jb = bid % JBn; bid /= JBn;
+    const int ib = bid % IB;
+    const int ps = bid / IB;
+    const int i0 = ib * COB, j0 = jb * JBK;
+    const bool xsum_on = a.xbpart != nullptr && ib == 0;
+    const int Wx = 2 * a.W, CB = a.C0;
+
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    float4 xs4[WCI];
+#pragma unroll
+    for (int cb = 0; cb < WCI; ++cb) xs4[cb] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const int tiles_per_img = a.tiles_x * a.tiles_y, ntiles = tiles_per_img * a.N;
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    // staging constants: G unit u = tid + it * 512 -> pixel lp = u / 32 (= tid / 32 + 16 it), channel quad u % 32 (the same for every it);
+    // X unit (per 32-channel block) u -> (tap, pixel) = u / 8 (= tid / 8 + 64 it: tap = it), quad u % 8
+    const int g_part = tid & 31, g_lp0 = tid >> 5, x_part = tid & 7, x_lp = tid >> 3;
+    const int x_py = x_lp / TWT, x_px = x_lp - x_py * TWT;
+    float4 rg[G_IT], rx[WCI][X_IT];
+    const size_t g_img = (size_t)a.H * a.W * a.CA * 4, x_img = (size_t)4 * a.H * a.W * CB * 4;
+    auto load_tile = [&](int tile) {
+        const int img = tile / tiles_per_img;
+        int ty, tx;
+        band_tile(tile - img * tiles_per_img, a.tiles_x, a.tiles_y, a.band, ty, tx);
+        const int y0 = ty * TH, x0 = tx * TWT;
+        const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)(static_cast<const char*>(a.g) + (size_t)img * g_img), 0, (int)g_img, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)(static_cast<const char*>(a.x0) + (size_t)img * x_img), 0, (int)x_img, 0x00020000);
+#pragma unroll
+        for (int it = 0; it < G_IT; ++it) {
+            const int lp = g_lp0 + 16 * it, py = lp / TWT, px = lp - py * TWT;
+            const int gy = y0 + py, gx = x0 + px;
+            const unsigned off = (gy < a.H && gx < a.W) ? (unsigned)(((gy * a.W + gx) * a.CA + i0 + g_part * 4) * 4) : OOB;
+            rg[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, (int)off, 0, 0));
+        }
+        const bool pok = y0 + x_py < a.H && x0 + x_px < a.W;
+#pragma unroll
+        for (int cb = 0; cb < WCI; ++cb)
+#pragma unroll
+            for (int it = 0; it < X_IT; ++it) {                       // it = tap
+                const int gy = 2 * (y0 + x_py) + (it >> 1), gx = 2 * (x0 + x_px) + (it & 1);
+                const unsigned off = pok ? (unsigned)(((gy * Wx + gx) * CB + j0 + cb * 32 + x_part * 4) * 4) : OOB;
+                rx[cb][it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)off, 0, 0));
+            }
+    };
+    auto put3 = [&](bf16_t* d, int plane_elems, const float4& raw) {       // the exact three-piece cut of conv_x3_dev.h split_store
+        const unsigned x0 = __float_as_uint(raw.x), x1 = __float_as_uint(raw.y), x2 = __float_as_uint(raw.z), x3 = __float_as_uint(raw.w);
+        const float r0 = raw.x - __uint_as_float(x0 & 0xFFFF0000u), r1 = raw.y - __uint_as_float(x1 & 0xFFFF0000u);
+        const float r2 = raw.z - __uint_as_float(x2 & 0xFFFF0000u), r3 = raw.w - __uint_as_float(x3 & 0xFFFF0000u);
+        const unsigned y0 = __float_as_uint(r0), y1 = __float_as_uint(r1), y2 = __float_as_uint(r2), y3 = __float_as_uint(r3);
+        const unsigned z0 = __float_as_uint(r0 - __uint_as_float(y0 & 0xFFFF0000u)), z1 = __float_as_uint(r1 - __uint_as_float(y1 & 0xFFFF0000u));
+        const unsigned z2 = __float_as_uint(r2 - __uint_as_float(y2 & 0xFFFF0000u)), z3 = __float_as_uint(r3 - __uint_as_float(y3 & 0xFFFF0000u));
+        auto hp = [](unsigned lo, unsigned hi_) { return __builtin_amdgcn_perm(hi_, lo, 0x07060302u); };
+        *reinterpret_cast<uint2*>(d) = make_uint2(hp(x0, x1), hp(x2, x3));
+        *reinterpret_cast<uint2*>(d + plane_elems) = make_uint2(hp(y0, y1), hp(y2, y3));
+        *reinterpret_cast<uint2*>(d + 2 * plane_elems) = make_uint2(hp(z0, z1), hp(z2, z3));
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < G_IT; ++it)
+            put3(ldsG + ((g_part * 4) >> 5) * GBLK + (g_lp0 + 16 * it) * 32 + ((g_part * 4) & 31), GPL, rg[it]);
+#pragma unroll
+        for (int cb = 0; cb < WCI; ++cb)
+#pragma unroll
+            for (int it = 0; it < X_IT; ++it) {
+                put3(ldsX + (cb * X_PIX + it * TPIX + x_lp) * 32 + x_part * 4, XPL, rx[cb][it]);
+                if (xsum_on) { xs4[cb].x += rx[cb][it].x; xs4[cb].y += rx[cb][it].y; xs4[cb].z += rx[cb][it].z; xs4[cb].w += rx[cb][it].w; }      // (out-of-image units loaded zeros)
+            }
+    };
+    // fragment addresses (wgrad8_kernel): a 16-lane group reads a [4 pixels][16 channels] block per ds_read_b64_tr_b16
+    const int gi = lane & 15, gg = lane >> 4;
+    const int lq0 = 8 * hi + (gi >> 2);
+    const bf16_t* gq = ldsG + wco * GBLK + lq0 * 32 + (gg & 1) * 16 + (gi & 3) * 4;
+    const bf16_t* xq = ldsX + (wci * X_PIX + lq0) * 32 + (gg & 1) * 16 + (gi & 3) * 4;
+    auto tr8 = [](const bf16_t* p0) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+        const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 4 * 32));
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+
+    if (ps < ntiles) load_tile(ps);
+    for (int tile = ps; tile < ntiles; tile += a.psplit) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        if (tile + a.psplit < ntiles) load_tile(tile + a.psplit);
+#pragma unroll
+        for (int ks = 0; ks < KSB; ++ks) {
+            bf16x8 ga[NPC];
+#pragma unroll
+            for (int pc = 0; pc < NPC; ++pc) ga[pc] = tr8(gq + pc * GPL + ks * 16 * 32);
+#pragma unroll
+            for (int t0 = 0; t0 < TAPS; t0 += 2) {
+                bf16x8 xb[2][NPC];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                    for (int pc = 0; pc < NPC; ++pc) xb[tt][pc] = tr8(xq + pc * XPL + ((t0 + tt) * TPIX + ks * 16) * 32);
+                constexpr int GI[6] = {0, 1, 2, 0, 1, 0};
+                constexpr int XI[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+                for (int q = 0; q < 6; ++q)
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+                        acc[t0 + tt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[GI[q]], xb[tt][XI[q]], acc[t0 + tt], 0, 0, 0);
+            }
+        }
+    }
+    // ---- the partial of this block -------------------------------------------------------------------------------------
+    const size_t pbase = (size_t)ps * TAPS * a.CA * a.CBp;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * hi;
+            a.part[pbase + ((size_t)t * a.CA + i0 + wco * 32 + row) * a.CBp + j0 + wci * 32 + m] = acc[t][i];
+        }
+    if (xsum_on) {                                                    // block-uniform: column sums of dout over this block's pixels; 64 threads hold each channel quad, fixed-order combine
+        __syncthreads();
+        float4* r = reinterpret_cast<float4*>(lds);                   // [WCI][512]
+#pragma unroll
+        for (int cb = 0; cb < WCI; ++cb) r[cb * THREADS + tid] = xs4[cb];
+        __syncthreads();
+        if (tid < JBK) {
+            const int cb = tid >> 5, c = tid & 31, quad = c >> 2, comp = c & 3;
+            float s_ = 0.f;
+            for (int k = 0; k < THREADS / 8; ++k) s_ += reinterpret_cast<const float*>(&r[cb * THREADS + quad + 8 * k])[comp];
+            a.xbpart[(size_t)ps * a.CBp + j0 + tid] = s_;
+        }
+    }
+}
+
+bool wgradt8_takes(int CA, int CB) {
+    static const int on = [] { const char* e = getenv("ELD_WGRADT8"); return e ? atoi(e) : 1; }();      // ELD_WGRADT8=0: the transposed convs' weight gradient stays on wgrad_kernel
+    return on && CA % 128 == 0 && CB % 64 == 0;
+}
+int wgradt8_ntiles(int N, int H, int W) { return ((W + 7) / 8) * ((H + 7) / 8) * N; }
+
+static int launch_wt8(WgradArgs a, hipStream_t st) {
+    a.xcd = eld_xcd_mask() & XCD_WGRAD8;
+    a.band = eld_tile_band();
+    a.tiles_x = (a.W + 7) / 8;
+    a.tiles_y = (a.H + 7) / 8;
+    const size_t lds_bytes = (size_t)(3 * 4 * (64 * 32 + 32) + 3 * 2 * 256 * 32) * 2;
+    const long long blocks = (long long)(a.CA / 128) * (a.CBp / 64) * a.psplit;
+    if (blocks <= 0) return 0;
+    if ((size_t)4 * a.H * a.W * a.C0 * 4 >= 0xFFFFFFF0ull || (size_t)a.H * a.W * a.CA * 4 >= 0xFFFFFFF0ull) return ELD_ENOTSUP;
+    auto kern = wgradt8_kernel<0>;
+    static EldAttrOnce once;
+    { const int rc = once.ensure(kern, lds_bytes); if (rc) return rc; }
+    ELD_LAUNCH(kern, dim3((unsigned)blocks), dim3(512), lds_bytes, st, a);
+    ELD_LAUNCH_CHECK();
+    return 0;
+}
+
 bool wgrad8_shape(int CA, int CBp, int& COB, int& JBK, int& TH, int& TWo, bool bf16) {
     if (CA % 32 || CBp % 32) return false;
     TWo = 32;
@@ -1148,6 +1329,7 @@ int launch_wgrad(const WgradArgs& a, int mode, hipStream_t st) {
     }
     if (mode == CONV_3X3 && algo == 1) return c64 ? launch_w<float, CONV_3X3, 2, 2, ALG_X3>(a, st) : launch_w<float, CONV_3X3, 1, 2, ALG_X3>(a, st);
     if (mode == CONV_3X3) return c64 ? launch_w<float, CONV_3X3, 2, 4>(a, st) : launch_w<float, CONV_3X3, 1, 4>(a, st);
+    if (mode == CONV_GATHER2X2 && algo == 1 && a.wgrad8 && a.C1 == 0 && a.C0 == a.CBp && wgradt8_takes(a.CA, a.C0)) return launch_wt8(a, st);      // partials sized for the 128 x 64 blocks (unet.hip wgrad_geom)
     if (mode == CONV_GATHER2X2 && algo == 1) return c64 ? launch_w<float, CONV_GATHER2X2, 2, 2, ALG_X3>(a, st) : launch_w<float, CONV_GATHER2X2, 1, 2, ALG_X3>(a, st);
     if (mode == CONV_GATHER2X2) return c64 ? launch_w<float, CONV_GATHER2X2, 2, 2>(a, st) : launch_w<float, CONV_GATHER2X2, 1, 2>(a, st);
     return ELD_EINVAL;

@@ -80,6 +80,17 @@ WgradGeom wgrad_geom(int mode, int CA, int CB, int N, int H, int W, int algo) {
         g.floats = (size_t)g.psplit * ((size_t)g.T * CA * g.CBp + CA);
         return g;
     }
+    // algo 1, transposed convs with >= 128 x 64 channels: wgradt8_kernel (one 8-wave workgroup per CU, 128 x 64 blocks, 8 x 8-pixel tiles per image)
+    if (algo == 1 && mode == CONV_GATHER2X2 && CB == g.CBp && wgradt8_takes(CA, CB)) {
+        g.w8 = 1;
+        g.groups = (CA / 128) * (g.CBp / 64);
+        g.ntiles = wgradt8_ntiles(N, H, W);
+        int ps = 256 / g.groups;
+        if (ps > g.ntiles) ps = g.ntiles;
+        g.psplit = ps < 1 ? 1 : ps;
+        g.floats = (size_t)g.psplit * ((size_t)g.T * CA * g.CBp + CA);
+        return g;
+    }
     const int COB = (CA % 64 == 0) ? 64 : 32;
     const int TH = mode == CONV_3X3 ? 4 : 2;
     g.groups = (CA / COB) * (g.CBp / 32);
@@ -164,10 +175,10 @@ int convt_bwd_data(const float* dout, const float* wb, const float* act, float* 
 
 // dw[ci][co][tap] = sum in[p][ci] * dout[gather(p,tap)][co];  db[co] = column sums of dout
 int convt_wgrad(const float* in, const float* dout, float* dw, float* db, float* part, int N, int H, int W, int Cin, int Cout, hipStream_t st) {
-    const WgradGeom q = wgrad_geom(CONV_GATHER2X2, Cin, Cout, N, H, W, 0);
+    const WgradGeom q = wgrad_geom(CONV_GATHER2X2, Cin, Cout, N, H, W, g_algo == 1 ? 1 : 0);
     WgradArgs a = {};
     a.g = in; a.CA = Cin; a.x0 = dout; a.C0 = Cout; a.N = N; a.H = H; a.W = W;
-    a.part = part; a.bpart = nullptr; a.CBp = q.CBp; a.psplit = q.psplit;
+    a.part = part; a.bpart = nullptr; a.CBp = q.CBp; a.psplit = q.psplit; a.wgrad8 = q.w8;
     // bias gradient = column sums of dout: accumulated by the weight-gradient kernel from its staging registers (every dout pixel
     // passes through exactly once per block column); the partials take the plan's bias slot (psplit * CA floats >= psplit * CBp)
     const bool fused_bias = db != nullptr && q.CBp <= q.CA && Cout == q.CBp;
@@ -252,7 +263,11 @@ int make_plan(Plan& P, int N, int H, int W, int in_ch, int out_ch) {
             f = f1 > f ? f1 : f;
             const size_t f3 = wgrad_geom(CONV_3X3, d.cout, i == L_E0A ? 16 : d.cin, N, P.Hl[lev], P.Wl[lev], 3).floats;
             f = f3 > f ? f3 : f;
-        } else if (d.kind == 1) f = wgrad_geom(CONV_GATHER2X2, d.cin, d.cout, N, P.Hl[lev + 1], P.Wl[lev + 1], 0).floats;
+        } else if (d.kind == 1) {
+            f = wgrad_geom(CONV_GATHER2X2, d.cin, d.cout, N, P.Hl[lev + 1], P.Wl[lev + 1], 0).floats;
+            const size_t f1 = wgrad_geom(CONV_GATHER2X2, d.cin, d.cout, N, P.Hl[lev + 1], P.Wl[lev + 1], 1).floats;
+            f = f1 > f ? f1 : f;
+        }
         pmax = f > pmax ? f : pmax;
     }
     // split-K partial sums of small problems share this region: up to 16 parts of the largest 3x3 output that can take the split
@@ -891,7 +906,7 @@ extern "C" size_t eld_layer_workspace_bytes(int N, int H, int W, int Cin, int Co
     size_t f = (size_t)9 * Cout * cinp * 2 + 64;                            // one packed weight set (fp32 or pre-split slabs)
     size_t p = 0, q;
     if (Cout % 32 == 0) { q = wgrad_geom(CONV_3X3, Cout, Cin, N, H, W, 0).floats; p = q > p ? q : p; q = wgrad_geom(CONV_3X3, Cout, Cin, N, H, W, 1).floats; p = q > p ? q : p; }
-    if (Cin % 32 == 0) { q = wgrad_geom(CONV_GATHER2X2, Cin, Cout, N, H, W, 0).floats; p = q > p ? q : p; }
+    if (Cin % 32 == 0) { q = wgrad_geom(CONV_GATHER2X2, Cin, Cout, N, H, W, 0).floats; p = q > p ? q : p; q = wgrad_geom(CONV_GATHER2X2, Cin, Cout, N, H, W, 1).floats; p = q > p ? q : p; }
     q = colsum_ws_floats(Cout > Cin ? Cout : Cin); p = q > p ? q : p;
     return (align_up(f, 64) + align_up(p, 64) + 64) * sizeof(float);      // + 64 operand-bound slots (conv_fp32_algo 2)
 }
